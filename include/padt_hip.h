@@ -1,0 +1,109 @@
+/* padt_hip.h — C ABI of libpadt_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for PaDT's
+ * generate-with-Visual-Reference-Tokens hot path.
+ *
+ * The reference (Gorilla-Lab-SCUT/PaDT) has no native boundary: every kernel is reached through a third-party Python
+ * call (torch ATen/BLAS, flash-attn).  Each entry below names the reference call site(s) it replaces (file:line into
+ * the reference repo; "HF:" = transformers models/qwen2_5_vl/modeling_qwen2_5_vl.py as cited in SURVEY.md).
+ *
+ * Conventions
+ *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates nothing and keeps no hidden
+ *     state (work buffers are caller-provided; sizes from the *_workspace/_nblk query functions).
+ *   - All pointers are device pointers.  bf16 = raw 16-bit brain floats.  Strides (`ld*`) are in ELEMENTS.
+ *   - Return 0 on success, -1 for rejected arguments, -2 for a HIP launch error; text via padt_last_error().
+ *   - Row-major everywhere; weights in nn.Linear layout [out_features][in_features].
+ */
+#ifndef PADT_HIP_H
+#define PADT_HIP_H
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---- plumbing --------------------------------------------------------------------------------------------------- */
+int         padt_abi_version(void);
+const char* padt_last_error(void);
+int         padt_device_info(int device, char* name, int name_len, int* n_cu, long* hbm_bytes);
+int         padt_memset(void* stream, void* dst, int value, long bytes);
+int         padt_event_create(void** ev);
+int         padt_event_record(void* ev, void* stream);
+int         padt_event_elapsed_ms(void* start, void* stop, float* ms);
+int         padt_event_destroy(void* ev);
+
+/* ---- GEMM: C[M,N] = epi(A[M,K] · W[N,K]^T + bias) ------------------------------------------------------------------
+ * epilogue: 0 none, 1 exact-erf GELU, 2 += R (residual), 3 SwiGLU (W rows interleaved gate16|up16; C has N/2 columns).
+ * out_f32: C is float instead of bf16.  M <= 64 takes the weight-streaming (HBM-bound) kernel, else the 128x128x64
+ * LDS-DMA MFMA tile kernel.  Replaces every nn.Linear / Conv3d-as-GEMM: HF:116-122 (patch embed), HF:219-220,85-96,
+ * 141-151 (ViT qkv/proj/MLP/merger), HF:630-633,545-553 (LLM), padt.py:189 (vis_proj), padt_decoder.py:15-18,82-86,
+ * 142-184 (decoder projections, MLPs, heads). */
+int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
+                   const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32);
+
+/* ---- attention ------------------------------------------------------------------------------------------------------
+ * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
+ * q: token t head h at q + t*ldq + h*head_dim (k, v likewise with kv head h / (n_heads/n_kv_heads)).
+ * Replaces flash_attn_varlen_func at padt_decoder.py:55 and in HF's ViT (HF:225-291) / LLM prefill (HF:641-689). */
+int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
+                     long ldo, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int n_heads,
+                     int n_kv_heads, int head_dim, float scale, int causal);
+/* Single-token decode attention over the KV cache (K row-major [B][Hkv][S_max][D], V transposed [B][Hkv][D][S_max]),
+ * split over 64-key chunks + combine.  lens[b] = valid keys incl. the token just appended; max_len bounds them.
+ * Replaces the Lq==1 case of HF:641-689 with DynamicCache. */
+long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max);
+int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens, void* out,
+                      void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, int max_len,
+                      float scale);
+
+/* ---- row kernels ---------------------------------------------------------------------------------------------------- */
+/* y = act(w * (x [+ add[row/add_div]]) * rsqrt(mean(.^2)+eps)), act: 0 none, 1 exact GELU.
+ * HF:74-79; padt_decoder.py:71-74,143,156,168-172,220. */
+int padt_rmsnorm(void* stream, const void* x, long ldx, const void* add, long ld_add, int add_div, const void* w, void* y,
+                 long ldy, long rows, long D, float eps, int act);
+/* nn.LayerNorm (vis_norm), padt.py:121,188. */
+int padt_layernorm(void* stream, const void* x, long ldx, const void* w, const void* b, void* y, long ldy, long rows,
+                   long D, float eps);
+/* in-place rotate-half rotary over n_heads consecutive heads; fp32 cos/sin tables [T][ld_cs] (first head_dim/2 cols).
+ * HF:160-171 (ViT q,k), padt_decoder.py:38-51 (decoder image side). */
+int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T, int n_heads,
+                   int head_dim);
+/* dst[i] = src[idx[i]] (bf16 / f32 rows).  padt.py:70-75,103-104 (window order), padt.py:365-373 (per-object copies). */
+int padt_gather_rows(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D);
+int padt_gather_rows_f32(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D);
+/* y = a + b[row % b_rows].  padt_decoder.py:30-31 (additive positional queries), :202 (vp_embedding). */
+int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y, long ldy, long n,
+                  long D);
+/* fp32 → bf16 with zero-padded row tail (pixel_values.type(visual.dtype), padt.py:184). */
+int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad);
+/* in-place fp32 sigmoid (bbox head, padt_decoder.py:164). */
+int padt_sigmoid_f32(void* stream, void* x, long n);
+/* inputs_embeds from the two-pointer table [E ‖ proto] + image-embed scatter.  padt.py:193-219, 226-229.
+ * err_flag (optional) is set to 1 when an id falls outside the table (padt.py:203 assert). */
+int padt_embed_tokens(void* stream, const long* ids, const int* img_index, const void* embed_table, const void* proto,
+                      const void* image_embeds, void* out, long T, long vocab, long n_proto, long D, int* err_flag);
+/* mRoPE on q,k + KV-cache append (K row-major, V transposed) (+ packed roped K for prefill attention).
+ * HF:557-599 (apply_multimodal_rotary_pos_emb), HF:665-666 (cache update), padt.py:256-277 (positions). */
+int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample, const int* slot,
+                      const int* lens, const void* inv_freq, void* q_out, long ld_q, void* k_pack, long ld_kp,
+                      void* k_cache, void* vt_cache, long T, int n_heads, int n_kv_heads, int head_dim, int s_max,
+                      int sec0, int sec1);
+/* PaDT mask head tail: per-patch 4x4 dot with the object's mask token, scattered to (n_obj, 4H, 4W) fp32.
+ * padt_decoder.py:241-274. */
+int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
+                      const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm);
+
+/* ---- VRT head + greedy bookkeeping ------------------------------------------------------------------------------------
+ * logits = hidden · [embed_table ‖ proto]^T through two base pointers, -inf outside text ∪ own patch rows, per-block
+ * (max, argmax) partials; optional dense fp32 logits.  padt.py:292-301.  mode_table/step: scripted logits-processor
+ * slot for synthetic weights (0 free, 1 text rows, 2 own VRT rows, 3 force EOS), padt.py:717. */
+long padt_vrt_head_nblk(long vocab, long n_proto);
+int  padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab, const void* proto,
+                   long n_proto, const int* vrt_off, const int* mode_table, const int* step, void* logits_f32,
+                   long ld_logits, void* part_val, void* part_idx, long batch, long D, int eos);
+/* argmax reduction (ties → lowest id), pad/EOS bookkeeping, token append, hidden-row stash, slot/len/position/step
+ * advance — all on device.  padt.py:745-757, 732-737. */
+int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D, int eos,
+                      int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok, int* step, int* slot,
+                      int* lens, int* pos3, const void* hidden, void* hidden_buf, int advance);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PADT_HIP_H */

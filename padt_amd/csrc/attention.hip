@@ -1,0 +1,396 @@
+// Varlen flash attention (prefill-style) and split-KV decode attention for gfx950, bf16 MFMA 16x16x32, fp32 softmax.
+//
+// attn_varlen_kernel<D, CAUSAL>: one block (4 waves) = 64 query rows of one (segment, head); K/V tiles of 64 keys are
+//   staged in LDS — K row-major (padded rows, conflict-free ds_read_b128), V TRANSPOSED (MFMA wants both operands
+//   contiguous along the contraction index, which for P·V is the key index).  Online softmax lives in the MFMA C layout
+//   (lane owns 4 rows x 1 column per 16x16 block → row reductions are 4 xor-shuffles inside 16-lane groups); P goes
+//   through a wave-private LDS strip to become an A fragment.  Never materialises S.
+//   Replaces flash_attn_varlen_func at: HF ViT attention (28 window layers: 36 segments/img of 64/48/36 tokens; 4 full
+//   layers: one 2116-token segment/img), LLM prefill (causal, GQA 16:2, d=128) and PaDTDecoderFlashAttention2.forward
+//   (padt_decoder.py:55: query↔query, query→image, image→query; d=80).
+// decode_attn_kernel: one wave per (64-key split, kv head, sample); the GQA group's q heads are the 16 MFMA rows; K is
+//   read straight from the row-major K cache, V from the TRANSPOSED V cache (both 16-byte fragment loads, no LDS
+//   staging: nothing is shared between waves); partial (m, l, O) per split are merged by decode_combine_kernel.
+#include "common.h"
+
+struct AttnArgs {
+    const bf16_t* q; long ldq;      // token stride (elements); head h at +h*D
+    const bf16_t* k; long ldk;      // kv head g at +g*D
+    const bf16_t* v; long ldv;
+    bf16_t* o; long ldo;
+    const int* cu_q; const int* cu_k;
+    int group;                      // q heads per kv head
+    float scale_log2;               // softmax scale * log2(e)
+};
+
+template <int D> struct AttnCfg {
+    static constexpr int KQ = (D + 31) / 32;          // k-steps for QK^T
+    static constexpr int NB = D / 16;                 // 16-wide d blocks for PV
+    static constexpr int KROW = D + 8;                // padded K row (elements)
+    static constexpr int VROW = 64 + 8;               // padded V^T / P row (elements)
+    static constexpr int K_BYTES = 64 * KROW * 2;
+    static constexpr int V_BYTES = D * VROW * 2;
+    static constexpr int P_BYTES = 4 * 16 * VROW * 2;
+    static constexpr int LDS = K_BYTES + V_BYTES + P_BYTES;
+};
+
+template <int D, bool CAUSAL>
+__global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
+    using C = AttnCfg<D>;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
+    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + C::K_BYTES);
+    bf16_t* Ps = reinterpret_cast<bf16_t*>(smem + C::K_BYTES + C::V_BYTES);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int seg = blockIdx.z, h = blockIdx.y, tile = blockIdx.x;
+    const int q_beg = p.cu_q[seg], Lq = p.cu_q[seg + 1] - q_beg;
+    const int k_beg = p.cu_k[seg], Lk = p.cu_k[seg + 1] - k_beg;
+    if (tile * 64 >= Lq) return;
+    const int hk = h / p.group;
+    const int shift = Lk - Lq;                                    // causal: key j visible to query i iff j <= i + shift
+
+    // ---- Q fragments (A operand): row = this wave's 16 query rows
+    const int qrow = tile * 64 + wave * 16 + frow;                // row inside the segment
+    bf16x8 qf[C::KQ];
+#pragma unroll
+    for (int kk = 0; kk < C::KQ; ++kk) {
+        const int d = kk * 32 + fq * 8;
+        qf[kk] = (qrow < Lq && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + h * D + d) : zero_frag();
+    }
+
+    f32x4 o[C::NB];
+#pragma unroll
+    for (int i = 0; i < C::NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float m_run[4], l_run[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
+
+    int nkt = (Lk + 63) / 64;
+    if (CAUSAL) {
+        const int last = tile * 64 + 63 + shift;                  // last visible key for this tile
+        int lim = last < 0 ? 0 : (last / 64 + 1);
+        nkt = lim < nkt ? lim : nkt;
+    }
+    bf16_t* Pw = Ps + wave * 16 * C::VROW;
+    constexpr int CPR = D / 8;                                    // 16-byte chunks per K/V row
+
+    for (int kt = 0; kt < nkt; ++kt) {
+        __syncthreads();                                          // previous tile fully consumed
+        for (int idx = tid; idx < 64 * CPR; idx += 256) {
+            const int row = idx / CPR, c = idx % CPR;
+            const int key = kt * 64 + row;
+            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
+            if (key < Lk) {
+                kv = *reinterpret_cast<const u32x4*>(p.k + (long)(k_beg + key) * p.ldk + hk * D + c * 8);
+                vv = *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8);
+            }
+            *reinterpret_cast<u32x4*>(Ks + row * C::KROW + c * 8) = kv;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                Vt[(c * 8 + 2 * j) * C::VROW + row] = (bf16_t)(vv[j] & 0xffffu);
+                Vt[(c * 8 + 2 * j + 1) * C::VROW + row] = (bf16_t)(vv[j] >> 16);
+            }
+        }
+        __syncthreads();
+
+        // ---- S = Q K^T  (16 x 64 per wave)
+        f32x4 s[4];
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int kk = 0; kk < C::KQ; ++kk) {
+                const int d = kk * 32 + fq * 8;
+                bf16x8 kf = (d < D) ? ld_frag(Ks + (kb * 16 + frow) * C::KROW + d) : zero_frag();
+                s[kb] = mfma16(qf[kk], kf, s[kb]);
+            }
+        }
+        // lane holds S[row = fq*4 + r][key = kt*64 + kb*16 + frow]
+        float mloc[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb) {
+            const int key = kt * 64 + kb * 16 + frow;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float x = s[kb][r] * p.scale_log2;
+                const int qi = tile * 64 + wave * 16 + fq * 4 + r;
+                bool ok = key < Lk;
+                if (CAUSAL) ok = ok && (key <= qi + shift);
+                x = ok ? x : -INFINITY;
+                s[kb][r] = x;
+                mloc[r] = fmaxf(mloc[r], x);
+            }
+        }
+        float alpha[4], msafe[4];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float m = mloc[r];
+            m = fmaxf(m, __shfl_xor(m, 1, 64));
+            m = fmaxf(m, __shfl_xor(m, 2, 64));
+            m = fmaxf(m, __shfl_xor(m, 4, 64));
+            m = fmaxf(m, __shfl_xor(m, 8, 64));
+            const float mnew = fmaxf(m_run[r], m);
+            msafe[r] = (mnew == -INFINITY) ? 0.f : mnew;
+            alpha[r] = exp2f(m_run[r] - msafe[r]);                 // m_run = -inf → 0
+            m_run[r] = mnew;
+        }
+        float lsum[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                const float pv = exp2f(s[kb][r] - msafe[r]);       // masked → exp2(-inf) = 0
+                lsum[r] += pv;
+                Pw[(fq * 4 + r) * C::VROW + kb * 16 + frow] = f2bf(pv);
+            }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float t = lsum[r];
+            t += __shfl_xor(t, 1, 64);
+            t += __shfl_xor(t, 2, 64);
+            t += __shfl_xor(t, 4, 64);
+            t += __shfl_xor(t, 8, 64);
+            l_run[r] = l_run[r] * alpha[r] + t;
+        }
+#pragma unroll
+        for (int i = 0; i < C::NB; ++i)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[i][r] *= alpha[r];
+        __syncthreads();                                          // P strip visible (same wave, but keep it simple)
+
+        // ---- O += P V   (A = P[16 x 64], B = V^T rows)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const bf16x8 pf = ld_frag(Pw + frow * C::VROW + ks * 32 + fq * 8);
+#pragma unroll
+            for (int i = 0; i < C::NB; ++i) {
+                const bf16x8 vf = ld_frag(Vt + (i * 16 + frow) * C::VROW + ks * 32 + fq * 8);
+                o[i] = mfma16(pf, vf, o[i]);
+            }
+        }
+    }
+
+    // ---- normalise and store: lane holds O[row = fq*4 + r][d = i*16 + frow]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int qi = tile * 64 + wave * 16 + fq * 4 + r;
+        if (qi >= Lq) continue;
+        const float inv = l_run[r] > 0.f ? 1.0f / l_run[r] : 0.f;
+        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + h * D;
+#pragma unroll
+        for (int i = 0; i < C::NB; ++i) dst[i * 16 + frow] = f2bf(o[i][r] * inv);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Decode attention, head_dim D (multiple of 32), one new token per sample.
+struct DecodeArgs {
+    const bf16_t* q;        // [B][Hq*D]
+    const bf16_t* kc;       // K cache [B][Hkv][S_max][D]
+    const bf16_t* vtc;      // V^T cache [B][Hkv][D][S_max]
+    const int* lens;        // [B] number of valid keys (including the token just appended)
+    float* part_o;          // [B][Hkv][nsplit][16][D]
+    float* part_ml;         // [B][Hkv][nsplit][16][2]
+    bf16_t* out;            // [B][Hq*D]
+    int Hq, Hkv, S_max, nsplit;
+    float scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
+    __shared__ __attribute__((aligned(16))) bf16_t Pw[16 * 72];
+    const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
+    const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int group = p.Hq / p.Hkv;
+    const int len = p.lens[b];
+    const int k0 = split * 64;
+    const long pbase = (((long)b * p.Hkv + g) * p.nsplit + split) * 16;
+    constexpr int KQ = D / 32, NB = D / 16;
+
+    if (k0 >= len) {                                              // empty split: neutral partial
+        if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
+        return;
+    }
+    bf16x8 qf[KQ];
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk)
+        qf[kk] = (frow < group) ? ld_frag(p.q + (long)b * p.Hq * D + (g * group + frow) * D + kk * 32 + fq * 8) : zero_frag();
+
+    const bf16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    const bf16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+
+    f32x4 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        int key = k0 + kb * 16 + frow;
+        key = key < p.S_max ? key : p.S_max - 1;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) s[kb] = mfma16(qf[kk], ld_frag(kbase + (long)key * D + kk * 32 + fq * 8), s[kb]);
+    }
+    float mrow[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int key = k0 + kb * 16 + frow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            float x = (key < len) ? s[kb][r] * p.scale_log2 : -INFINITY;
+            s[kb][r] = x;
+            mrow[r] = fmaxf(mrow[r], x);
+        }
+    }
+    float lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = mrow[r];
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        m = fmaxf(m, __shfl_xor(m, 8, 64));
+        mrow[r] = m;                                              // finite: key k0 < len exists
+        lrow[r] = 0.f;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = exp2f(s[kb][r] - mrow[r]);
+            lrow[r] += pv;
+            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2bf(pv);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = lrow[r];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        lrow[r] = t;
+    }
+    __syncthreads();
+    f32x4 o[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
+        int kk0 = k0 + ks * 32 + fq * 8;                          // 8 keys, 16-byte aligned in the V^T row
+        kk0 = (kk0 + 8 <= p.S_max) ? kk0 : p.S_max - 8;           // (S_max % 64 == 0, so this never actually clamps)
+#pragma unroll
+        for (int i = 0; i < NB; ++i) o[i] = mfma16(pf, ld_frag(vbase + (long)(i * 16 + frow) * p.S_max + kk0), o[i]);
+    }
+    // partials: lane holds O[head = fq*4 + r][d = i*16 + frow]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int hrow = fq * 4 + r;
+        float* po = p.part_o + (pbase + hrow) * D;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) po[i * 16 + frow] = o[i][r];
+        if (frow == 0) { p.part_ml[(pbase + hrow) * 2] = mrow[r]; p.part_ml[(pbase + hrow) * 2 + 1] = lrow[r]; }
+    }
+}
+
+template <int D>
+__global__ void decode_combine_kernel(DecodeArgs p) {
+    const int b = blockIdx.y, hq = blockIdx.x, d = threadIdx.x;
+    const int group = p.Hq / p.Hkv;
+    const int g = hq / group, hrow = hq % group;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const long base = (((long)b * p.Hkv + g) * p.nsplit + s) * 16 + hrow;
+        M = fmaxf(M, p.part_ml[base * 2]);
+    }
+    float L = 0.f, acc = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const long base = (((long)b * p.Hkv + g) * p.nsplit + s) * 16 + hrow;
+        const float m = p.part_ml[base * 2];
+        if (m == -INFINITY) continue;
+        const float w = exp2f(m - M);
+        L += w * p.part_ml[base * 2 + 1];
+        acc += w * p.part_o[base * D + d];
+    }
+    p.out[(long)b * p.Hq * D + hq * D + d] = f2bf(L > 0.f ? acc / L : 0.f);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+extern "C" void padt_set_error(const char* msg);
+
+template <int D, bool CAUSAL>
+static void launch_attn(const AttnArgs& a, int max_q_tiles, int H, int nseg, hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_varlen_kernel<D, CAUSAL>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, AttnCfg<D>::LDS);
+        done = true;
+    }
+    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL>), dim3(max_q_tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+}
+
+extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+                                void* o, long ldo, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q,
+                                int n_heads, int n_kv_heads, int head_dim, float scale, int causal) {
+    if (nseg <= 0 || max_seqlen_q <= 0) return 0;
+    if ((ldq & 7) || (ldk & 7) || (ldv & 7) || n_heads % n_kv_heads) {
+        padt_set_error("padt_attn_varlen: strides must be multiples of 8 elements; heads % kv_heads == 0");
+        return -1;
+    }
+    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, cu_q, cu_k,
+               n_heads / n_kv_heads, scale * 1.4426950408889634f};
+    const int tiles = (max_seqlen_q + 63) / 64;
+    hipStream_t s = (hipStream_t)stream;
+#define PADT_ATTN_CASE(DD)                                                  \
+    case DD:                                                                \
+        if (causal) launch_attn<DD, true>(a, tiles, n_heads, nseg, s);      \
+        else launch_attn<DD, false>(a, tiles, n_heads, nseg, s);            \
+        break;
+    switch (head_dim) {
+        PADT_ATTN_CASE(32)
+        PADT_ATTN_CASE(64)
+        PADT_ATTN_CASE(80)
+        PADT_ATTN_CASE(128)
+        default: padt_set_error("padt_attn_varlen: head_dim must be 32, 64, 80 or 128"); return -1;
+    }
+#undef PADT_ATTN_CASE
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+extern "C" long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max) {
+    const long nsplit = (s_max + 63) / 64;
+    return (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
+}
+
+extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens,
+                                void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,
+                                int s_max, int max_len, float scale) {
+    if (batch <= 0) return 0;
+    if (n_heads % n_kv_heads || n_heads / n_kv_heads > 16 || (s_max & 63) || max_len > s_max || max_len <= 0) {
+        padt_set_error("padt_decode_attn: need heads/kv_heads <= 16, s_max % 64 == 0, 0 < max_len <= s_max");
+        return -1;
+    }
+    DecodeArgs a;
+    a.q = (const bf16_t*)q; a.kc = (const bf16_t*)k_cache; a.vtc = (const bf16_t*)vt_cache; a.lens = lens;
+    a.out = (bf16_t*)out; a.Hq = n_heads; a.Hkv = n_kv_heads; a.S_max = s_max;
+    a.nsplit = (max_len + 63) / 64;
+    a.part_o = (float*)workspace;
+    a.part_ml = a.part_o + (long)batch * n_kv_heads * a.nsplit * 16 * head_dim;
+    a.scale_log2 = scale * 1.4426950408889634f;
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 32:
+            hipLaunchKernelGGL(decode_attn_kernel<32>, dim3(a.nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<32>, dim3(n_heads, batch), dim3(32), 0, s, a);
+            break;
+        case 128:
+            hipLaunchKernelGGL(decode_attn_kernel<128>, dim3(a.nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<128>, dim3(n_heads, batch), dim3(128), 0, s, a);
+            break;
+        default: padt_set_error("padt_decode_attn: head_dim must be 32 or 128"); return -1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}

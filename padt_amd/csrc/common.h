@@ -1,0 +1,72 @@
+// Device-side helpers shared by every kernel file.  gfx950 (MI355X, CDNA4) only: wave = 64 lanes,
+// MFMA 16x16x32 bf16 fragments, LDS-DMA (global_load_lds_dwordx4).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned short bf16_t;                                   // raw bf16 bits in memory
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;       // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(4))) float f32x4;         // one 16x16 MFMA C/D fragment
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16 bytes
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;  // 8 bytes
+
+#define PADT_DEV __device__ __forceinline__
+
+PADT_DEV float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+
+// round-to-nearest-even; NaN stays NaN, +-inf stays +-inf
+PADT_DEV bf16_t f2bf(float f) {
+    unsigned u = __builtin_bit_cast(unsigned, f);
+    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (bf16_t)(u >> 16);
+}
+
+PADT_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
+
+PADT_DEV bf16x8 ld_frag(const void* p) { return *reinterpret_cast<const bf16x8*>(p); }
+
+PADT_DEV bf16x8 zero_frag() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(bf16x8, z);
+}
+
+PADT_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
+PADT_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+
+// unpack 8 bf16 (one 16-byte vector) to floats
+PADT_DEV void unpack8(const u32x4& v, float* f) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
+        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
+    }
+}
+PADT_DEV u32x4 pack8(const float* f) {
+    u32x4 v;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    return v;
+}
+
+PADT_DEV float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+PADT_DEV float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+// XCD-aware, bijective remap of a 1-D block id (guide T1): each of the 8 XCDs (private L2) gets a contiguous chunk of
+// the tile space, so neighbouring tiles that share an operand panel hit the same L2.
+PADT_DEV int xcd_remap(int bid, int nwg) {
+    const int nx = 8;
+    int xcd = bid % nx, q = nwg / nx, r = nwg % nx;
+    int base = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + bid / nx;
+}

@@ -1,0 +1,421 @@
+// HBM-bound row kernels for gfx950: norms, rotary embeddings, gathers, KV-cache append, PaDT decoder glue.
+// All bf16 traffic is 16-byte vectorised (8 elements per lane per access); reductions are wave64 xor-shuffles.
+#include "common.h"
+
+extern "C" void padt_set_error(const char* msg);
+
+#define PADT_CHECK_LAUNCH(name)                                          \
+    do {                                                                 \
+        hipError_t e_ = hipGetLastError();                               \
+        if (e_ != hipSuccess) { padt_set_error(hipGetErrorString(e_)); return -2; } \
+    } while (0)
+
+// ---------------------------------------------------------------------------------------------------------------------
+// RMSNorm (HF Qwen2_5_VLRMSNorm, modeling_qwen2_5_vl.py:74-79; padt_decoder.py:71-74,143,156,170): one wave per row,
+// fp32 accumulate, single rounding on the way out (act = 1 applies exact-erf GELU after the weight: the
+// Linear→RMSNorm→GELU of mask_output_upscaling1, padt_decoder.py:168-172).  Optional fused "add" input: y = norm(x + a[row / a_div]) which
+// implements padt_decoder.py:220  high = RMSNorm(repeat4(low) + high)  with a_div = 4.
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ a,
+                                                      long lda, int a_div, const bf16_t* __restrict__ w,
+                                                      bf16_t* __restrict__ y, long ldy, int rows, int D, float eps,
+                                                      int act) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    const bf16_t* ar = a ? a + (long)(row / a_div) * lda : nullptr;
+    float ss = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+        if (ar) {
+            float g[8];
+            unpack8(*reinterpret_cast<const u32x4*>(ar + c), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    bf16_t* yr = y + (long)row * ldy;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8], g[8], wv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+        if (ar) {
+            unpack8(*reinterpret_cast<const u32x4*>(ar + c), g);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) f[i] += g[i];
+        }
+        unpack8(*reinterpret_cast<const u32x4*>(w + c), wv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            f[i] = f[i] * rstd * wv[i];
+            if (act == 1) f[i] = gelu_erf(f[i]);
+        }
+        *reinterpret_cast<u32x4*>(yr + c) = pack8(f);
+    }
+}
+
+extern "C" int padt_rmsnorm(void* stream, const void* x, long ldx, const void* add, long ld_add, int add_div,
+                            const void* w, void* y, long ldy, long rows, long D, float eps, int act) {
+    if (rows <= 0) return 0;
+    if ((D & 7) || (ldx & 7) || (ldy & 7) || (add && (ld_add & 7)) || add_div <= 0) {
+        padt_set_error("padt_rmsnorm: D and strides must be multiples of 8");
+        return -1;
+    }
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)add, ld_add, add_div, (const bf16_t*)w, (bf16_t*)y, ldy, (int)rows, (int)D, eps, act);
+    PADT_CHECK_LAUNCH("rmsnorm");
+    return 0;
+}
+
+// LayerNorm with mean centring (vis_norm, padt.py:121,188; eps 1e-5, weight + bias).
+__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
+                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+                                                        int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    float s = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s += f[i];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float v = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; v += d * d; }
+    }
+    const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
+    bf16_t* yr = y + (long)row * ldy;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8], wv[8], bv[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+        unpack8(*reinterpret_cast<const u32x4*>(w + c), wv);
+        unpack8(*reinterpret_cast<const u32x4*>(b + c), bv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) f[i] = (f[i] - mean) * rstd * wv[i] + bv[i];
+        *reinterpret_cast<u32x4*>(yr + c) = pack8(f);
+    }
+}
+
+extern "C" int padt_layernorm(void* stream, const void* x, long ldx, const void* w, const void* b, void* y, long ldy,
+                              long rows, long D, float eps) {
+    if (rows <= 0) return 0;
+    if ((D & 7) || (ldx & 7) || (ldy & 7)) { padt_set_error("padt_layernorm: D and strides must be multiples of 8"); return -1; }
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, (int)rows, (int)D, eps);
+    PADT_CHECK_LAUNCH("layernorm");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Rotate-half rotary in place over `nh` consecutive heads of width D per token, fp32 math, cos/sin tables fp32 [T][ld_cs]
+// (first D/2 columns used).  ViT q,k (HF apply_rotary_pos_emb_vision :160-171; q and k are adjacent in the fused qkv
+// row so one launch covers both) and the PaDT decoder's image-side q or k (padt_decoder.py:38-51).
+__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
+                                                        const float* __restrict__ sn, long ld_cs, long T, int nh, int D) {
+    const int half = D >> 1;
+    const long total = T * nh * half;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int d = (int)(i % half);
+        const long th = i / half;
+        const int h = (int)(th % nh);
+        const long t = th / nh;
+        bf16_t* p = x + t * ldx + (long)h * D;
+        const float c = cs[t * ld_cs + d], s = sn[t * ld_cs + d];
+        const float x1 = bf2f(p[d]), x2 = bf2f(p[d + half]);
+        p[d] = f2bf(x1 * c - x2 * s);
+        p[d + half] = f2bf(x2 * c + x1 * s);
+    }
+}
+
+extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T,
+                              int n_heads, int head_dim) {
+    if (T <= 0) return 0;
+    if (head_dim & 1) { padt_set_error("padt_rope_half: head_dim must be even"); return -1; }
+    const long total = T * n_heads * (head_dim / 2);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                       (const float*)cos_t, (const float*)sin_t, ld_cs, T, n_heads, head_dim);
+    PADT_CHECK_LAUNCH("rope_half");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// dst[i] = src[idx[i]]  (16-byte vectors).  ViT window permutation (padt.py:70-75), un-permutation of the merger output
+// (padt.py:103-104), per-object replication of image memory (padt.py:365-373).
+__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long ld_src,
+                                                          const int* __restrict__ idx, bf16_t* __restrict__ dst,
+                                                          long ld_dst, long n, int vec_per_row) {
+    const long total = n * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vec_per_row;
+        const int c = (int)(i % vec_per_row) * 8;
+        *reinterpret_cast<u32x4*>(dst + r * ld_dst + c) = *reinterpret_cast<const u32x4*>(src + (long)idx[r] * ld_src + c);
+    }
+}
+
+extern "C" int padt_gather_rows(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst,
+                                long n, long D) {
+    if (n <= 0) return 0;
+    if ((D & 7) || (ld_src & 7) || (ld_dst & 7)) { padt_set_error("padt_gather_rows: D and strides must be multiples of 8"); return -1; }
+    const long total = n * (D / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                       ld_src, idx, (bf16_t*)dst, ld_dst, n, (int)(D / 8));
+    PADT_CHECK_LAUNCH("gather_rows");
+    return 0;
+}
+
+// same for fp32 rows (cos/sin tables replicated per object in vl_decode)
+__global__ __launch_bounds__(256) void gather_rows_f32_kernel(const float* __restrict__ src, long ld_src,
+                                                              const int* __restrict__ idx, float* __restrict__ dst,
+                                                              long ld_dst, long n, int D) {
+    const long total = n * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / D;
+        const int c = (int)(i % D);
+        dst[r * ld_dst + c] = src[(long)idx[r] * ld_src + c];
+    }
+}
+
+extern "C" int padt_gather_rows_f32(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst,
+                                    long n, long D) {
+    if (n <= 0) return 0;
+    long blocks = (n * D + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(gather_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)src, ld_src, idx, (float*)dst, ld_dst, n, (int)D);
+    PADT_CHECK_LAUNCH("gather_rows_f32");
+    return 0;
+}
+
+// y = a + b[row % b_rows]   (decoder: key/query + positional query, padt_decoder.py:30-31; b_rows == rows → plain add)
+__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b,
+                                                       long ldb, long b_rows, bf16_t* __restrict__ y, long ldy, long n,
+                                                       int vec_per_row) {
+    const long total = n * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vec_per_row;
+        const int c = (int)(i % vec_per_row) * 8;
+        float f[8], g[8];
+        unpack8(*reinterpret_cast<const u32x4*>(a + r * lda + c), f);
+        unpack8(*reinterpret_cast<const u32x4*>(b + (r % b_rows) * ldb + c), g);
+#pragma unroll
+        for (int k = 0; k < 8; ++k) f[k] += g[k];
+        *reinterpret_cast<u32x4*>(y + r * ldy + c) = pack8(f);
+    }
+}
+
+extern "C" int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y,
+                             long ldy, long n, long D) {
+    if (n <= 0) return 0;
+    if ((D & 7) || (lda & 7) || (ldb & 7) || (ldy & 7) || b_rows <= 0) { padt_set_error("padt_add_rows: bad arguments"); return -1; }
+    const long total = n * (D / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
+                       (const bf16_t*)b, ldb, b_rows, (bf16_t*)y, ldy, n, (int)(D / 8));
+    PADT_CHECK_LAUNCH("add_rows");
+    return 0;
+}
+
+// fp32 → bf16 cast (pixel_values.type(self.visual.dtype), padt.py:184) with optional zero padding of the row tail.
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y,
+                                                            long ldy, long rows, int D, int D_pad) {
+    const long total = rows * D_pad;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / D_pad;
+        const int c = (int)(i % D_pad);
+        y[r * ldy + c] = c < D ? f2bf(x[r * ldx + c]) : (bf16_t)0;
+    }
+}
+
+extern "C" int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad) {
+    if (rows <= 0) return 0;
+    long blocks = (rows * D_pad + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
+                       ldx, (bf16_t*)y, ldy, rows, (int)D, (int)D_pad);
+    PADT_CHECK_LAUNCH("cast_f32_bf16");
+    return 0;
+}
+
+__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int D,
+                                   int sigmoid) {
+    const long total = rows * D;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / D;
+        const int c = (int)(i % D);
+        float v = bf2f(x[r * ldx + c]);
+        y[r * ldy + c] = sigmoid ? 1.0f / (1.0f + __expf(-v)) : v;
+    }
+}
+
+// in-place fp32 sigmoid (bbox head's nn.Sigmoid, padt_decoder.py:164)
+__global__ void sigmoid_f32_kernel(float* __restrict__ x, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
+        x[i] = 1.0f / (1.0f + expf(-x[i]));
+}
+
+extern "C" int padt_sigmoid_f32(void* stream, void* x, long n) {
+    if (n <= 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(sigmoid_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (float*)x, n);
+    PADT_CHECK_LAUNCH("sigmoid_f32");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// VRT embedding: inputs_embeds[t] = image_embeds[img_index[t]] if img_index[t] >= 0 else [E ‖ proto][ids[t]]
+// (padt.py:193-219 prefill, 226-229 decode) — the table is never concatenated: two base pointers.
+__global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restrict__ ids, const int* __restrict__ img_index,
+                                                           const bf16_t* __restrict__ E, const bf16_t* __restrict__ proto,
+                                                           const bf16_t* __restrict__ image_embeds, bf16_t* __restrict__ out,
+                                                           long T, int V, int n_proto, int vec_per_row, int* __restrict__ err) {
+    const long total = T * vec_per_row;
+    const int D = vec_per_row * 8;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long t = i / vec_per_row;
+        const int c = (int)(i % vec_per_row) * 8;
+        const long id = ids[t];
+        const int ii = img_index ? img_index[t] : -1;
+        const bf16_t* src;
+        if (ii >= 0) src = image_embeds + (long)ii * D;
+        else if (id >= 0 && id < V) src = E + id * D;
+        else if (id >= V && id < (long)V + n_proto) src = proto + (id - V) * D;
+        else { if (err) atomicExch(err, 1); src = E; }            // assert input_ids.max() < table rows (padt.py:203)
+        *reinterpret_cast<u32x4*>(out + t * D + c) = *reinterpret_cast<const u32x4*>(src + c);
+    }
+}
+
+extern "C" int padt_embed_tokens(void* stream, const long* ids, const int* img_index, const void* embed_table,
+                                 const void* proto, const void* image_embeds, void* out, long T, long vocab, long n_proto,
+                                 long D, int* err_flag) {
+    if (T <= 0) return 0;
+    if (D & 7) { padt_set_error("padt_embed_tokens: D must be a multiple of 8"); return -1; }
+    long blocks = (T * (D / 8) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ids, img_index,
+                       (const bf16_t*)embed_table, (const bf16_t*)proto, (const bf16_t*)image_embeds, (bf16_t*)out, T,
+                       (int)vocab, (int)n_proto, (int)(D / 8), err_flag);
+    PADT_CHECK_LAUNCH("embed_tokens");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// LLM q/k/v post-processing for T tokens: mRoPE on q and k (HF apply_multimodal_rotary_pos_emb :557-599, sections
+// [s0,s1,s2] over head_dim/2, rotate-half pairs), write q to q_out, roped k to the row-major K cache and (prefill) to a
+// packed k buffer, v to the TRANSPOSED V cache.  qkv row = [Hq*D | Hkv*D | Hkv*D] (bias already added by the GEMM).
+struct QkvPostArgs {
+    const bf16_t* qkv; long ld;
+    const int* pos;            // [3][T]  (t, h, w) rope positions
+    const int* sample;         // [T] sample index (cache row); null → token index
+    const int* slot;           // [T] cache slot; null → read from lens[sample] (decode)
+    const int* lens;           // [B] current lengths (decode: slot = lens[b])
+    const float* inv_freq;     // [D/2]
+    bf16_t* q_out; long ld_q;
+    bf16_t* k_pack; long ld_kp; // may be null
+    bf16_t* kc; bf16_t* vtc;   // caches
+    int T, Hq, Hkv, D, S_max, sec0, sec1;
+};
+
+__global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
+    const int t = blockIdx.x;
+    const int half = p.D >> 1;
+    const int b = p.sample ? p.sample[t] : t;
+    const int slot = p.slot ? p.slot[t] : p.lens[b];
+    const bf16_t* row = p.qkv + (long)t * p.ld;
+    const int nqk = (p.Hq + p.Hkv) * half;
+    for (int i = threadIdx.x; i < nqk; i += blockDim.x) {
+        const int h = i / half, d = i % half;
+        const int axis = d < p.sec0 ? 0 : (d < p.sec0 + p.sec1 ? 1 : 2);
+        const float ang = (float)p.pos[(long)axis * p.T + t] * p.inv_freq[d];
+        const float c = cosf(ang), s = sinf(ang);
+        const bf16_t* x = row + (long)h * p.D;
+        const float x1 = bf2f(x[d]), x2 = bf2f(x[d + half]);
+        const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
+        if (h < p.Hq) {
+            bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
+            q[d] = o1; q[d + half] = o2;
+        } else {
+            const int g = h - p.Hq;
+            bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
+            kc[d] = o1; kc[d + half] = o2;
+            if (p.k_pack) {
+                bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
+                kp[d] = o1; kp[d + half] = o2;
+            }
+        }
+    }
+    const bf16_t* v = row + (long)(p.Hq + p.Hkv) * p.D;
+    for (int i = threadIdx.x; i < p.Hkv * p.D; i += blockDim.x) {
+        const int g = i / p.D, d = i % p.D;
+        p.vtc[(((long)b * p.Hkv + g) * p.D + d) * p.S_max + slot] = v[i];
+    }
+}
+
+extern "C" int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample,
+                                 const int* slot, const int* lens, const void* inv_freq, void* q_out, long ld_q,
+                                 void* k_pack, long ld_kp, void* k_cache, void* vt_cache, long T, int n_heads,
+                                 int n_kv_heads, int head_dim, int s_max, int sec0, int sec1) {
+    if (T <= 0) return 0;
+    if (!slot && !lens) { padt_set_error("padt_llm_qkv_post: need slot[] or lens[]"); return -1; }
+    QkvPostArgs a{(const bf16_t*)qkv, ld_qkv, pos3, sample, slot, lens, (const float*)inv_freq, (bf16_t*)q_out, ld_q,
+                  (bf16_t*)k_pack, ld_kp, (bf16_t*)k_cache, (bf16_t*)vt_cache, (int)T, n_heads, n_kv_heads, head_dim,
+                  s_max, sec0, sec1};
+    hipLaunchKernelGGL(llm_qkv_post_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, a);
+    PADT_CHECK_LAUNCH("llm_qkv_post");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// PaDT mask head tail (padt_decoder.py:241-274): e2[(n,a,b)][(c,d,:)] · mask_tok[obj(n)] → masks[obj][4*row+2a+c][4*col+2b+d]
+// e2: [4*Np][4*dm] bf16 (row = patch*4 + a*2 + b, col = (c*2+d)*dm + k), tok: [n_obj][dm] bf16.
+__global__ __launch_bounds__(256) void mask_scatter_kernel(const bf16_t* __restrict__ e2, long ld_e2,
+                                                           const bf16_t* __restrict__ tok, long ld_tok,
+                                                           const int* __restrict__ cu_patch, const int* __restrict__ obj_w,
+                                                           float* __restrict__ masks, int n_obj, int Hm4, int Wm4, int dm) {
+    // one thread per output logit: index = ((patch*4 + ab)*4 + cd)
+    const long total = (long)cu_patch[n_obj] * 16;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cd = (int)(i & 3), ab = (int)((i >> 2) & 3);
+        const long patch = i >> 4;
+        int lo = 0, hi = n_obj;                                    // obj = last o with cu_patch[o] <= patch
+        while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cu_patch[mid] <= patch) lo = mid; else hi = mid; }
+        const int obj = lo;
+        const int pin = (int)(patch - cu_patch[obj]);
+        const int W = obj_w[obj];
+        const int prow = pin / W, pcol = pin % W;
+        const bf16_t* e = e2 + (patch * 4 + ab) * ld_e2 + (long)cd * dm;
+        const bf16_t* tk = tok + (long)obj * ld_tok;
+        float acc = 0.f;
+        for (int k = 0; k < dm; ++k) acc += bf2f(e[k]) * bf2f(tk[k]);
+        const int a = ab >> 1, bb = ab & 1, c = cd >> 1, d = cd & 1;
+        masks[((long)obj * Hm4 + prow * 4 + a * 2 + c) * Wm4 + pcol * 4 + bb * 2 + d] = acc;
+    }
+}
+
+extern "C" int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok,
+                                 const int* cu_patch, const int* obj_w, void* masks_f32, int n_obj, long total_patches,
+                                 int Hm4, int Wm4, int dm) {
+    if (n_obj <= 0 || total_patches <= 0) return 0;
+    long blocks = (total_patches * 16 + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)e2,
+                       ld_e2, (const bf16_t*)mask_tok, ld_tok, cu_patch, obj_w, (float*)masks_f32, n_obj, Hm4, Wm4, dm);
+    PADT_CHECK_LAUNCH("mask_scatter");
+    return 0;
+}

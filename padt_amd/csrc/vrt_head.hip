@@ -1,0 +1,204 @@
+// VRT logit head with fused logit mask + arg-max, and the greedy-loop bookkeeping kernel.
+//
+// Reference (padt.py:292-301, 713-757): logits = hidden @ cat([embed_tokens|lm_head, prototypes]).T, masked_fill(-inf)
+// outside [text vocab ∪ the sample's own patch rows], argmax of the last position in fp32, finished rows get pad,
+// EOS clears `unfinished`.  Here the two tables are read through two base pointers (the 0.6 GB concatenation per forward
+// never happens), only the last position is computed, and the logits never touch HBM unless a caller asks for them.
+//
+// vrt_head_kernel: block = 4 waves = 16 table rows, K interleaved over the waves (same weight-streaming scheme as the
+// skinny GEMM), swapped MFMA so a lane owns 4 consecutive table rows of one sample; block-local (max, argmax) per
+// sample goes to a partial buffer.  greedy_step_kernel: final reduction (ties → lowest index, as torch.argmax),
+// pad/EOS bookkeeping, append to the token buffer, stash the step's last-layer hidden row for parseVRTintoCompletion
+// (padt_processor.py:125), advance cache slots / rope positions / step counter — all on device, so a decode step is one
+// replayable hipGraph.
+#include "common.h"
+
+extern "C" void padt_set_error(const char* msg);
+
+struct HeadArgs {
+    const bf16_t* h; long ldh;         // [B][D]
+    const bf16_t* E; int V;            // text rows
+    const bf16_t* proto; int NP;       // prototype rows
+    const int* vrt_off;                // [B+1]
+    const int* mode_table;             // [T] or null: 0 free, 1 text rows only, 2 own VRT rows only, 3 force EOS
+    const int* step;                   // device step counter (index into mode_table) or null
+    float* logits; long ldl;           // optional [B][V+NP]
+    float* part_val; int* part_idx;    // [nblk][16*MT]
+    int B, D, eos;
+};
+
+template <int MT>
+__global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
+    __shared__ __attribute__((aligned(16))) float red[3][MT][64][4];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int n0 = blockIdx.x * 16;
+    const int NT = p.V + p.NP;
+    int n = n0 + frow;
+    n = n < NT ? n : NT - 1;
+    const bf16_t* wrow = (n < p.V) ? p.E + (long)n * p.D : p.proto + (long)(n - p.V) * p.D;
+    const bf16_t* xrow[MT];
+    bool xok[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = j * 16 + frow;
+        xok[j] = m < p.B;
+        xrow[j] = p.h + (long)(xok[j] ? m : 0) * p.ldh;
+    }
+    f32x4 acc[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int nks = (p.D + 31) / 32;
+    constexpr int U = 4;
+    for (int ks0 = wave; ks0 < nks; ks0 += 4 * U) {
+        bf16x8 wf[U], xf[U][MT];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int ks = ks0 + u * 4;
+            const int k = ks * 32 + fq * 8;
+            const bool kok = (ks < nks) && (k < p.D);
+            wf[u] = kok ? ld_frag(wrow + k) : zero_frag();
+#pragma unroll
+            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + k) : zero_frag();
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[j] = mfma16(wf[u], xf[u][j], acc[j]);
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 1][j][lane][0]) = acc[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const int mode = (p.mode_table && p.step) ? p.mode_table[*p.step] : 0;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) acc[j] += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
+        const int m = j * 16 + frow;                      // sample
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        int lo = 0, hi = 0;
+        if (m < p.B) { lo = p.vrt_off[m]; hi = p.vrt_off[m + 1]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = n0 + fq * 4 + r;
+            bool ok = (m < p.B) && (row < NT);
+            if (ok) {
+                if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
+                else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
+            }
+            const float v = ok ? acc[j][r] : -INFINITY;
+            if (p.logits && m < p.B && row < NT) p.logits[(long)m * p.ldl + row] = v;
+            if (v > best) { best = v; bidx = row; }      // rows ascend with r → first max wins
+        }
+        // combine the 4 lanes (fq = 0..3) that hold the same sample
+#pragma unroll
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bidx, off, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (fq == 0 && m < p.B) {
+            p.part_val[(long)blockIdx.x * p.B + m] = best;
+            p.part_idx[(long)blockIdx.x * p.B + m] = bidx;
+        }
+    }
+}
+
+struct GreedyArgs {
+    const float* part_val; const int* part_idx; int nblk;
+    int B, D, eos, pad, T_max;
+    int* unfinished;          // [B]
+    long* tokens_out;         // [B][T_max]
+    long* cur_tok;            // [B] token to feed to the next step
+    int* step;                // device counter
+    int* slot; int* lens;     // [B] KV append index / valid-key count for the NEXT step
+    int* pos3;                // [3][B] rope positions for the NEXT step
+    const bf16_t* hidden;     // [B][D] last-layer hidden of this step (post final norm)
+    bf16_t* hidden_buf;       // [T_max][B][D]
+    int advance;              // 1: bump slot/lens/pos (decode steps and after prefill)
+};
+
+__global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
+    __shared__ float sv[256];
+    __shared__ int si[256];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < p.nblk; i += 256) {
+        const float v = p.part_val[(long)i * p.B + b];
+        const int ix = p.part_idx[(long)i * p.B + b];
+        if (v > best || (v == best && ix < bidx)) { best = v; bidx = ix; }
+    }
+    sv[tid] = best; si[tid] = bidx;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+        if (tid < s) {
+            const float ov = sv[tid + s]; const int oi = si[tid + s];
+            if (ov > sv[tid] || (ov == sv[tid] && oi < si[tid])) { sv[tid] = ov; si[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    const int step = *p.step;
+    if (step < p.T_max) {
+        const bf16_t* h = p.hidden + (long)b * p.D;
+        bf16_t* hb = p.hidden_buf + ((long)step * p.B + b) * p.D;
+        for (int c = tid * 8; c < p.D; c += 256 * 8) *reinterpret_cast<u32x4*>(hb + c) = *reinterpret_cast<const u32x4*>(h + c);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        const int unf = p.unfinished[b];
+        long next = unf ? (long)si[0] : (long)p.pad;                 // padt.py:749
+        if (step < p.T_max) p.tokens_out[(long)b * p.T_max + step] = next;
+        p.cur_tok[b] = next;
+        p.unfinished[b] = unf & (next != p.eos);                     // padt.py:756
+        if (p.advance) {
+            p.slot[b] += 1; p.lens[b] += 1;
+            p.pos3[b] += 1; p.pos3[p.B + b] += 1; p.pos3[2 * p.B + b] += 1;
+        }
+    }
+}
+
+// one-thread kernel: bump the step counter after all samples' greedy_step blocks ran
+__global__ void step_inc_kernel(int* step) { *step += 1; }
+
+extern "C" long padt_vrt_head_nblk(long vocab, long n_proto) { return (vocab + n_proto + 15) / 16; }
+
+extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
+                             const void* proto, long n_proto, const int* vrt_off, const int* mode_table,
+                             const int* step, void* logits_f32, long ld_logits, void* part_val, void* part_idx,
+                             long batch, long D, int eos) {
+    if (batch <= 0) return 0;
+    if (batch > 64 || (D & 7) || (ldh & 7)) { padt_set_error("padt_vrt_head: batch <= 64, D % 8 == 0 required"); return -1; }
+    HeadArgs a{(const bf16_t*)hidden, ldh, (const bf16_t*)embed_table, (int)vocab, (const bf16_t*)proto, (int)n_proto,
+               vrt_off, mode_table, step, (float*)logits_f32, ld_logits, (float*)part_val, (int*)part_idx, (int)batch,
+               (int)D, eos};
+    const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
+    hipStream_t s = (hipStream_t)stream;
+    if (batch <= 16) hipLaunchKernelGGL(vrt_head_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
+    else if (batch <= 32) hipLaunchKernelGGL(vrt_head_kernel<2>, dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(vrt_head_kernel<4>, dim3(nblk), dim3(256), 0, s, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+extern "C" int padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D,
+                                int eos, int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok,
+                                int* step, int* slot, int* lens, int* pos3, const void* hidden, void* hidden_buf,
+                                int advance) {
+    if (batch <= 0) return 0;
+    if (D & 7) { padt_set_error("padt_greedy_step: D % 8 == 0 required"); return -1; }
+    GreedyArgs a{(const float*)part_val, (const int*)part_idx, (int)nblk, (int)batch, (int)D, eos, pad, (int)t_max,
+                 unfinished, tokens_out, cur_tok, step, slot, lens, pos3, (const bf16_t*)hidden, (bf16_t*)hidden_buf,
+                 advance};
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(greedy_step_kernel, dim3((unsigned)batch), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}

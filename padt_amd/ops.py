@@ -1,0 +1,208 @@
+"""Thin torch-tensor → C-ABI wrappers.  PyTorch is used for device memory and streams only; every arithmetic op below
+is a hand-written gfx950 kernel in libpadt_hip.so (see include/padt_hip.h).  No fallbacks."""
+import torch
+
+from . import _lib
+
+EPI_NONE, EPI_GELU, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3
+BF16 = torch.bfloat16
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk_bf16(*ts):
+    for t in ts:
+        if t is not None:
+            assert t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1, (t.dtype, t.device, t.stride())
+
+
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=False, K=None):
+    """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias).  a/w/out may be row-strided 2-D views.  N' = N/2 for SwiGLU."""
+    lib = _lib.load()
+    _chk_bf16(a, w, bias, residual)
+    M = a.shape[0]
+    N = w.shape[0]
+    K = K if K is not None else a.shape[1]
+    assert w.shape[1] >= K or w.shape[1] == K, (w.shape, K)
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else BF16)
+    assert out.stride(-1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
+    _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+                                  _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
+                                  1 if out_f32 else 0), "padt_gemm_bf16")
+    return out
+
+
+def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None):
+    """q/k/v/out: 2-D (tokens, row) bf16 views whose row holds the heads contiguously; cu_*: int32 device tensors."""
+    lib = _lib.load()
+    _chk_bf16(q, k, v, out)
+    assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
+    nseg = cu_q.numel() - 1
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(lib.padt_attn_varlen(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+                                    out.stride(0), _p(cu_q), _p(cu_k), nseg, int(max_seqlen_q), n_heads, n_kv_heads,
+                                    head_dim, float(scale), 1 if causal else 0), "padt_attn_varlen")
+    return out
+
+
+def decode_attn_workspace(batch, n_kv_heads, head_dim, s_max):
+    return _lib.load().padt_decode_attn_workspace(batch, n_kv_heads, head_dim, s_max)
+
+
+def decode_attn(q, k_cache, vt_cache, lens, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len, scale=None):
+    lib = _lib.load()
+    _chk_bf16(q, k_cache, vt_cache, out)
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(lib.padt_decode_attn(_stream(), _p(q), _p(k_cache), _p(vt_cache), _p(lens), _p(out), _p(workspace),
+                                    q.shape[0], n_heads, n_kv_heads, head_dim, s_max, int(max_len), float(scale)),
+               "padt_decode_attn")
+    return out
+
+
+def rmsnorm(x, w, out=None, eps=1e-6, add=None, add_div=1, D=None, gelu=False):
+    lib = _lib.load()
+    _chk_bf16(x, w, add)
+    D = D if D is not None else x.shape[1]
+    if out is None:
+        out = torch.empty((x.shape[0], D), device=x.device, dtype=BF16)
+    _lib.check(lib.padt_rmsnorm(_stream(), _p(x), x.stride(0), _p(add), add.stride(0) if add is not None else 0, add_div,
+                                _p(w), _p(out), out.stride(0), x.shape[0], D, float(eps), 1 if gelu else 0), "padt_rmsnorm")
+    return out
+
+
+def layernorm(x, w, b, out=None, eps=1e-5):
+    lib = _lib.load()
+    _chk_bf16(x, w, b)
+    if out is None:
+        out = torch.empty_like(x)
+    _lib.check(lib.padt_layernorm(_stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), x.shape[0],
+                                  x.shape[1], float(eps)), "padt_layernorm")
+    return out
+
+
+def rope_half_(x, cos, sin, n_heads, head_dim):
+    """in place on the first n_heads*head_dim columns of x (T, row)."""
+    lib = _lib.load()
+    _chk_bf16(x)
+    assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(-1) == 1 and sin.stride() == cos.stride()
+    _lib.check(lib.padt_rope_half(_stream(), _p(x), x.stride(0), _p(cos), _p(sin), cos.stride(0), x.shape[0], n_heads,
+                                  head_dim), "padt_rope_half")
+    return x
+
+
+def gather_rows(src, idx, out=None, D=None):
+    lib = _lib.load()
+    assert idx.dtype == torch.int32 and src.stride(-1) == 1
+    D = D if D is not None else src.shape[1]
+    n = idx.numel()
+    if out is None:
+        out = torch.empty((n, D), device=src.device, dtype=src.dtype)
+    if src.dtype == BF16:
+        _lib.check(lib.padt_gather_rows(_stream(), _p(src), src.stride(0), _p(idx), _p(out), out.stride(0), n, D),
+                   "padt_gather_rows")
+    elif src.dtype == torch.float32:
+        _lib.check(lib.padt_gather_rows_f32(_stream(), _p(src), src.stride(0), _p(idx), _p(out), out.stride(0), n, D),
+                   "padt_gather_rows_f32")
+    else:
+        raise TypeError(src.dtype)
+    return out
+
+
+def add_rows(a, b, out=None):
+    lib = _lib.load()
+    _chk_bf16(a, b)
+    if out is None:
+        out = torch.empty_like(a)
+    _lib.check(lib.padt_add_rows(_stream(), _p(a), a.stride(0), _p(b), b.stride(0), b.shape[0], _p(out), out.stride(0),
+                                 a.shape[0], a.shape[1]), "padt_add_rows")
+    return out
+
+
+def cast_f32_bf16(x, D_pad=None, out=None):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.stride(-1) == 1
+    D = x.shape[1]
+    D_pad = D_pad or D
+    if out is None:
+        out = torch.empty((x.shape[0], D_pad), device=x.device, dtype=BF16)
+    _lib.check(lib.padt_cast_f32_bf16(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], D, D_pad),
+               "padt_cast_f32_bf16")
+    return out
+
+
+def sigmoid_f32_(x):
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    _lib.check(lib.padt_sigmoid_f32(_stream(), _p(x), x.numel()), "padt_sigmoid_f32")
+    return x
+
+
+def embed_tokens(ids, img_index, table, proto, image_embeds, out=None, err_flag=None):
+    lib = _lib.load()
+    _chk_bf16(table, proto, image_embeds)
+    assert ids.dtype == torch.int64 and ids.is_contiguous()
+    T, D = ids.numel(), table.shape[1]
+    if out is None:
+        out = torch.empty((T, D), device=table.device, dtype=BF16)
+    _lib.check(lib.padt_embed_tokens(_stream(), _p(ids), _p(img_index), _p(table), _p(proto), _p(image_embeds), _p(out),
+                                     T, table.shape[0], 0 if proto is None else proto.shape[0], D, _p(err_flag)),
+               "padt_embed_tokens")
+    return out
+
+
+def llm_qkv_post(qkv, pos3, inv_freq, q_out, k_cache, vt_cache, n_heads, n_kv_heads, head_dim, s_max, sections,
+                 sample=None, slot=None, lens=None, k_pack=None):
+    lib = _lib.load()
+    _chk_bf16(qkv, q_out, k_cache, vt_cache, k_pack)
+    assert pos3.dtype == torch.int32 and pos3.is_contiguous() and inv_freq.dtype == torch.float32
+    _lib.check(lib.padt_llm_qkv_post(_stream(), _p(qkv), qkv.stride(0), _p(pos3), _p(sample), _p(slot), _p(lens),
+                                     _p(inv_freq), _p(q_out), q_out.stride(0), _p(k_pack),
+                                     k_pack.stride(0) if k_pack is not None else 0, _p(k_cache), _p(vt_cache),
+                                     qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max, sections[0], sections[1]),
+               "padt_llm_qkv_post")
+
+
+def mask_scatter(e2, mask_tok, cu_patch, obj_w, masks, n_obj, total_patches, dm):
+    lib = _lib.load()
+    _chk_bf16(e2, mask_tok)
+    assert masks.dtype == torch.float32 and masks.is_contiguous()
+    _lib.check(lib.padt_mask_scatter(_stream(), _p(e2), e2.stride(0), _p(mask_tok), mask_tok.stride(0), _p(cu_patch),
+                                     _p(obj_w), _p(masks), n_obj, total_patches, masks.shape[1], masks.shape[2], dm),
+               "padt_mask_scatter")
+    return masks
+
+
+def vrt_head_nblk(vocab, n_proto):
+    return _lib.load().padt_vrt_head_nblk(vocab, n_proto)
+
+
+def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=None, step=None, logits=None):
+    lib = _lib.load()
+    _chk_bf16(hidden, table, proto)
+    _lib.check(lib.padt_vrt_head(_stream(), _p(hidden), hidden.stride(0), _p(table), table.shape[0], _p(proto),
+                                 proto.shape[0], _p(vrt_off), _p(mode_table), _p(step), _p(logits),
+                                 logits.stride(0) if logits is not None else 0, _p(part_val), _p(part_idx),
+                                 hidden.shape[0], hidden.shape[1], eos), "padt_vrt_head")
+
+
+def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens_out, cur_tok, step, slot, lens, pos3,
+                eos, pad, advance=True):
+    lib = _lib.load()
+    B, D = hidden.shape
+    _lib.check(lib.padt_greedy_step(_stream(), _p(part_val), _p(part_idx), nblk, B, D, eos, pad, tokens_out.shape[1],
+                                    _p(unfinished), _p(tokens_out), _p(cur_tok), _p(step), _p(slot), _p(lens), _p(pos3),
+                                    _p(hidden), _p(hidden_buf), 1 if advance else 0), "padt_greedy_step")
+
+
+def memset(t, value=0):
+    lib = _lib.load()
+    _lib.check(lib.padt_memset(_stream(), _p(t), value, t.numel() * t.element_size()), "padt_memset")
+    return t

@@ -1,0 +1,374 @@
+"""Per-kernel parity: every C-ABI kernel vs a plain PyTorch fp32 statement of the same op on the same bf16 inputs.
+
+Tolerance (written once, used everywhere): a bf16 result must be within one bf16 rounding of the fp32 reference,
+|out - ref| <= ulps * (2^-8 |ref| + 2e-3 * rms(ref)), ulps = 1  (fp32 outputs: 1e-4 relative to rms).  Attention uses
+ulps = 6: the probabilities are rounded to bf16 before the P·V MFMA (exactly what flash-attn 2, the reference's GPU
+attention, does), which adds up to 2^-8 relative error per probability on top of the output rounding.
+Integer outputs are bit-exact.
+"""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from padt_amd import ops as _ops
+    return _ops
+
+
+def rnd(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).to(BF).cuda()
+
+
+def close_bf16(out, ref, what="", ulps=1.0):
+    out, ref = out.float(), ref.float()
+    assert out.shape == ref.shape, (what, out.shape, ref.shape)
+    assert torch.isfinite(out).all(), f"{what}: non-finite output"
+    rms = ref.pow(2).mean().sqrt().item() + 1e-12
+    err = (out - ref).abs()
+    lim = (ref.abs() * 2 ** -8 + 2e-3 * rms) * ulps
+    bad = err > lim
+    assert not bad.any(), f"{what}: {int(bad.sum())} / {bad.numel()} outside tolerance, max err {err.max().item():.3e} (rms {rms:.3e})"
+
+
+def close_f32(out, ref, what="", rel=1e-4):
+    rms = ref.float().pow(2).mean().sqrt().item() + 1e-12
+    err = (out.float() - ref.float()).abs().max().item()
+    assert err <= rel * rms + 1e-6, f"{what}: max err {err:.3e} vs rms {rms:.3e}"
+
+
+# ------------------------------------------------------------------------------------------------------------ GEMM
+def interleave_gate_up(wg, wu):
+    n, k = wg.shape
+    return torch.stack([wg.view(n // 16, 16, k), wu.view(n // 16, 16, k)], dim=1).reshape(2 * n, k)
+
+
+@pytest.mark.parametrize("M,N,K", [(300, 200, 136), (129, 128, 64), (2116, 3840, 1280), (1000, 1280, 3456), (577, 2048, 1176),
+                                   (8, 2048, 2048), (5, 1000, 72), (20, 96, 320), (50, 4, 1280), (64, 1, 1280), (16, 2560, 2048)])
+def test_gemm_plain_bias(ops, M, N, K):
+    a, w, b = rnd(M, K, seed=1), rnd(N, K, scale=0.05, seed=2), rnd(N, seed=3)
+    ref = a.float() @ w.float().T + b.float()
+    n_pad = (N + 3) // 4 * 4
+    out = torch.full((M, n_pad), 7.0, device="cuda", dtype=BF)
+    ops.gemm(a, w, b, out=out)
+    close_bf16(out[:, :N], ref, f"gemm {M}x{N}x{K}")
+    if n_pad != N:
+        assert (out[:, N:] == 7.0).all(), "wrote outside N"
+    out32 = torch.zeros((M, n_pad), device="cuda", dtype=torch.float32)
+    ops.gemm(a, w, None, out=out32, out_f32=True)
+    close_f32(out32[:, :N], a.float() @ w.float().T, f"gemm f32 {M}x{N}x{K}", rel=2e-5)
+
+
+@pytest.mark.parametrize("M", [7, 40, 700])
+def test_gemm_epilogues(ops, M):
+    K, N = 256, 384
+    a, w, b, r = rnd(M, K, seed=4), rnd(N, K, scale=0.06, seed=5), rnd(N, seed=6), rnd(M, N, seed=7)
+    lin = a.float() @ w.float().T + b.float()
+    close_bf16(ops.gemm(a, w, b, epilogue=ops.EPI_GELU), torch.nn.functional.gelu(lin), f"gelu M={M}")
+    close_bf16(ops.gemm(a, w, b, epilogue=ops.EPI_RESID, residual=r), lin + r.float(), f"resid M={M}")
+    out = r.clone()                                           # in-place residual (C aliases R) as the model uses it
+    ops.gemm(a, w, b, out=out, epilogue=ops.EPI_RESID, residual=out)
+    close_bf16(out, lin + r.float(), f"resid inplace M={M}")
+    wg, wu, bg, bu = rnd(N, K, scale=0.06, seed=8), rnd(N, K, scale=0.06, seed=9), rnd(N, seed=10), rnd(N, seed=11)
+    wi = interleave_gate_up(wg, wu)
+    bi = interleave_gate_up(bg.view(N, 1), bu.view(N, 1)).view(-1)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().T + bg.float()) * (a.float() @ wu.float().T + bu.float())
+    close_bf16(ops.gemm(a, wi, bi, epilogue=ops.EPI_SWIGLU), ref, f"swiglu M={M}")
+
+
+def test_gemm_strided_views_and_argument_errors(ops):
+    from padt_amd._lib import PaDTHipError
+    big = rnd(100, 512, seed=12)
+    a = big[:, 128:128 + 200]                                  # row-strided view, 16-byte aligned offset
+    w = rnd(64, 200, scale=0.1, seed=13)
+    close_bf16(ops.gemm(a, w), a.float() @ w.float().T, "strided A")
+    with pytest.raises(PaDTHipError):
+        ops.gemm(big[:, :100], rnd(8, 100))                    # K not a multiple of 8
+
+
+# ------------------------------------------------------------------------------------------------------------ attention
+def ref_attn(q, k, v, cu_q, cu_k, H, Hkv, D, causal):
+    Tq = q.shape[0]
+    out = torch.zeros(Tq, H * D, device=q.device)
+    qf, kf, vf = q.float().view(Tq, H, D), k.float().view(-1, Hkv, D), v.float().view(-1, Hkv, D)
+    rep = H // Hkv
+    for s in range(len(cu_q) - 1):
+        q0, q1, k0, k1 = cu_q[s], cu_q[s + 1], cu_k[s], cu_k[s + 1]
+        if q1 == q0:
+            continue
+        qs = qf[q0:q1].transpose(0, 1)
+        ks = kf[k0:k1].transpose(0, 1).repeat_interleave(rep, 0)
+        vs = vf[k0:k1].transpose(0, 1).repeat_interleave(rep, 0)
+        sc = qs @ ks.transpose(1, 2) * D ** -0.5
+        if causal:
+            Lq, Lk = q1 - q0, k1 - k0
+            sc = sc.masked_fill(~torch.ones(Lq, Lk, dtype=torch.bool, device=q.device).tril(Lk - Lq), float("-inf"))
+        out[q0:q1] = (torch.softmax(sc, -1) @ vs).transpose(0, 1).reshape(q1 - q0, H * D)
+    return out
+
+
+@pytest.mark.parametrize("D,H,Hkv,lens,causal", [
+    (80, 16, 16, [64] * 5 + [48] * 3 + [36], False),          # ViT window layer segments
+    (80, 16, 16, [2116], False),                               # ViT full layer
+    (128, 16, 2, [577, 100, 1, 65], True),                     # LLM prefill, GQA 8:1, ragged
+    (32, 4, 2, [10, 130, 64], True),
+    (64, 2, 2, [70], False),
+])
+def test_attn_self(ops, D, H, Hkv, lens, causal):
+    T = sum(lens)
+    cu = [0]
+    for l in lens:
+        cu.append(cu[-1] + l)
+    qkv = rnd(T, (H + 2 * Hkv) * D, seed=20)
+    q, k, v = qkv[:, : H * D], qkv[:, H * D: (H + Hkv) * D], qkv[:, (H + Hkv) * D:]
+    out = torch.zeros(T, H * D, device="cuda", dtype=BF)
+    cu_t = torch.tensor(cu, dtype=torch.int32, device="cuda")
+    ops.attn_varlen(q, k, v, out, cu_t, cu_t, max(lens), H, Hkv, D, causal=causal)
+    close_bf16(out, ref_attn(q, k, v, cu, cu, H, Hkv, D, causal), f"attn D={D} lens={lens[:3]}..", ulps=6)
+
+
+@pytest.mark.parametrize("lq,lk", [([8, 5, 10], [529, 345, 16]), ([2116, 64], [8, 7]), ([3, 0, 4], [12, 9, 130])])
+def test_attn_cross_decoder_shapes(ops, lq, lk):
+    D, H = 80, 16
+    cq, ck = [0], [0]
+    for a, b in zip(lq, lk):
+        cq.append(cq[-1] + a)
+        ck.append(ck[-1] + b)
+    q, k, v = rnd(cq[-1], H * D, seed=21), rnd(ck[-1], H * D, seed=22), rnd(ck[-1], H * D, seed=23)
+    out = torch.zeros(cq[-1], H * D, device="cuda", dtype=BF)
+    ops.attn_varlen(q, k, v, out, torch.tensor(cq, dtype=torch.int32, device="cuda"),
+                    torch.tensor(ck, dtype=torch.int32, device="cuda"), max(lq), H, H, D)
+    close_bf16(out, ref_attn(q, k, v, cq, ck, H, H, D, False), f"cross {lq}x{lk}", ulps=6)
+
+
+def test_attn_online_softmax_rescale_branch(ops):
+    """One key far above the rest in a late tile forces the running-max rescale (guide §5.4 rule 26)."""
+    D, H, L = 128, 2, 200
+    q, k, v = rnd(L, H * D, seed=24), rnd(L, H * D, seed=25), rnd(L, H * D, seed=26)
+    k[150] = (q[10].float() * 4).to(BF)
+    cu = torch.tensor([0, L], dtype=torch.int32, device="cuda")
+    out = torch.zeros(L, H * D, device="cuda", dtype=BF)
+    ops.attn_varlen(q, k, v, out, cu, cu, L, H, H, D)
+    close_bf16(out, ref_attn(q, k, v, [0, L], [0, L], H, H, D, False), "rescale", ulps=6)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 16, 2), (32, 4, 2)])
+def test_decode_attn(ops, D, Hq, Hkv):
+    B, S_max = 3, 640
+    lens = [578, 130, 64]
+    q = rnd(B, Hq * D, seed=30)
+    kc = rnd(B, Hkv, S_max, D, seed=31)
+    v = rnd(B, Hkv, S_max, D, seed=32)
+    vt = v.transpose(2, 3).contiguous()
+    lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    ws = torch.empty(ops.decode_attn_workspace(B, Hkv, D, S_max), dtype=torch.uint8, device="cuda")
+    out = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
+    ops.decode_attn(q, kc, vt, lens_t, out, ws, Hq, Hkv, D, S_max, max(lens))
+    rep = Hq // Hkv
+    ref = torch.zeros(B, Hq * D, device="cuda")
+    for b in range(B):
+        kk = kc[b, :, : lens[b]].float().repeat_interleave(rep, 0)      # Hq,L,D
+        vv = v[b, :, : lens[b]].float().repeat_interleave(rep, 0)
+        sc = torch.einsum("hd,hld->hl", q[b].float().view(Hq, D), kk) * D ** -0.5
+        ref[b] = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vv).reshape(-1)
+    close_bf16(out, ref, "decode attn", ulps=6)
+
+
+# ------------------------------------------------------------------------------------------------------------ row kernels
+def test_rmsnorm_layernorm(ops):
+    g = ops.rmsnorm(rnd(5, 1280, seed=47), (1 + 0.1 * rnd(1280, seed=41).float()).to(BF), gelu=True)
+    gx = rnd(5, 1280, seed=47).float()
+    close_bf16(g, torch.nn.functional.gelu((1 + 0.1 * rnd(1280, seed=41).float()).to(BF).float() * gx *
+                                           torch.rsqrt(gx.pow(2).mean(-1, keepdim=True) + 1e-6)), "rmsnorm+gelu")
+    x, w, b = rnd(37, 1280, seed=40), (1 + 0.1 * rnd(1280, seed=41).float()).to(BF), rnd(1280, seed=42)
+    xf = x.float()
+    close_bf16(ops.rmsnorm(x, w), w.float() * xf * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6), "rmsnorm")
+    low = rnd(10, 1280, seed=43)
+    y = ops.rmsnorm(x[:37], w, add=low, add_div=4)
+    s = xf + low.float().repeat_interleave(4, 0)[:37]
+    close_bf16(y, w.float() * s * torch.rsqrt(s.pow(2).mean(-1, keepdim=True) + 1e-6), "rmsnorm+repeat4 add")
+    x2 = rnd(9, 2048, seed=44)
+    close_bf16(ops.layernorm(x2, rnd(2048, seed=45), rnd(2048, seed=46)),
+               torch.nn.functional.layer_norm(x2.float(), (2048,), rnd(2048, seed=45).float(), rnd(2048, seed=46).float(), 1e-5), "layernorm")
+
+
+def test_rope_half_gather_add_cast(ops):
+    T, H, D = 50, 32, 80
+    x = rnd(T, 3 * 16 * 80, seed=50)
+    ang = torch.rand(T, 40, device="cuda") * 50
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().contiguous(), emb.sin().contiguous()
+    ref = x.float().clone()
+    v = ref[:, : H * D].view(T, H, D)
+    rot = torch.cat([-v[..., 40:], v[..., :40]], -1)
+    ref[:, : H * D] = (v * cos[:, None] + rot * sin[:, None]).reshape(T, -1)
+    y = x.clone()
+    ops.rope_half_(y, cos, sin, H, D)
+    close_bf16(y, ref, "rope_half")
+    idx = torch.randint(0, T, (77,), device="cuda", dtype=torch.int32)
+    assert torch.equal(ops.gather_rows(x, idx), x[idx.long()])
+    assert torch.equal(ops.gather_rows(cos, idx), cos[idx.long()])
+    a, b = rnd(24, 1280, seed=51), rnd(8, 1280, seed=52)
+    close_bf16(ops.add_rows(a, b), a.float() + b.float().repeat(3, 1), "add_rows")
+    f = torch.randn(33, 1176, device="cuda")
+    c = ops.cast_f32_bf16(f, 1184)
+    assert torch.equal(c[:, :1176], f.to(BF)) and (c[:, 1176:] == 0).all()
+    s = torch.randn(12, device="cuda")
+    close_f32(ops.sigmoid_f32_(s.clone()), torch.sigmoid(s), "sigmoid")
+
+
+def test_embed_tokens(ops):
+    V, NP, D, T = 1000, 37, 256, 64
+    E, P, I = rnd(V, D, seed=60), rnd(NP, D, seed=61), rnd(20, D, seed=62)
+    ids = torch.randint(0, V + NP, (T,), device="cuda")
+    img = torch.full((T,), -1, dtype=torch.int32, device="cuda")
+    img[5:25] = torch.arange(20, dtype=torch.int32, device="cuda")
+    err = torch.zeros(1, dtype=torch.int32, device="cuda")
+    out = ops.embed_tokens(ids, img, E, P, I, err_flag=err)
+    ref = torch.cat([E, P])[ids]
+    ref[5:25] = I
+    assert torch.equal(out, ref) and int(err) == 0
+    ids[0] = V + NP
+    ops.embed_tokens(ids, img, E, P, I, err_flag=err)
+    assert int(err) == 1
+
+
+def test_llm_qkv_post(ops):
+    Hq, Hkv, D, S = 16, 2, 128, 128
+    B, T = 2, 11
+    qkv = rnd(T, (Hq + 2 * Hkv) * D, seed=70)
+    pos = torch.randint(0, 600, (3, T), dtype=torch.int32, device="cuda")
+    sample = torch.tensor([0] * 6 + [1] * 5, dtype=torch.int32, device="cuda")
+    slot = torch.tensor(list(range(6)) + list(range(5)), dtype=torch.int32, device="cuda")
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).cuda()
+    q_out = torch.zeros(T, Hq * D, device="cuda", dtype=BF)
+    kp = torch.zeros(T, Hkv * D, device="cuda", dtype=BF)
+    kc = torch.zeros(B, Hkv, S, D, device="cuda", dtype=BF)
+    vt = torch.zeros(B, Hkv, D, S, device="cuda", dtype=BF)
+    ops.llm_qkv_post(qkv, pos, inv, q_out, kc, vt, Hq, Hkv, D, S, (16, 24, 24), sample=sample, slot=slot, k_pack=kp)
+    fr = pos.float()[..., None] * inv                                  # 3,T,64
+    emb = torch.cat([fr, fr], -1)
+    sec = [16, 24, 24] * 2
+    cos = torch.cat([c[i % 3] for i, c in enumerate(emb.cos().split(sec, -1))], -1)   # T,128
+    sin = torch.cat([c[i % 3] for i, c in enumerate(emb.sin().split(sec, -1))], -1)
+
+    def rope(x):
+        x = x.float()
+        return x * cos[:, None] + torch.cat([-x[..., 64:], x[..., :64]], -1) * sin[:, None]
+    qr = rope(qkv[:, : Hq * D].view(T, Hq, D))
+    kr = rope(qkv[:, Hq * D: (Hq + Hkv) * D].view(T, Hkv, D))
+    vv = qkv[:, (Hq + Hkv) * D:].view(T, Hkv, D)
+    close_bf16(q_out, qr.reshape(T, -1), "mrope q")
+    close_bf16(kp, kr.reshape(T, -1), "mrope k")
+    for t in range(T):
+        b, s = int(sample[t]), int(slot[t])
+        assert torch.equal(kc[b, :, s], kp[t].view(Hkv, D))
+        assert torch.equal(vt[b, :, :, s], vv[t])
+
+
+def test_mask_scatter(ops):
+    dm, n_obj = 80, 3
+    grids = [(6, 8), (6, 8), (4, 4)]
+    pn = [h * w for h, w in grids]
+    cu = [0]
+    for p in pn:
+        cu.append(cu[-1] + p)
+    N = cu[-1]
+    e2 = rnd(4 * N, 4 * dm, seed=80)
+    tok = rnd(n_obj, dm, seed=81)
+    Hm, Wm = 6, 8
+    masks = torch.zeros(n_obj, 4 * Hm, 4 * Wm, device="cuda")
+    ops.mask_scatter(e2, tok, torch.tensor(cu, dtype=torch.int32, device="cuda"),
+                     torch.tensor([w for _, w in grids], dtype=torch.int32, device="cuda"), masks, n_obj, N, dm)
+    ref = torch.zeros_like(masks)
+    e = e2.float().view(N, 2, 2, 2, 2, dm)                           # n, a, b, c, d, k
+    for o in range(n_obj):
+        W = grids[o][1]
+        for pi in range(pn[o]):
+            n = cu[o] + pi
+            r, c_ = pi // W, pi % W
+            lg = (e[n] * tok[o].float()).sum(-1)                     # a,b,c,d
+            blk = lg.permute(0, 2, 1, 3).reshape(4, 4)               # (a,c),(b,d)
+            ref[o, 4 * r: 4 * r + 4, 4 * c_: 4 * c_ + 4] = blk
+    close_f32(masks, ref, "mask_scatter", rel=1e-5)
+
+
+@pytest.mark.parametrize("B", [1, 8, 20])
+def test_vrt_head_and_greedy(ops, B):
+    V, D, per = 3001, 256, 37
+    NP = B * per
+    E, P, h = rnd(V, D, seed=90), rnd(NP, D, seed=91), rnd(B, D, seed=92)
+    off = torch.arange(0, NP + 1, per, dtype=torch.int32, device="cuda")
+    nblk = ops.vrt_head_nblk(V, NP)
+    pv = torch.empty(nblk * B, device="cuda")
+    pi = torch.empty(nblk * B, dtype=torch.int32, device="cuda")
+    logits = torch.zeros(B, V + NP, device="cuda")
+    T_max, eos, pad = 6, 17, 3
+    modes = torch.tensor([0, 1, 2, 3, 0, 0], dtype=torch.int32, device="cuda")
+    full = h.float() @ torch.cat([E, P]).float().T
+    allow = torch.zeros(B, V + NP, dtype=torch.bool, device="cuda")
+    allow[:, :V] = True
+    for b in range(B):
+        allow[b, V + b * per: V + (b + 1) * per] = True
+    unfinished = torch.ones(B, dtype=torch.int32, device="cuda")
+    tokens = torch.zeros(B, T_max, dtype=torch.int64, device="cuda")
+    cur = torch.zeros(B, dtype=torch.int64, device="cuda")
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    slot = torch.full((B,), 5, dtype=torch.int32, device="cuda")
+    lens = torch.full((B,), 6, dtype=torch.int32, device="cuda")
+    pos3 = torch.full((3, B), 9, dtype=torch.int32, device="cuda")
+    hbuf = torch.zeros(T_max, B, D, device="cuda", dtype=BF)
+    exp_unf = torch.ones(B, dtype=torch.bool, device="cuda")
+    for s in range(4):
+        ops.vrt_head(h, E, P, off, pv, pi, eos, mode_table=modes, step=step, logits=logits)
+        m = allow.clone()
+        if s == 1:
+            m[:, V:] = False
+        elif s == 2:
+            m[:, :V] = False
+        elif s == 3:
+            m[:] = False
+            m[:, eos] = True
+        ref = full.masked_fill(~m, float("-inf"))
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(logits), fin), f"mask pattern step {s}"
+        close_f32(logits[fin], ref[fin], "head logits", rel=2e-5)
+        ops.greedy_step(pv, pi, nblk, h, hbuf, unfinished, tokens, cur, step, slot, lens, pos3, eos, pad)
+        want = logits.argmax(-1)                                     # torch.argmax: first max
+        want = torch.where(exp_unf, want, torch.full_like(want, pad))
+        exp_unf = exp_unf & (want != eos)
+        assert torch.equal(tokens[:, s], want), f"tokens step {s}"
+        assert torch.equal(cur, want) and int(step) == s + 1
+        assert torch.equal(unfinished.bool(), exp_unf)
+        assert torch.equal(hbuf[s], h)
+    assert int(slot[0]) == 9 and int(lens[0]) == 10 and int(pos3[2, B - 1]) == 13
+    assert not exp_unf.any()                                        # step 3 forced EOS everywhere
+
+
+def test_vrt_head_tie_breaks_to_lowest_index(ops):
+    V, D = 64, 64
+    E = torch.zeros(V, D, device="cuda", dtype=BF)
+    E[5, 0] = 1.0
+    E[40, 0] = 1.0                                                  # exact tie between rows 5 and 40 (different blocks)
+    P = torch.zeros(16, D, device="cuda", dtype=BF)
+    h = torch.zeros(1, D, device="cuda", dtype=BF)
+    h[0, 0] = 2.0
+    off = torch.tensor([0, 16], dtype=torch.int32, device="cuda")
+    nblk = ops.vrt_head_nblk(V, 16)
+    pv, pi = torch.empty(nblk, device="cuda"), torch.empty(nblk, dtype=torch.int32, device="cuda")
+    ops.vrt_head(h, E, P, off, pv, pi, eos=1)
+    st = [torch.ones(1, dtype=torch.int32, device="cuda"), torch.zeros(1, 2, dtype=torch.int64, device="cuda"),
+          torch.zeros(1, dtype=torch.int64, device="cuda"), torch.zeros(1, dtype=torch.int32, device="cuda")]
+    z = torch.zeros(3, dtype=torch.int32, device="cuda")
+    ops.greedy_step(pv, pi, nblk, h, torch.zeros(2, 1, D, device="cuda", dtype=BF), st[0], st[1], st[2], st[3],
+                    z[:1].clone(), z[:1].clone(), z.clone(), 1, 0)
+    assert int(st[2]) == 5
