@@ -457,7 +457,7 @@ def decode_step(w, cfg: OracleConfig, st: PrefillState, input_ids: Tensor, all_h
 
 def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pixel_values: Tensor,
              grid_thw: Tensor, max_new_tokens: int, schedule: Optional[Sequence[str]] = None,
-             collect_logits: bool = False):
+             collect_logits: bool = False, force_tokens: Optional[Tensor] = None):
     """Greedy loop, padt.py:670-762 (essentials).
 
     ``schedule`` (synthetic-weights only): per step one of 't' (argmax restricted to text rows),
@@ -489,6 +489,8 @@ def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pi
         if collect_logits:
             all_logits.append(nl)
         nxt = torch.argmax(nl, dim=-1)
+        if force_tokens is not None and t < force_tokens.shape[1]:
+            nxt = force_tokens[:, t].clone()                 # teacher forcing (tests: margin rule of SURVEY.md §7)
         nxt = nxt * unfinished + cfg.pad_token_id * (1 - unfinished)
         seq = torch.cat([seq, nxt[:, None]], dim=-1)
         unfinished = unfinished & (nxt != cfg.eos_token_id).long()

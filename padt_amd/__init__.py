@@ -1,0 +1,21 @@
+"""padt_amd — MI355X-native (gfx950 HIP) implementation of PaDT's generate-with-Visual-Reference-Tokens hot path.
+
+Drop-in names of the reference package (src/PaDT/__init__.py:1, src/PaDT/models/__init__.py:1-3):
+``PaDTForConditionalGeneration``, ``PaDTDecoder``, ``VisonTextProcessingClass``, ``parseVRTintoCompletion``.
+Importing the package needs only PyTorch; constructing a model loads libpadt_hip.so and fails loudly without it.
+"""
+from .config import PaDTConfig, VisionConfig, padt_pro_3b, padt_pro_7b, small_test_config
+from .processor import VisonTextProcessingClass, parseVRTintoCompletion
+
+__all__ = ["PaDTForConditionalGeneration", "PaDTDecoder", "VisonTextProcessingClass", "parseVRTintoCompletion",
+           "PaDTConfig", "VisionConfig", "padt_pro_3b", "padt_pro_7b", "small_test_config"]
+
+
+def __getattr__(name):
+    if name == "PaDTForConditionalGeneration":
+        from .modeling import PaDTForConditionalGeneration
+        return PaDTForConditionalGeneration
+    if name == "PaDTDecoder":
+        from .decoder import PaDTDecoder
+        return PaDTDecoder
+    raise AttributeError(name)

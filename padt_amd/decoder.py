@@ -1,0 +1,143 @@
+"""PaDT decoder (padt_decoder.py:131-276) and ``vl_decode`` batching (padt.py:342-412) on the HIP kernels.
+
+Literal reproduction of the reference's conventions: low-res memory = prototypes in raster order,
+high-res memory and rotary tables in ViT window order, added/painted index-wise; RoPE on the image side only, additive
+learned-query "pos" on the query side; query_pos is always the INITIAL query tensor.
+The per-object replication of image memory (padt.py:365-373) is a row gather; the input projection of the low-res
+memory is computed once per image and then replicated (identical rows in, identical rows out).
+"""
+from typing import List, Tuple
+
+import torch
+
+from . import ops
+from .config import PaDTConfig
+
+I32 = torch.int32
+
+
+class PaDTDecoder:
+    def __init__(self, cfg: PaDTConfig, W, device, dtype=torch.bfloat16):
+        self.cfg, self.W, self.device = cfg, W, device
+        self.config = dict(cfg.vl_decoder)
+        self.dtype = dtype
+        self.use_mask_loss = self.config.get("use_mask_loss", True)
+        self.dh = self.config["hidden_size"]
+        self.heads = self.config["num_heads"]
+        self.hd = self.dh // self.heads
+
+    # ---- one attention module (PaDTDecoderFlashAttention2.forward, padt_decoder.py:20-60)
+    def _attention(self, pfx, query, key, cu_q, cu_k, max_q, q_pos, k_pos, rotary, residual):
+        W, H, hd = self.W, self.heads, self.hd
+        q_in = query if rotary[0] else ops.add_rows(query, q_pos)
+        k_in = key if rotary[1] else ops.add_rows(key, k_pos)
+        q = ops.gemm(q_in, W[pfx + "q_proj.w"], W[pfx + "q_proj.b"])
+        k = ops.gemm(k_in, W[pfx + "k_proj.w"], W[pfx + "k_proj.b"])
+        v = ops.gemm(key, W[pfx + "v_proj.w"], W[pfx + "v_proj.b"])
+        if rotary[0]:
+            ops.rope_half_(q, q_pos[0], q_pos[1], H, hd)
+        if rotary[1]:
+            ops.rope_half_(k, k_pos[0], k_pos[1], H, hd)
+        a = torch.empty_like(q)
+        ops.attn_varlen(q, k, v, a, cu_q, cu_k, max_q, H, H, hd)
+        return ops.gemm(a, W[pfx + "proj.w"], W[pfx + "proj.b"], out=residual, epilogue=ops.EPI_RESID, residual=residual)
+
+    # ---- PaDTDecoderBlock.forward, padt_decoder.py:95-128
+    def _block(self, pfx, query, memory, cu_q, cu_m, max_q, max_m, query_pos, memory_pos):
+        W = self.W
+        qn = ops.rmsnorm(query, W[pfx + "norm1"])
+        self._attention(pfx + "self_attn.", qn, qn, cu_q, cu_q, max_q, query_pos, query_pos, (False, False), query)
+        qn = ops.rmsnorm(query, W[pfx + "norm2"])
+        mn = ops.rmsnorm(memory, W[pfx + "norm3"])
+        self._attention(pfx + "cross_attn_query_to_image.", qn, mn, cu_q, cu_m, max_q, query_pos, memory_pos, (False, True), query)
+        n4 = ops.rmsnorm(query, W[pfx + "norm4"])
+        h = ops.gemm(n4, W[pfx + "mlp.0.w"], W[pfx + "mlp.0.b"], epilogue=ops.EPI_GELU)
+        ops.gemm(h, W[pfx + "mlp.2.w"], W[pfx + "mlp.2.b"], out=query, epilogue=ops.EPI_RESID, residual=query)
+        qn = ops.rmsnorm(query, W[pfx + "norm5"])
+        mn = ops.rmsnorm(memory, W[pfx + "norm6"])
+        self._attention(pfx + "cross_attn_image_to_query.", mn, qn, cu_m, cu_q, max_m, memory_pos, query_pos, (True, False), memory)
+        return query, memory
+
+    def _in_proj(self, x):
+        W = self.W
+        n = ops.rmsnorm(x, W["dec.input_projection.0.weight"])
+        h = ops.gemm(n, W["dec.input_projection.1.weight"], W["dec.input_projection.1.bias"], epilogue=ops.EPI_GELU)
+        return ops.gemm(h, W["dec.input_projection.3.weight"], W["dec.input_projection.3.bias"])
+
+    def _mlp3(self, name, x, last_f32=False):
+        W = self.W
+        h = ops.gemm(x, W[f"dec.{name}.0.weight"], W[f"dec.{name}.0.bias"], epilogue=ops.EPI_GELU)
+        h = ops.gemm(h, W[f"dec.{name}.2.weight"], W[f"dec.{name}.2.bias"], epilogue=ops.EPI_GELU)
+        n_out = W[f"dec.{name}.4.weight"].shape[0]
+        out = torch.zeros((x.shape[0], (n_out + 3) // 4 * 4), device=x.device, dtype=torch.float32 if last_f32 else x.dtype)
+        ops.gemm(h, W[f"dec.{name}.4.weight"], W[f"dec.{name}.4.bias"], out=out, out_f32=last_f32)
+        return out[:, :n_out]
+
+    def forward_objects(self, feats_cat, n_vp: List[int], low_img, high_img, pe_img, obj_sample: List[int],
+                        patch_off: List[int], patch_num: List[int], grids: List[List[int]]):
+        """feats_cat (ΣVRT, D_llm); low_img/high_img/pe_img = per-image tensors (all samples concatenated);
+        obj_sample[o] = sample index of object o; patch_off/patch_num per sample."""
+        W, dev, mu = self.W, self.device, self.cfg.merge_unit
+        n_obj = len(n_vp)
+        dh = self.dh
+        # ---- queries: [box, score, mask tokens ‖ proj(feat)+vp_embedding] per object (padt_decoder.py:196-207)
+        feats = ops.add_rows(self._in_proj(feats_cat), W["dec.vp_embedding.weight"])
+        q_rows, cu_q, acc = [], [0], 0
+        # gather index into the stacked [3 learned tokens ; feats] table
+        for n in n_vp:
+            q_rows += [0, 1, 2] + [3 + acc + j for j in range(n)]
+            acc += n
+            cu_q.append(cu_q[-1] + 3 + n)
+        table = torch.cat([W["dec.bbox_score_mask_tokens.weight"], feats], dim=0)
+        cu_query = ops.gather_rows(table, torch.tensor(q_rows, dtype=I32, device=dev))
+        cu_q_t = torch.tensor(cu_q, dtype=I32, device=dev)
+        max_q = max(n_vp) + 3
+        # ---- per-object replication of image memory (padt.py:362-376) as gather indices
+        low_idx, high_idx, cu_p = [], [], [0]
+        for o in range(n_obj):
+            s = obj_sample[o]
+            low_idx.append(torch.arange(patch_off[s] // mu, (patch_off[s] + patch_num[s]) // mu, dtype=I32))
+            high_idx.append(torch.arange(patch_off[s], patch_off[s] + patch_num[s], dtype=I32))
+            cu_p.append(cu_p[-1] + patch_num[s])
+        low_idx = torch.cat(low_idx).to(dev)
+        high_idx = torch.cat(high_idx).to(dev)
+        cu_p_t = torch.tensor(cu_p, dtype=I32, device=dev)
+        cu_l_t = torch.tensor([c // mu for c in cu_p], dtype=I32, device=dev)
+        max_p = max(patch_num[s] for s in obj_sample)
+        low = ops.gather_rows(self._in_proj(low_img), low_idx)            # projection once per image, then replicate
+        high = ops.gather_rows(high_img, high_idx)
+        cos = ops.gather_rows(pe_img[0], high_idx)
+        sin = ops.gather_rows(pe_img[1], high_idx)
+        # low-res PE = PE of every mu-th high-res token (padt_decoder.py:212): strided row view, no copy
+        low_pe = (cos.view(-1, mu * cos.shape[1])[:, : cos.shape[1]], sin.view(-1, mu * sin.shape[1])[:, : sin.shape[1]])
+
+        query_pos = cu_query
+        out = cu_query.clone()
+        out, low = self._block("dec.low_res_transformer.", out, low, cu_q_t, cu_l_t, max_q, max_p // mu, query_pos, low_pe)
+        high = ops.rmsnorm(high, W["dec.high_res_norm.weight"], add=low, add_div=mu)       # padt_decoder.py:220
+        out, high = self._block("dec.high_res_transformer1.", out, high, cu_q_t, cu_p_t, max_q, max_p, query_pos, (cos, sin))
+        out, high = self._block("dec.high_res_transformer2.", out, high, cu_q_t, cu_p_t, max_q, max_p, query_pos, (cos, sin))
+
+        tok_idx = torch.tensor([cu_q[o] + j for j in range(3) for o in range(n_obj)], dtype=I32, device=dev)
+        tok = ops.gather_rows(out, tok_idx)                                # [box tokens ; score tokens ; mask tokens]
+        bbox = self._mlp3("bbox_prediction", tok[:n_obj], last_f32=True).contiguous()
+        ops.sigmoid_f32_(bbox)
+        sc = torch.zeros((n_obj, 4), device=dev, dtype=torch.float32)
+        ops.gemm(tok[n_obj:2 * n_obj], W["dec.score_prediction.weight"], W["dec.score_prediction.bias"], out=sc, out_f32=True)
+        score = sc[:, :1]
+        Hs = torch.tensor([grids[s][1] for s in obj_sample], dtype=torch.int64, device=dev)
+        Ws = torch.tensor([grids[s][2] for s in obj_sample], dtype=torch.int64, device=dev)
+        if not self.use_mask_loss:
+            return bbox, score, None, ()
+        mask_tok = self._mlp3("mask_output_mlp", tok[2 * n_obj:])           # (n_obj, dh/16) row-strided view
+        dm = dh // 16
+        # ---- mask head (padt_decoder.py:241-274): two GEMMs + dot/scatter
+        N = high.shape[0]
+        up1 = ops.gemm(high, W["dec.mask_output_upscaling1.0.weight"], W["dec.mask_output_upscaling1.0.bias"])
+        up1 = ops.rmsnorm(up1, W["dec.mask_output_upscaling1.1.weight"], gelu=True)
+        e2 = ops.gemm(up1.view(4 * N, dh // 4), W["dec.mask_output_upscaling2.0.weight"],
+                      W["dec.mask_output_upscaling2.0.bias"], epilogue=ops.EPI_GELU)
+        Hm, Wm = int(Hs.max()), int(Ws.max())
+        masks = torch.zeros((n_obj, 4 * Hm, 4 * Wm), device=dev, dtype=torch.float32)
+        ops.mask_scatter(e2, mask_tok, cu_p_t, Ws.to(I32), masks, n_obj, N, dm)
+        return bbox, score, masks, (Hs, Ws)

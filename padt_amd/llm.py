@@ -1,0 +1,258 @@
+"""LLM side of the hot loop: dynamic VRT embedding, prefill, hipGraph-replayed decode steps, VRT head, greedy loop.
+
+Host work here is integer bookkeeping (packing, position ids, cache slots) and kernel sequencing; all arithmetic runs in
+libpadt_hip.so.  Differences from the reference's control flow that do not change results:
+  * prompts are PACKED (left-padding is dropped instead of masked) — attention is per-sample varlen, so padded and
+    packed runs see identical keys; rope positions follow transformers==4.50 ``get_rope_index`` and are
+    padding-independent (position of step t = max prompt position + 1 + t);
+  * the [embed_tokens ‖ prototypes] table is never concatenated (padt.py:194,228 rebuild it every forward);
+  * only the last prompt position goes through the VRT head (padt.py:294 computes all L positions, :713 keeps one);
+  * a decode step is ONE captured hipGraph replayed per token; argmax, EOS/pad bookkeeping, token append and the
+    per-step hidden-state stash all happen on device, the host syncs once per `sync_every` steps.
+"""
+from dataclasses import dataclass
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import ops
+from .config import PaDTConfig
+
+I32 = torch.int32
+
+
+# ------------------------------------------------------------------------------------------------ host integer prep
+def rope_index_packed(cfg: PaDTConfig, rows: List[List[int]], grids: List[List[int]]):
+    """transformers==4.50.0 ``get_rope_index`` on unpadded token lists (called at padt.py:263).
+
+    Returns (pos [3][T_total] list-of-lists per sample, next_pos per sample = max+1).
+    text run: running index on all 3 axes; image: t = start, h = start+row, w = start+col over the merged grid;
+    next run starts at previous max + 1.
+    """
+    m = cfg.vision_config.spatial_merge_size
+    out, nxt = [], []
+    gi = 0
+    for toks in rows:
+        chunks: List[torch.Tensor] = []
+        st = 0
+        n_img = sum(1 for i in range(len(toks) - 1)
+                    if toks[i] == cfg.vision_start_token_id and toks[i + 1] == cfg.image_token_id)
+        for _ in range(n_img):
+            ed = toks.index(cfg.image_token_id, st)
+            t, h, w = grids[gi]
+            gi += 1
+            lt, lh, lw = t, h // m, w // m
+            text_len = ed - st
+            st_idx = int(chunks[-1].max()) + 1 if chunks else 0
+            chunks.append(torch.arange(text_len).view(1, -1).expand(3, -1) + st_idx)
+            ti = torch.zeros(lt * lh * lw, dtype=torch.long)
+            hi = torch.arange(lh).view(1, -1, 1).expand(lt, -1, lw).flatten()
+            wi = torch.arange(lw).view(1, 1, -1).expand(lt, lh, -1).flatten()
+            chunks.append(torch.stack([ti, hi, wi]) + text_len + st_idx)
+            st = ed + lt * lh * lw
+        if st < len(toks):
+            st_idx = int(chunks[-1].max()) + 1 if chunks else 0
+            chunks.append(torch.arange(len(toks) - st).view(1, -1).expand(3, -1) + st_idx)
+        pos = torch.cat(chunks, dim=1).reshape(3, -1)
+        out.append(pos)
+        nxt.append(int(pos.max()) + 1)
+    return out, nxt
+
+
+@dataclass
+class PromptPlan:
+    B: int
+    L_pad: int                       # padded prompt length of the caller's (B, L) input
+    lens: List[int]                  # valid tokens per sample
+    ids: torch.Tensor                # (T,) int64 packed global ids
+    img_index: torch.Tensor          # (T,) int32: index into image_embeds or -1
+    pos3: torch.Tensor               # (3, T) int32
+    sample: torch.Tensor             # (T,) int32
+    slot: torch.Tensor               # (T,) int32
+    cu: torch.Tensor                 # (B+1,) int32
+    last_idx: torch.Tensor           # (B,) int32 index of each sample's last token
+    next_pos: List[int]
+    rope_deltas: torch.Tensor        # (B,1) int64, 4.50 convention: max+1 - L_pad
+    vrt_off: List[int]               # (B+1) prototype row offsets
+
+
+def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
+                grid_thw: torch.Tensor, device) -> PromptPlan:
+    ids_cpu = input_ids.detach().cpu()
+    B, L = ids_cpu.shape
+    am = attention_mask.detach().cpu() if attention_mask is not None else torch.ones_like(ids_cpu)
+    grids = [[int(x) for x in r] for r in grid_thw.tolist()]
+    if len(grids) != B:
+        raise ValueError("one image per sample is required (padt.py:301 indexes the logit mask by image)")
+    rows = [ids_cpu[b][am[b] == 1].tolist() for b in range(B)]
+    n_img_tok = sum(r.count(cfg.image_token_id) for r in rows)
+    merged = [g[0] * g[1] * g[2] // cfg.merge_unit for g in grids]
+    if n_img_tok != sum(merged):
+        raise ValueError(f"Image features and image tokens do not match: tokens: {n_img_tok}, features {sum(merged)}")
+    pos, nxt = rope_index_packed(cfg, rows, grids)
+    lens = [len(r) for r in rows]
+    ids = torch.tensor([t for r in rows for t in r], dtype=torch.int64)
+    is_img = ids == cfg.image_token_id
+    img_index = torch.where(is_img, torch.cumsum(is_img.to(torch.int64), 0) - 1, torch.full_like(ids, -1)).to(I32)
+    cu = [0]
+    for l in lens:
+        cu.append(cu[-1] + l)
+    sample = torch.cat([torch.full((l,), b, dtype=I32) for b, l in enumerate(lens)])
+    slot = torch.cat([torch.arange(l, dtype=I32) for l in lens])
+    off = [0]
+    for n in merged:
+        off.append(off[-1] + n)
+    return PromptPlan(
+        B=B, L_pad=L, lens=lens, ids=ids.to(device), img_index=img_index.to(device),
+        pos3=torch.cat(pos, dim=1).to(I32).contiguous().to(device), sample=sample.to(device), slot=slot.to(device),
+        cu=torch.tensor(cu, dtype=I32, device=device), last_idx=torch.tensor([c - 1 for c in cu[1:]], dtype=I32, device=device),
+        next_pos=nxt, rope_deltas=torch.tensor([[n - L] for n in nxt], dtype=torch.int64), vrt_off=off)
+
+
+# ------------------------------------------------------------------------------------------------ decode session
+MODE = {"f": 0, None: 0, "t": 1, "v": 2, "e": 3}
+
+
+class DecodeSession:
+    """Persistent device state for one (batch, S_max, max prototypes, T_max) shape: KV caches, per-step state, the
+    prototype table and the captured decode-step hipGraph.  Pointers are stable across generate() calls so the graph
+    is captured once."""
+
+    def __init__(self, cfg: PaDTConfig, W, B: int, s_max: int, np_max: int, t_max: int, device):
+        self.cfg, self.W, self.B, self.s_max, self.np_max, self.t_max = cfg, W, B, s_max, np_max, t_max
+        D, hd, Hkv, nl = cfg.hidden_size, cfg.head_dim, cfg.num_key_value_heads, cfg.num_hidden_layers
+        bf = torch.bfloat16
+        z = lambda *s, dt=bf: torch.zeros(*s, device=device, dtype=dt)
+        self.kc = [z(B, Hkv, s_max, hd) for _ in range(nl)]
+        self.vtc = [z(B, Hkv, hd, s_max) for _ in range(nl)]
+        self.proto = z(np_max, D)
+        self.vrt_off = z(B + 1, dt=I32)
+        self.mode_table = z(t_max + 1, dt=I32)
+        self.step = z(1, dt=I32)
+        self.unfinished = z(B, dt=I32)
+        self.tokens = z(B, t_max, dt=torch.int64)
+        self.cur_tok = z(B, dt=torch.int64)
+        self.slot = z(B, dt=I32)
+        self.lens = z(B, dt=I32)
+        self.pos3 = z(3, B, dt=I32)
+        self.hidden_buf = z(t_max, B, D)
+        self.nblk = ops.vrt_head_nblk(cfg.vocab_size, np_max)
+        self.part_val = z(self.nblk * B, dt=torch.float32)
+        self.part_idx = z(self.nblk * B, dt=I32)
+        self.attn_ws = torch.empty(ops.decode_attn_workspace(B, Hkv, hd, s_max), dtype=torch.uint8, device=device)
+        half = hd // 2
+        self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(device)
+        assert self.inv_freq.numel() == half
+        # decode-step activations (static addresses → graph-replayable)
+        I = W.llm_ipad
+        self.x = z(B, D)
+        self.n = z(B, D)
+        self.qkv = z(B, (cfg.num_attention_heads + 2 * Hkv) * hd)
+        self.q = z(B, cfg.num_attention_heads * hd)
+        self.att = z(B, cfg.num_attention_heads * hd)
+        self.h = z(B, I)
+        self.hn = z(B, D)
+        self.err = z(1, dt=I32)
+        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.np_cur = np_max
+
+    # one decode step, all on the current stream (eager or under capture)
+    def step_kernels(self):
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x, err_flag=self.err)
+        for i in range(cfg.num_hidden_layers):
+            p = f"llm.{i}."
+            ops.rmsnorm(self.x, W[p + "ln1"], out=self.n, eps=cfg.rms_norm_eps)
+            ops.gemm(self.n, W[p + "qkv.w"], W[p + "qkv.b"], out=self.qkv)
+            ops.llm_qkv_post(self.qkv, self.pos3, self.inv_freq, self.q, self.kc[i], self.vtc[i], Hq, Hkv, hd, self.s_max,
+                             cfg.mrope_section, slot=self.slot)
+            ops.decode_attn(self.q, self.kc[i], self.vtc[i], self.lens, self.att, self.attn_ws, Hq, Hkv, hd, self.s_max,
+                            self.s_max)
+            ops.gemm(self.att, W[p + "o.w"], out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+            ops.rmsnorm(self.x, W[p + "ln2"], out=self.n, eps=cfg.rms_norm_eps)
+            ops.gemm(self.n, W[p + "gu.w"], out=self.h, epilogue=ops.EPI_SWIGLU)
+            ops.gemm(self.h, W[p + "down.w"], out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+        ops.rmsnorm(self.x, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
+        self.head_and_select(self.hn, advance=True)
+
+    def head_and_select(self, hn, advance: bool):
+        cfg, W = self.cfg, self.W
+        ops.vrt_head(hn, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
+                     mode_table=self.mode_table, step=self.step)
+        ops.greedy_step(self.part_val, self.part_idx, self.nblk, hn, self.hidden_buf, self.unfinished, self.tokens,
+                        self.cur_tok, self.step, self.slot, self.lens, self.pos3, cfg.eos_token_id, cfg.pad_token_id,
+                        advance=advance)
+
+    def run_steps(self, n: int, use_graph: bool = True):
+        if n <= 0:
+            return
+        if not use_graph:
+            for _ in range(n):
+                self.step_kernels()
+            return
+        if self.graph is None:
+            self.step_kernels()                              # real step; also pays every one-time kernel attribute call
+            n -= 1
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step_kernels()
+            self.graph = g
+        for _ in range(n):
+            self.graph.replay()
+
+
+class LanguageModel:
+    def __init__(self, cfg: PaDTConfig, W, device):
+        self.cfg, self.W, self.device = cfg, W, device
+        self._sessions = {}
+
+    def prototypes(self, image_embeds: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """padt.py:187-191: LayerNorm then + W2(W1 x)."""
+        W = self.W
+        if not self.cfg.use_visual_prototype_projection:
+            if out is None:
+                return image_embeds.clone()
+            out.copy_(image_embeds)
+            return out
+        p = ops.layernorm(image_embeds, W["proto.norm.w"], W["proto.norm.b"], eps=1e-5)
+        t = ops.gemm(p, W["proto.0.w"])
+        return ops.gemm(t, W["proto.1.w"], out=out, epilogue=ops.EPI_RESID, residual=p)
+
+    def session(self, B: int, need_s: int, need_np: int, need_t: int) -> DecodeSession:
+        s_max = (need_s + 63) // 64 * 64
+        key = B
+        s = self._sessions.get(key)
+        if s is None or s.s_max < s_max or s.np_max < need_np or s.t_max < need_t:
+            s = DecodeSession(self.cfg, self.W, B, max(s_max, s.s_max if s else 0), max(need_np, s.np_max if s else 0),
+                              max(need_t, s.t_max if s else 0), self.device)
+            self._sessions[key] = s
+        return s
+
+    def prefill(self, plan: PromptPlan, image_embeds: torch.Tensor, sess: DecodeSession):
+        """Packed prefill; fills the session's KV caches; returns the post-norm hidden states of all prompt tokens (T,D)."""
+        cfg, W = self.cfg, self.W
+        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        T = plan.ids.numel()
+        dev = image_embeds.device
+        bf = torch.bfloat16
+        x = ops.embed_tokens(plan.ids, plan.img_index, W["llm.embed"], sess.proto, image_embeds, err_flag=sess.err)
+        n = torch.empty_like(x)
+        qkv = torch.empty((T, (Hq + 2 * Hkv) * hd), device=dev, dtype=bf)
+        q = torch.empty((T, Hq * hd), device=dev, dtype=bf)
+        kp = torch.empty((T, Hkv * hd), device=dev, dtype=bf)
+        att = torch.empty((T, Hq * hd), device=dev, dtype=bf)
+        h = torch.empty((T, W.llm_ipad), device=dev, dtype=bf)
+        mx = max(plan.lens)
+        for i in range(cfg.num_hidden_layers):
+            p = f"llm.{i}."
+            ops.rmsnorm(x, W[p + "ln1"], out=n, eps=cfg.rms_norm_eps)
+            ops.gemm(n, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv)
+            ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
+                             cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
+            ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
+            ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
+            ops.rmsnorm(x, W[p + "ln2"], out=n, eps=cfg.rms_norm_eps)
+            ops.gemm(n, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU)
+            ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
+        return ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)

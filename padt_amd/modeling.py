@@ -1,0 +1,251 @@
+"""``PaDTForConditionalGeneration`` — drop-in surface of ``src/PaDT/models/padt.py`` on the MI355X HIP path.
+
+Kept callable exactly as the reference's callers use them (eval/test_demo.py:20-113, eval/evaluation_scripts/utils.py:
+194-246): ``from_pretrained``, ``generate(**processor_outputs, use_cache=True, max_new_tokens=…, do_sample=False,
+output_hidden_states=True, return_dict_in_generate=True[, synced_gpus=False])`` → object with ``.sequences /
+.hidden_states / .past_image_embeds / .past_logit_mask / .past_high_res_image_embeds / .past_visual_pe`` (attribute and
+``['key']`` access, padt.py:786-798), ``vl_decode(feats, low, high, image_grid_thw, visual_pe)`` → dict (padt.py:397-412),
+``.config.vision_config.spatial_merge_size`` and ``.model.embed_tokens.weight.shape[0]``.
+
+There is no HuggingFace modeling code and no PyTorch compute on this path: the methods sequence kernels from
+libpadt_hip.so (see vision.py / llm.py / decoder.py) and fail loudly if that library is missing.
+"""
+import json
+import os
+from types import SimpleNamespace
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _lib, ops
+from .config import PaDTConfig
+from .decoder import PaDTDecoder
+from .llm import MODE, LanguageModel, plan_prompt
+from .vision import VisionEncoder
+from .weights import load_checkpoint_state_dict, prepare_weights, synthetic_state_dict
+
+
+class StepHiddenStates:
+    """Lazy stand-in for HF's ``hidden_states`` (T-tuple of per-layer tuples): ``hs[step][-1]`` is the last-layer,
+    post-final-norm state that predicted completion token ``step`` — (B, L, D) for step 0, (B, 1, D) afterwards
+    (padt.py:732-737; consumed at padt_processor.py:125).  Only the last layer is retained."""
+
+    class _Layers:
+        def __init__(self, last):
+            self._last = last
+
+        def __getitem__(self, i):
+            if i in (-1,):
+                return self._last()
+            raise IndexError("only the last layer ([-1]) is retained on the MI355X path")
+
+        def __len__(self):
+            return 1
+
+    def __init__(self, hidden_buf, n_steps, prefill_packed, lens, L_pad):
+        self.buf, self.n, self.prefill, self.lens, self.L = hidden_buf, n_steps, prefill_packed, lens, L_pad
+        self._prefill_padded = None
+
+    def __len__(self):
+        return self.n
+
+    def _step0(self):
+        if self._prefill_padded is None:
+            B, D = len(self.lens), self.prefill.shape[1]
+            out = torch.zeros((B, self.L, D), device=self.prefill.device, dtype=self.prefill.dtype)
+            o = 0
+            for b, l in enumerate(self.lens):
+                out[b, self.L - l:] = self.prefill[o:o + l]          # left padding, as the reference's callers produce
+                o += l
+            self._prefill_padded = out
+        return self._prefill_padded
+
+    def __getitem__(self, step):
+        if isinstance(step, slice):
+            return [self[i] for i in range(*step.indices(self.n))]
+        if step < 0:
+            step += self.n
+        if not 0 <= step < self.n:
+            raise IndexError(step)
+        if step == 0:
+            return self._Layers(self._step0)
+        return self._Layers(lambda s=step: self.buf[s].unsqueeze(1))
+
+    def last_layer_rows(self):
+        """(T, B, D) tensor of the per-step last-position states (step 0 = last prompt position)."""
+        return self.buf[: self.n]
+
+
+class CustomGenerateDecoderOnlyOutput(dict):
+    """Attribute + item access like HF's ModelOutput (padt.py:40-45)."""
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+class PaDTForConditionalGeneration:
+    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16):
+        if dtype != torch.bfloat16:
+            raise ValueError("the MI355X path computes in bf16 (fp32 accumulate); pass torch_dtype=torch.bfloat16")
+        _lib.load()                                            # fail loudly before touching any weight
+        self.config = config
+        self.device = torch.device(device)
+        self.dtype = dtype
+        self.W = prepare_weights(state_dict, config, self.device)
+        self.visual = VisionEncoder(config, self.W, self.device)
+        self.lm = LanguageModel(config, self.W, self.device)
+        self.vl_decoder = PaDTDecoder(config, self.W, self.device, dtype)
+        self.model = SimpleNamespace(embed_tokens=SimpleNamespace(weight=self.W["llm.embed"]))
+        self.use_visual_prototype_projection = config.use_visual_prototype_projection
+        self.rope_deltas = None
+
+    # ------------------------------------------------------------------ construction
+    @classmethod
+    def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.bfloat16, attn_implementation=None,
+                        device_map=None, config=None, **_):
+        """Loads ``config.json`` + ``*.safetensors`` (checkpoint key layout of PaDT-MLLM/PaDT_*).  ``attn_implementation``
+        is accepted and ignored: attention is always the HIP flash kernel."""
+        path = str(pretrained_model_name_or_path)
+        if not os.path.isdir(path):
+            raise FileNotFoundError(f"{path}: checkpoints must be a local directory (no hub access on this path)")
+        if config is None:
+            config = PaDTConfig.from_hf_dict(json.load(open(os.path.join(path, "config.json"))))
+        elif isinstance(config, dict):
+            config = PaDTConfig.from_hf_dict(config)
+        device = "cuda"
+        if isinstance(device_map, dict) and "" in device_map:
+            d = device_map[""]
+            device = f"cuda:{d}" if isinstance(d, int) else str(d)
+        elif isinstance(device_map, (str, torch.device)):
+            device = str(device_map)
+        return cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype)
+
+    @classmethod
+    def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
+        """Random-init weights of the given architecture (no checkpoints offline)."""
+        sd = state_dict if state_dict is not None else synthetic_state_dict(config, seed=seed, device=device,
+                                                                            dtype=torch.bfloat16, **kw)
+        return cls(config, sd, device=device)
+
+    def eval(self):
+        return self
+
+    # ------------------------------------------------------------------ generate (padt.py:414-616 → 618-800)
+    @torch.no_grad()
+    def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
+                 max_new_tokens=1024, do_sample=False, output_hidden_states=True, return_dict_in_generate=True,
+                 synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
+                 use_graph: bool = True, **unused):
+        """Greedy generation over the unified text‖VRT vocabulary.
+
+        ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
+        VRT rows only, 'e' force EOS, None free — applied where HF's ``logits_processor`` sits (padt.py:717).
+        """
+        if do_sample:
+            raise NotImplementedError("sampling (padt.py:740-743) is not on the accelerated path; use do_sample=False")
+        if pixel_values is None or image_grid_thw is None:
+            raise ValueError("pixel_values and image_grid_thw are required (text-only input crashes in the reference too, "
+                             "padt.py:292 with image_prototypes unbound)")
+        cfg, dev = self.config, self.device
+        grid = image_grid_thw.detach().cpu().long()
+        plan = plan_prompt(cfg, input_ids, attention_mask, grid, dev)
+        B = plan.B
+        T_max = int(max_new_tokens)
+        n_proto = plan.vrt_off[-1]
+        sess = self.lm.session(B, max(plan.lens) + T_max, n_proto, T_max)
+
+        # ---- ViT → prototypes → session table
+        low, high, pe = self.visual(pixel_values.to(dev), grid)
+        proto = self.lm.prototypes(low, out=sess.proto[:n_proto])
+        # ---- per-generate device state
+        st = torch.zeros(T_max + 1, dtype=torch.int32)
+        if schedule is not None:
+            for i, m in enumerate(schedule[: T_max]):
+                st[i] = MODE[m]
+        sess.mode_table[: T_max + 1].copy_(st.to(dev))
+        off = torch.tensor(plan.vrt_off + [plan.vrt_off[-1]] * (sess.B + 1 - len(plan.vrt_off)), dtype=torch.int32)
+        sess.vrt_off.copy_(off.to(dev))
+        sess.step.zero_()
+        sess.unfinished.fill_(1)
+        sess.err.zero_()
+        lens_t = torch.tensor(plan.lens, dtype=torch.int32)
+        sess.slot.copy_(lens_t.to(dev))                           # next append index
+        sess.lens.copy_((lens_t + 1).to(dev))                     # keys visible to the next token
+        sess.pos3.copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev))
+        self.rope_deltas = plan.rope_deltas
+
+        # ---- prefill + first token
+        hn_all = self.lm.prefill(plan, low, sess)
+        h_last = ops.gather_rows(hn_all, plan.last_idx)
+        sess.head_and_select(h_last, advance=False)
+
+        # ---- decode steps: hipGraph replays, host sync every `sync_every` steps
+        done_steps = 1
+        while done_steps < T_max:
+            n = min(sync_every, T_max - done_steps)
+            sess.run_steps(n, use_graph=use_graph)
+            done_steps += n
+            if not bool(sess.unfinished.any()):
+                break
+        if int(sess.err) != 0:
+            raise AssertionError("input_ids.max() >= extended table rows (padt.py:203)")
+        toks = sess.tokens[:, :done_steps].clone()
+        # reference stops right after the step in which the last sequence finished (padt.py:756-757)
+        eos_hit = (toks == cfg.eos_token_id)
+        if bool(eos_hit.any(dim=1).all()):
+            stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
+            toks = toks[:, :stop]
+        n_steps = toks.shape[1]
+        sequences = torch.cat([input_ids.to(dev), toks], dim=1)
+        hidden = StepHiddenStates(sess.hidden_buf[:n_steps].clone(), n_steps, hn_all.clone(),
+                                  plan.lens, plan.L_pad)
+        table_rows = cfg.vocab_size + n_proto
+
+        def logit_mask():
+            m = torch.zeros((B, table_rows), dtype=torch.bool, device=dev)
+            m[:, : cfg.vocab_size] = True
+            for b in range(B):
+                m[b, cfg.vocab_size + plan.vrt_off[b]: cfg.vocab_size + plan.vrt_off[b + 1]] = True
+            return m
+
+        out = CustomGenerateDecoderOnlyOutput(
+            sequences=sequences, scores=None, logits=None, attentions=None,
+            hidden_states=hidden if output_hidden_states else None, past_key_values=sess,
+            past_image_embeds=proto.clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=high,
+            past_visual_pe=pe)
+        return out if return_dict_in_generate else sequences
+
+    # ------------------------------------------------------------------ vl_decode (padt.py:342-412)
+    @torch.no_grad()
+    def vl_decode(self, object_vp_feats, low_res_image_embeds, high_res_image_embeds, image_grid_thws, visual_pes):
+        cfg, dev = self.config, self.device
+        flat = sum(object_vp_feats, [])
+        if len(flat) == 0:                                        # padt.py:406-412 (the dummy pass of 383-393 is skipped)
+            return {"pred_boxes": torch.zeros((0, 4), device=dev, dtype=self.dtype),
+                    "pred_score": torch.zeros((0, 1), device=dev, dtype=self.dtype),
+                    "pred_mask": torch.zeros((0, 8, 8), device=dev, dtype=self.dtype),
+                    "pred_mask_valid_hw": (), "sample_idx": []}
+        grids = [[int(x) for x in g] for g in torch.as_tensor(image_grid_thws).tolist()]
+        patch_num = [g[0] * g[1] * g[2] for g in grids]
+        patch_off = [0]
+        for n in patch_num:
+            patch_off.append(patch_off[-1] + n)
+        obj_sample, n_vp = [], []
+        for si, feats in enumerate(object_vp_feats):
+            for f in feats:
+                obj_sample.append(si)
+                n_vp.append(int(f.shape[0]))
+        feats_cat = torch.cat([f.to(dev, torch.bfloat16) for f in flat], dim=0).contiguous()
+        bbox, score, masks, hw = self.vl_decoder.forward_objects(
+            feats_cat, n_vp, low_res_image_embeds, high_res_image_embeds, visual_pes, obj_sample, patch_off, patch_num, grids)
+        return {"pred_boxes": bbox, "pred_score": score, "pred_mask": masks, "pred_mask_valid_hw": hw,
+                "sample_idx": obj_sample}
+
+    def forward(self, *args, is_main=True, **kwargs):
+        if is_main:
+            raise NotImplementedError("teacher-forced forward_main is a training surface (out of scope); use generate()")
+        return self.vl_decode(*args, **kwargs)
+
+    __call__ = forward

@@ -1,0 +1,278 @@
+"""Checkpoint → MI355X weight layout.
+
+Input: a state dict with the checkpoint's (HF-4.50) key names — ``visual.*``, ``model.*``, ``lm_head.weight``,
+``vis_norm.*``, ``vis_proj.*``, ``vl_decoder.*`` — from safetensors shards or from
+``synthetic_state_dict`` (no checkpoints exist offline).  Output: ``PreparedWeights``, bf16 device tensors laid out for
+the kernels in libpadt_hip.so:
+  * every Linear stays [out][in] (K-contiguous = MFMA operand order), conv3d patch-embed flattened to [hidden][C*T*p*p];
+  * LLM q/k/v fused into one [Hq*D + 2*Hkv*D][hidden] matrix (+ fused bias);
+  * SwiGLU gate/up interleaved in 16-row blocks ([gate16 | up16] ...) so one GEMM tile holds matching gate/up columns
+    and the activation is fused into the epilogue; MLP intermediates zero-padded to a multiple of 64 (3420 → 3456).
+"""
+import json
+import math
+import os
+import zlib
+from typing import Dict, Optional
+
+import torch
+
+from .config import PaDTConfig
+
+BF16 = torch.bfloat16
+
+
+def _pad_to(n: int, m: int) -> int:
+    return (n + m - 1) // m * m
+
+
+# ------------------------------------------------------------------------------------------------- key → shape table
+def weight_shapes(cfg: PaDTConfig) -> Dict[str, tuple]:
+    v = cfg.vision_config
+    s: Dict[str, tuple] = {}
+    vh, vi = v.hidden_size, v.intermediate_size
+    s["visual.patch_embed.proj.weight"] = (vh, v.in_channels, v.temporal_patch_size, v.patch_size, v.patch_size)
+    for i in range(v.depth):
+        p = f"visual.blocks.{i}."
+        s[p + "norm1.weight"] = (vh,)
+        s[p + "norm2.weight"] = (vh,)
+        s[p + "attn.qkv.weight"] = (3 * vh, vh)
+        s[p + "attn.qkv.bias"] = (3 * vh,)
+        s[p + "attn.proj.weight"] = (vh, vh)
+        s[p + "attn.proj.bias"] = (vh,)
+        for n_, a, b in (("gate_proj", vi, vh), ("up_proj", vi, vh), ("down_proj", vh, vi)):
+            s[p + f"mlp.{n_}.weight"] = (a, b)
+            s[p + f"mlp.{n_}.bias"] = (a,)
+    mh = vh * cfg.merge_unit
+    s["visual.merger.ln_q.weight"] = (vh,)
+    s["visual.merger.mlp.0.weight"] = (mh, mh)
+    s["visual.merger.mlp.0.bias"] = (mh,)
+    s["visual.merger.mlp.2.weight"] = (cfg.hidden_size, mh)
+    s["visual.merger.mlp.2.bias"] = (cfg.hidden_size,)
+    D, I, hd = cfg.hidden_size, cfg.intermediate_size, cfg.head_dim
+    s["model.embed_tokens.weight"] = (cfg.vocab_size, D)
+    for i in range(cfg.num_hidden_layers):
+        p = f"model.layers.{i}."
+        s[p + "input_layernorm.weight"] = (D,)
+        s[p + "post_attention_layernorm.weight"] = (D,)
+        s[p + "self_attn.q_proj.weight"] = (cfg.num_attention_heads * hd, D)
+        s[p + "self_attn.q_proj.bias"] = (cfg.num_attention_heads * hd,)
+        for n_ in ("k_proj", "v_proj"):
+            s[p + f"self_attn.{n_}.weight"] = (cfg.num_key_value_heads * hd, D)
+            s[p + f"self_attn.{n_}.bias"] = (cfg.num_key_value_heads * hd,)
+        s[p + "self_attn.o_proj.weight"] = (D, cfg.num_attention_heads * hd)
+        s[p + "mlp.gate_proj.weight"] = (I, D)
+        s[p + "mlp.up_proj.weight"] = (I, D)
+        s[p + "mlp.down_proj.weight"] = (D, I)
+    s["model.norm.weight"] = (D,)
+    if not cfg.tie_word_embeddings:
+        s["lm_head.weight"] = (cfg.vocab_size, D)
+    if cfg.use_visual_prototype_projection:
+        s["vis_norm.weight"] = (D,)
+        s["vis_norm.bias"] = (D,)
+        s["vis_proj.0.weight"] = (cfg.lora_r, D)
+        s["vis_proj.1.weight"] = (D, cfg.lora_r)
+    dh, di = cfg.vl_decoder["hidden_size"], cfg.vl_decoder["intermediate_size"]
+    p = "vl_decoder."
+    s[p + "vp_embedding.weight"] = (1, dh)
+    s[p + "bbox_score_mask_tokens.weight"] = (3, dh)
+    s[p + "input_projection.0.weight"] = (D,)
+    s[p + "input_projection.1.weight"] = (dh, D)
+    s[p + "input_projection.1.bias"] = (dh,)
+    s[p + "input_projection.3.weight"] = (dh, dh)
+    s[p + "input_projection.3.bias"] = (dh,)
+    for blk in ("low_res_transformer", "high_res_transformer1", "high_res_transformer2"):
+        b = p + blk + "."
+        for k in range(1, 7):
+            s[b + f"norm{k}.weight"] = (dh,)
+        for att in ("self_attn", "cross_attn_query_to_image", "cross_attn_image_to_query"):
+            for pr in ("q_proj", "k_proj", "v_proj", "proj"):
+                s[b + f"{att}.{pr}.weight"] = (dh, dh)
+                s[b + f"{att}.{pr}.bias"] = (dh,)
+        s[b + "mlp.0.weight"] = (di, dh)
+        s[b + "mlp.0.bias"] = (di,)
+        s[b + "mlp.2.weight"] = (dh, di)
+        s[b + "mlp.2.bias"] = (dh,)
+    s[p + "high_res_norm.weight"] = (dh,)
+    for name, last in (("bbox_prediction", 4), ("mask_output_mlp", dh // 16)):
+        s[p + name + ".0.weight"] = (dh, dh)
+        s[p + name + ".0.bias"] = (dh,)
+        s[p + name + ".2.weight"] = (dh, dh)
+        s[p + name + ".2.bias"] = (dh,)
+        s[p + name + ".4.weight"] = (last, dh)
+        s[p + name + ".4.bias"] = (last,)
+    s[p + "score_prediction.weight"] = (1, dh)
+    s[p + "score_prediction.bias"] = (1,)
+    s[p + "mask_output_upscaling1.0.weight"] = (dh // 4 * 4, dh)
+    s[p + "mask_output_upscaling1.0.bias"] = (dh // 4 * 4,)
+    s[p + "mask_output_upscaling1.1.weight"] = (dh // 4 * 4,)
+    s[p + "mask_output_upscaling2.0.weight"] = (dh // 16 * 4, dh // 4)
+    s[p + "mask_output_upscaling2.0.bias"] = (dh // 16 * 4,)
+    return s
+
+
+def is_norm_weight(name: str) -> bool:
+    return (name.endswith("norm.weight") or "layernorm.weight" in name or ".ln_q.weight" in name
+            or any(name.endswith(f"norm{k}.weight") for k in range(1, 7))
+            or name.endswith("input_projection.0.weight") or name.endswith("mask_output_upscaling1.1.weight"))
+
+
+def synthetic_state_dict(cfg: PaDTConfig, seed: int = 0, std: float = 0.02, bias_std: float = 0.0,
+                         norm_jitter: float = 0.0, device="cpu", dtype=torch.float32) -> Dict[str, torch.Tensor]:
+    """Seeded random-init weights: N(0,std²) matrices, norm weights 1 (+jitter), biases 0 (or N(0,bias_std²)).
+
+    On CPU every tensor has its own generator seeded from (seed, crc32(key)) — the rule the test oracle uses, so both
+    sides can build identical weights independently.  On a CUDA device the same rule seeds a device generator (fast
+    path for the 3.85 B-parameter bench model; values differ from the CPU stream, distribution identical).
+    """
+    out = {}
+    dev = torch.device(device)
+    for name, shape in weight_shapes(cfg).items():
+        g = torch.Generator(device=dev).manual_seed((seed * 1000003 + zlib.crc32(name.encode())) & 0x7FFFFFFF)
+        if is_norm_weight(name):
+            t = torch.ones(shape, device=dev)
+            if norm_jitter > 0:
+                t = t + torch.randn(shape, generator=g, device=dev) * norm_jitter
+        elif name.endswith(".bias"):
+            t = torch.randn(shape, generator=g, device=dev) * bias_std if bias_std > 0 else torch.zeros(shape, device=dev)
+        else:
+            t = torch.randn(shape, generator=g, device=dev) * std
+        out[name] = t.to(dtype)
+    return out
+
+
+def load_checkpoint_state_dict(path: str) -> Dict[str, torch.Tensor]:
+    """Read every ``*.safetensors`` shard under ``path`` (HF layout, optional index json)."""
+    from safetensors.torch import load_file
+    files = sorted(f for f in os.listdir(path) if f.endswith(".safetensors"))
+    if not files:
+        raise FileNotFoundError(f"no *.safetensors under {path}")
+    sd: Dict[str, torch.Tensor] = {}
+    for f in files:
+        sd.update(load_file(os.path.join(path, f)))
+    # 5.x-style nesting ("model.language_model.", "model.visual.") → 4.50 names
+    ren = {}
+    for k, v in sd.items():
+        k2 = k
+        if k2.startswith("model.language_model."):
+            k2 = "model." + k2[len("model.language_model."):]
+        elif k2.startswith("model.visual."):
+            k2 = k2[len("model."):]
+        ren[k2] = v
+    return ren
+
+
+# ------------------------------------------------------------------------------------------------- prepared layout
+def interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[gate16 | up16 | gate16 | up16 ...] along dim 0 (rows already padded to a multiple of 16)."""
+    n = a.shape[0]
+    rest = a.shape[1:]
+    return torch.stack([a.reshape(n // 16, 16, *rest), b.reshape(n // 16, 16, *rest)], dim=1).reshape(2 * n, *rest)
+
+
+def _pad_rows(t: torch.Tensor, n: int) -> torch.Tensor:
+    if t.shape[0] == n:
+        return t
+    out = t.new_zeros((n,) + tuple(t.shape[1:]))
+    out[: t.shape[0]] = t
+    return out
+
+
+def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
+    if t.shape[1] == n:
+        return t
+    out = t.new_zeros((t.shape[0], n))
+    out[:, : t.shape[1]] = t
+    return out
+
+
+class PreparedWeights(dict):
+    """name → bf16 device tensor (kernel layout).  Plain dict plus a few derived sizes."""
+    vit_ipad: int
+    llm_ipad: int
+    dec_ipad: int
+
+
+def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda") -> PreparedWeights:
+    dev = torch.device(device)
+    W = PreparedWeights()
+
+    def put(name, t):
+        W[name] = t.to(device=dev, dtype=BF16).contiguous()
+
+    def get(name):
+        if name not in sd:
+            raise KeyError(f"checkpoint is missing '{name}'")
+        return sd[name]
+
+    v = cfg.vision_config
+    vi_pad = _pad_to(v.intermediate_size, 64)
+    W.vit_ipad = vi_pad
+    put("vit.patch_embed", get("visual.patch_embed.proj.weight").reshape(v.hidden_size, -1))
+    for i in range(v.depth):
+        s, d = f"visual.blocks.{i}.", f"vit.{i}."
+        put(d + "norm1", get(s + "norm1.weight"))
+        put(d + "norm2", get(s + "norm2.weight"))
+        put(d + "qkv.w", get(s + "attn.qkv.weight"))
+        put(d + "qkv.b", get(s + "attn.qkv.bias"))
+        put(d + "proj.w", get(s + "attn.proj.weight"))
+        put(d + "proj.b", get(s + "attn.proj.bias"))
+        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight"), vi_pad), _pad_rows(get(s + "mlp.up_proj.weight"), vi_pad)))
+        put(d + "gu.b", interleave16(_pad_rows(get(s + "mlp.gate_proj.bias"), vi_pad), _pad_rows(get(s + "mlp.up_proj.bias"), vi_pad)))
+        put(d + "down.w", _pad_cols(get(s + "mlp.down_proj.weight"), vi_pad))
+        put(d + "down.b", get(s + "mlp.down_proj.bias"))
+    put("vit.merger.ln_q", get("visual.merger.ln_q.weight"))
+    put("vit.merger.0.w", get("visual.merger.mlp.0.weight"))
+    put("vit.merger.0.b", get("visual.merger.mlp.0.bias"))
+    put("vit.merger.2.w", get("visual.merger.mlp.2.weight"))
+    put("vit.merger.2.b", get("visual.merger.mlp.2.bias"))
+
+    li_pad = _pad_to(cfg.intermediate_size, 64)
+    W.llm_ipad = li_pad
+    put("llm.embed", get("model.embed_tokens.weight"))
+    put("llm.head", get("model.embed_tokens.weight") if cfg.tie_word_embeddings else get("lm_head.weight"))
+    if cfg.tie_word_embeddings:
+        W["llm.head"] = W["llm.embed"]
+    for i in range(cfg.num_hidden_layers):
+        s, d = f"model.layers.{i}.", f"llm.{i}."
+        put(d + "ln1", get(s + "input_layernorm.weight"))
+        put(d + "ln2", get(s + "post_attention_layernorm.weight"))
+        put(d + "qkv.w", torch.cat([get(s + "self_attn.q_proj.weight"), get(s + "self_attn.k_proj.weight"), get(s + "self_attn.v_proj.weight")], 0))
+        put(d + "qkv.b", torch.cat([get(s + "self_attn.q_proj.bias"), get(s + "self_attn.k_proj.bias"), get(s + "self_attn.v_proj.bias")], 0))
+        put(d + "o.w", get(s + "self_attn.o_proj.weight"))
+        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(get(s + "mlp.up_proj.weight"), li_pad)))
+        put(d + "down.w", _pad_cols(get(s + "mlp.down_proj.weight"), li_pad))
+    put("llm.norm", get("model.norm.weight"))
+    if cfg.use_visual_prototype_projection:
+        put("proto.norm.w", get("vis_norm.weight"))
+        put("proto.norm.b", get("vis_norm.bias"))
+        put("proto.0.w", get("vis_proj.0.weight"))
+        put("proto.1.w", get("vis_proj.1.weight"))
+
+    dh, di = cfg.vl_decoder["hidden_size"], cfg.vl_decoder["intermediate_size"]
+    di_pad = _pad_to(di, 64)
+    W.dec_ipad = di_pad
+    p = "vl_decoder."
+    for name in ("vp_embedding.weight", "bbox_score_mask_tokens.weight", "input_projection.0.weight",
+                 "input_projection.1.weight", "input_projection.1.bias", "input_projection.3.weight",
+                 "input_projection.3.bias", "high_res_norm.weight", "score_prediction.weight", "score_prediction.bias",
+                 "mask_output_upscaling1.0.weight", "mask_output_upscaling1.0.bias", "mask_output_upscaling1.1.weight",
+                 "mask_output_upscaling2.0.weight", "mask_output_upscaling2.0.bias"):
+        put("dec." + name, get(p + name))
+    for head in ("bbox_prediction", "mask_output_mlp"):
+        for k in (0, 2, 4):
+            put(f"dec.{head}.{k}.weight", get(p + f"{head}.{k}.weight"))
+            put(f"dec.{head}.{k}.bias", get(p + f"{head}.{k}.bias"))
+    for blk in ("low_res_transformer", "high_res_transformer1", "high_res_transformer2"):
+        s, d = p + blk + ".", "dec." + blk + "."
+        for k in range(1, 7):
+            put(d + f"norm{k}", get(s + f"norm{k}.weight"))
+        for att in ("self_attn", "cross_attn_query_to_image", "cross_attn_image_to_query"):
+            for pr in ("q_proj", "k_proj", "v_proj", "proj"):
+                put(d + f"{att}.{pr}.w", get(s + f"{att}.{pr}.weight"))
+                put(d + f"{att}.{pr}.b", get(s + f"{att}.{pr}.bias"))
+        put(d + "mlp.0.w", _pad_rows(get(s + "mlp.0.weight"), di_pad))
+        put(d + "mlp.0.b", _pad_rows(get(s + "mlp.0.bias"), di_pad))
+        put(d + "mlp.2.w", _pad_cols(get(s + "mlp.2.weight"), di_pad))
+        put(d + "mlp.2.b", get(s + "mlp.2.bias"))
+    return W

@@ -1,0 +1,97 @@
+"""Shared helpers for the GPU parity tests / smoke / bench cpu_baseline: build matching product + oracle models from the
+same seeded bf16-representable weights, synthetic prompts, a fake tokenizer for the parser."""
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import padt_oracle as O  # noqa: E402  (test infrastructure — never imported by padt_amd/)
+from padt_amd.config import PaDTConfig  # noqa: E402
+from padt_amd.weights import synthetic_state_dict  # noqa: E402
+
+
+def oracle_config(cfg: PaDTConfig) -> O.OracleConfig:
+    v = cfg.vision_config
+    d = cfg.vl_decoder
+    return O.OracleConfig(
+        vocab_size=cfg.vocab_size, hidden_size=cfg.hidden_size, num_layers=cfg.num_hidden_layers,
+        num_heads=cfg.num_attention_heads, num_kv_heads=cfg.num_key_value_heads, head_dim=cfg.head_dim,
+        intermediate_size=cfg.intermediate_size, rms_eps=cfg.rms_norm_eps, rope_theta=cfg.rope_theta,
+        mrope_section=tuple(cfg.mrope_section), tie_word_embeddings=cfg.tie_word_embeddings, vit_hidden=v.hidden_size,
+        vit_depth=v.depth, vit_heads=v.num_heads, vit_intermediate=v.intermediate_size, patch_size=v.patch_size,
+        temporal_patch_size=v.temporal_patch_size, in_channels=v.in_channels, spatial_merge_size=v.spatial_merge_size,
+        window_size=v.window_size, fullatt_block_indexes=tuple(v.fullatt_block_indexes),
+        use_visual_prototype_projection=cfg.use_visual_prototype_projection, lora_r=cfg.lora_r,
+        dec_hidden=d["hidden_size"], dec_heads=d["num_heads"], dec_intermediate=d["intermediate_size"],
+        use_mask_loss=d.get("use_mask_loss", True), image_token_id=cfg.image_token_id,
+        vision_start_token_id=cfg.vision_start_token_id, eos_token_id=cfg.eos_token_id, pad_token_id=cfg.pad_token_id)
+
+
+def bf16_weights(cfg: PaDTConfig, seed=0, std=0.02, bias_std=0.02, norm_jitter=0.1):
+    """fp32 tensors whose values are exactly bf16-representable: the HIP path and the fp32 oracle see the same numbers."""
+    sd = synthetic_state_dict(cfg, seed=seed, std=std, bias_std=bias_std, norm_jitter=norm_jitter, device="cpu")
+    return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
+
+
+def synthetic_batch(cfg: PaDTConfig, grids, n_pre=15, n_post=33, seed=1234, ragged=False):
+    """SURVEY.md §8d prompt: n_pre text ids + <vision_start> + N x <|image_pad|> + n_post text ids; pixel_values ~ N(0,1)
+    (rounded to bf16).  ``ragged`` varies the text lengths per sample and left-pads."""
+    g = torch.Generator().manual_seed(seed)
+    grid = torch.tensor(grids, dtype=torch.long)
+    P = int((grid[:, 0] * grid[:, 1] * grid[:, 2]).sum())
+    pix = torch.randn(P, cfg.patch_dim, generator=g).to(torch.bfloat16).float()
+    rows = []
+    hi = min(cfg.vocab_size, cfg.image_token_id) - 1
+    for b, (t, h, w) in enumerate(grids):
+        n = t * h * w // cfg.merge_unit
+        pre = torch.randint(0, hi, (n_pre - 1 + (b % 3 if ragged else 0),), generator=g).tolist()
+        post = torch.randint(0, hi, (n_post + (2 * b % 5 if ragged else 0),), generator=g).tolist()
+        rows.append(pre + [cfg.vision_start_token_id] + [cfg.image_token_id] * n + post)
+    L = max(len(r) for r in rows)
+    ids = torch.full((len(rows), L), cfg.pad_token_id, dtype=torch.long)
+    am = torch.zeros((len(rows), L), dtype=torch.long)
+    for b, r in enumerate(rows):
+        ids[b, L - len(r):] = torch.tensor(r)
+        am[b, L - len(r):] = 1
+    return grid, pix, ids, am
+
+
+def rec_schedule(t_new=28, vrt_at=range(11, 16)):
+    """Scripted completion (random weights never emit EOS): text … 5 VRTs … text, EOS forced at the last step."""
+    s = ["t"] * t_new
+    for i in vrt_at:
+        s[i] = "v"
+    s[-1] = "e"
+    return s
+
+
+class FakeTokenizer:
+    def __init__(self, cfg: PaDTConfig, n_vrt: int):
+        self.cfg, self.n_vrt = cfg, n_vrt
+        self.eos_token = "<|im_end|>"
+
+    def tok(self, i: int) -> str:
+        c = self.cfg
+        if i == c.eos_token_id:
+            return self.eos_token
+        if i == c.pad_token_id:
+            return "<|endoftext|>"
+        if i >= c.vocab_size:
+            return "<|VRT_%d|>" % (i - c.vocab_size)
+        return " w%d" % i
+
+    def get_vocab(self):
+        return {self.tok(i): i for i in range(self.cfg.vocab_size + self.n_vrt)}
+
+
+class FakeProcessor:
+    def __init__(self, cfg, n_vrt):
+        self.tokenizer = FakeTokenizer(cfg, n_vrt)
+
+    def batch_decode(self, ids):
+        return [self.tokenizer.tok(int(i)) for i in ids]
