@@ -22,6 +22,9 @@ def _chk_bf16(*ts):
             assert t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1, (t.dtype, t.device, t.stride())
 
 
+GEMM_LOG = None   # bench.py sets this to a list to record (and later replay) every GEMM launch of one step
+
+
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=False, K=None):
     """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias).  a/w/out may be row-strided 2-D views.  N' = N/2 for SwiGLU."""
     lib = _lib.load()
@@ -34,6 +37,8 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     if out is None:
         out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     assert out.stride(-1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
+    if GEMM_LOG is not None:
+        GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K))
     _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
                                   _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
                                   1 if out_f32 else 0), "padt_gemm_bf16")
