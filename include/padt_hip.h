@@ -37,6 +37,21 @@ int         padt_event_destroy(void* ev);
 int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
                    const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32);
 
+/* Decode-sized (M <= 64) projection with the preceding RMSNorm fused into the prologue:
+ * C = epi(rstd(A)[m] * (A · W^T)[m] + bias), rstd = rsqrt(mean(A[m]^2)+eps); W carries the norm weight (W·diag(g), folded
+ * at load time).  epilogue 0 or 3 (SwiGLU).  Replaces {input_layernorm → q/k/v_proj} and {post_attention_layernorm →
+ * gate/up_proj} of a decode step (HF:727-757). */
+int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, const void* W, long ldw, const void* bias,
+                           void* C, long ldc, long M, long N, long K, int epilogue);
+
+/* Decode-step projection over FRAGMENT-PACKED weights, M <= 64 (HBM-bound weight streaming): same math as
+ * padt_gemm_bf16 / padt_gemm_rmsnorm_bf16, but W is stored as [N/16][Kp/32][64 lanes][8] so every wave instruction
+ * reads 1 KiB contiguous bytes (row-major fragments load 16 rows x 64 B and run the address unit at a quarter rate).
+ * Kp = padded K (multiple of 32) of the packed image, N must be a multiple of 16.  epilogue 0 none, 2 += R, 3 SwiGLU;
+ * norm_eps >= 0 fuses the preceding RMSNorm as a row scale (folded norm weight), < 0 disables it.  HF:727-757, T = 1. */
+int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
+                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps);
+
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
  * q: token t head h at q + t*ldq + h*head_dim (k, v likewise with kv head h / (n_heads/n_kv_heads)).
@@ -51,6 +66,16 @@ long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_m
 int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens, void* out,
                       void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, int max_len,
                       float scale);
+
+/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks + combine.
+ * rope_cs = this step's fp32 (cos, sin) table [B][head_dim/2][2] from padt_rope_table; slot[b] = append index (keys
+ * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace.  HF:557-599, 641-689, 665-666. */
+int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,
+                          void* vt_cache, void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,
+                          int s_max, int max_len, float scale);
+/* rope_cs[b][d] = (cos, sin)(pos3[axis(d)][b] * inv_freq[d]) with mRoPE sections (sec0, sec1, rest).  HF:525-538,589-595. */
+int padt_rope_table(void* stream, const int* pos3, const void* inv_freq, void* rope_cs, int batch, int head_dim, int sec0,
+                    int sec1);
 
 /* ---- row kernels ---------------------------------------------------------------------------------------------------- */
 /* y = act(w * (x [+ add[row/add_div]]) * rsqrt(mean(.^2)+eps)), act: 0 none, 1 exact GELU.

@@ -315,6 +315,163 @@ __global__ void decode_combine_kernel(DecodeArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Decode-step attention with mRoPE + KV-cache append fused in (replaces llm_qkv_post + decode_attn for T = 1).
+// Grid (64-key split, kv head, sample), one wave per block — same decomposition as decode_attn_kernel, so a layer's
+// ≈5 MB of KV is spread over ≈160 CUs.  Every block rotates the group's q heads (8 x 128 values) and the new k with the
+// step's cos/sin table (written once per step by greedy_step_kernel, fp32, [B][D/2][2]) into LDS; the block whose split
+// contains the append slot also writes k / v to the K / V^T caches.  The fresh token's K row and V^T column are always
+// taken from LDS, never read back from global, so no block depends on another block's (or its own) fresh stores.
+// HF:557-599 (mRoPE), :665-666 (cache update), :641-689 (attention with Lq == 1).
+struct DecodeRopeArgs {
+    const bf16_t* qkv; long ld_qkv;   // [B][(Hq + 2 Hkv) * D], bias already added
+    const float* rope_cs;             // [B][D/2][2] cos, sin of this step's position (sections already resolved)
+    const int* slot;                  // [B] append index; valid keys afterwards = slot + 1
+    bf16_t* kc; bf16_t* vtc;
+    float* part_o; float* part_ml;
+    int B, Hq, Hkv, S_max, nsplit;
+    float scale_log2;
+};
+
+template <int D>
+__global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) {
+    constexpr int QROW = D + 8, KQ = D / 32, NB = D / 16, HALF = D / 2;
+    __shared__ __attribute__((aligned(16))) bf16_t Qs[16 * QROW];
+    __shared__ __attribute__((aligned(16))) bf16_t Knew[D];
+    __shared__ __attribute__((aligned(16))) bf16_t Vnew[D];
+    __shared__ __attribute__((aligned(16))) bf16_t Pw[16 * 72];
+    const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
+    const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+    const int group = p.Hq / p.Hkv;
+    const int slot = p.slot[b];
+    const int len = slot + 1;
+    const int k0 = split * 64;
+    const long pbase = (((long)b * p.Hkv + g) * p.nsplit + split) * 16;
+    if (k0 >= len) {
+        if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
+        return;
+    }
+    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
+    bf16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    bf16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+    const bool owner = (slot >= k0) && (slot < k0 + 64);
+    const float* cs = p.rope_cs + (long)b * HALF * 2;
+
+    for (int i = lane; i < 16 * QROW; i += 64) Qs[i] = 0;
+    __syncthreads();
+    for (int i = lane; i < (group + 1) * HALF; i += 64) {
+        const int hh = i / HALF, d = i % HALF;
+        const float c = cs[2 * d], s = cs[2 * d + 1];
+        const bf16_t* x = (hh < group) ? row + (long)(g * group + hh) * D : row + (long)(p.Hq + g) * D;
+        const float x1 = bf2f(x[d]), x2 = bf2f(x[d + HALF]);
+        const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
+        if (hh < group) {
+            Qs[hh * QROW + d] = o1; Qs[hh * QROW + d + HALF] = o2;
+        } else {
+            Knew[d] = o1; Knew[d + HALF] = o2;
+            if (owner) { kbase[(long)slot * D + d] = o1; kbase[(long)slot * D + d + HALF] = o2; }
+        }
+    }
+    const bf16_t* vsrc = row + (long)(p.Hq + p.Hkv + g) * D;
+    for (int d = lane; d < D; d += 64) {
+        const bf16_t v = vsrc[d];
+        Vnew[d] = v;
+        if (owner) vbase[(long)d * p.S_max + slot] = v;
+    }
+    __syncthreads();
+
+    bf16x8 qf[KQ];
+#pragma unroll
+    for (int kk = 0; kk < KQ; ++kk) qf[kk] = ld_frag(Qs + frow * QROW + kk * 32 + fq * 8);
+    f32x4 s[4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+        const int key = k0 + kb * 16 + frow;
+        const int kcl = key < p.S_max ? key : p.S_max - 1;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) {
+            bf16x8 kf = ld_frag(kbase + (long)kcl * D + kk * 32 + fq * 8);
+            const bf16x8 kn = ld_frag(Knew + kk * 32 + fq * 8);
+            kf = (key == slot) ? kn : kf;
+            s[kb] = mfma16(qf[kk], kf, s[kb]);
+        }
+    }
+    float mrow[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int key = k0 + kb * 16 + frow;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float x = (key < len) ? s[kb][r] * p.scale_log2 : -INFINITY;
+            s[kb][r] = x;
+            mrow[r] = fmaxf(mrow[r], x);
+        }
+    }
+    float lrow[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float m = mrow[r];
+        m = fmaxf(m, __shfl_xor(m, 1, 64));
+        m = fmaxf(m, __shfl_xor(m, 2, 64));
+        m = fmaxf(m, __shfl_xor(m, 4, 64));
+        m = fmaxf(m, __shfl_xor(m, 8, 64));
+        mrow[r] = m;
+        lrow[r] = 0.f;
+    }
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float pv = exp2f(s[kb][r] - mrow[r]);
+            lrow[r] += pv;
+            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2bf(pv);
+        }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        float t = lrow[r];
+        t += __shfl_xor(t, 1, 64);
+        t += __shfl_xor(t, 2, 64);
+        t += __shfl_xor(t, 4, 64);
+        t += __shfl_xor(t, 8, 64);
+        lrow[r] = t;
+    }
+    __syncthreads();
+    f32x4 o[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+        const bf16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
+        const int kk0 = k0 + ks * 32 + fq * 8;                     // 8 consecutive keys of the V^T row
+        const int j = slot - kk0;                                  // position of the fresh token inside this fragment
+#pragma unroll
+        for (int i = 0; i < NB; ++i) {
+            const int d = i * 16 + frow;
+            u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (long)d * p.S_max + kk0);
+            if (j >= 0 && j < 8) {
+                const unsigned nv = Vnew[d];
+                const int wsel = j >> 1;
+#pragma unroll
+                for (int w2 = 0; w2 < 4; ++w2) {
+                    const unsigned cur = vv[w2];
+                    const unsigned pat = (j & 1) ? ((cur & 0x0000ffffu) | (nv << 16)) : ((cur & 0xffff0000u) | nv);
+                    vv[w2] = (w2 == wsel) ? pat : cur;
+                }
+            }
+            o[i] = mfma16(pf, __builtin_bit_cast(bf16x8, vv), o[i]);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int hrow = fq * 4 + r;
+        float* po = p.part_o + (pbase + hrow) * D;
+#pragma unroll
+        for (int i = 0; i < NB; ++i) po[i * 16 + frow] = o[i][r];
+        if (frow == 0) { p.part_ml[(pbase + hrow) * 2] = mrow[r]; p.part_ml[(pbase + hrow) * 2 + 1] = lrow[r]; }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 extern "C" void padt_set_error(const char* msg);
 
 template <int D, bool CAUSAL>
@@ -390,6 +547,61 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
             break;
         default: padt_set_error("padt_decode_attn: head_dim must be 32 or 128"); return -1;
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot,
+                                     void* k_cache, void* vt_cache, void* out, void* workspace, int batch, int n_heads,
+                                     int n_kv_heads, int head_dim, int s_max, int max_len, float scale) {
+    if (batch <= 0) return 0;
+    if (n_heads % n_kv_heads || n_heads / n_kv_heads > 16 || (s_max & 63) || (ld_qkv & 7) || max_len > s_max || max_len <= 0) {
+        padt_set_error("padt_decode_attn_rope: need heads/kv_heads <= 16, s_max % 64 == 0, ld_qkv % 8 == 0, 0 < max_len <= s_max");
+        return -1;
+    }
+    const int nsplit = (max_len + 63) / 64;
+    DecodeRopeArgs a{(const bf16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+                     (float*)workspace, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f};
+    a.part_ml = a.part_o + (long)batch * n_kv_heads * nsplit * 16 * head_dim;
+    DecodeArgs c;                                              // combine reads the same partial layout
+    c.q = nullptr; c.kc = nullptr; c.vtc = nullptr; c.lens = nullptr; c.part_o = a.part_o; c.part_ml = a.part_ml;
+    c.out = (bf16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 32:
+            hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<32>, dim3(n_heads, batch), dim3(32), 0, s, c);
+            break;
+        case 128:
+            hipLaunchKernelGGL(decode_attn_rope_kernel<128>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<128>, dim3(n_heads, batch), dim3(128), 0, s, c);
+            break;
+        default: padt_set_error("padt_decode_attn_rope: head_dim must be 32 or 128"); return -1;
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// fp32 cos/sin table of one decode step: rope_cs[b][d] = (cos, sin)(pos3[axis(d)][b] * inv_freq[d]), d < D/2.
+__global__ void rope_table_kernel(const int* __restrict__ pos3, const float* __restrict__ inv_freq, float* __restrict__ cs,
+                                  int B, int half, int sec0, int sec1) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * half) return;
+    const int b = i / half, d = i % half;
+    const int axis = d < sec0 ? 0 : (d < sec0 + sec1 ? 1 : 2);
+    const float ang = (float)pos3[axis * B + b] * inv_freq[d];
+    cs[2 * i] = cosf(ang);
+    cs[2 * i + 1] = sinf(ang);
+}
+
+extern "C" int padt_rope_table(void* stream, const int* pos3, const void* inv_freq, void* rope_cs, int batch, int head_dim,
+                               int sec0, int sec1) {
+    if (batch <= 0) return 0;
+    const int n = batch * (head_dim / 2);
+    hipLaunchKernelGGL(rope_table_kernel, dim3((n + 127) / 128), dim3(128), 0, (hipStream_t)stream, pos3,
+                       (const float*)inv_freq, (float*)rope_cs, batch, head_dim / 2, sec0, sec1);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

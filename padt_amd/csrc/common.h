@@ -14,15 +14,13 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;  // 8 bytes
 
 PADT_DEV float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 
-// round-to-nearest-even; NaN stays NaN, +-inf stays +-inf
-PADT_DEV bf16_t f2bf(float f) {
-    unsigned u = __builtin_bit_cast(unsigned, f);
-    if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x40);
-    u += 0x7fffu + ((u >> 16) & 1u);
-    return (bf16_t)(u >> 16);
+// round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32); NaN stays NaN, +-inf stays +-inf
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+PADT_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
+PADT_DEV unsigned pack2bf(float lo, float hi) {
+    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+    return __builtin_bit_cast(unsigned, v);
 }
-
-PADT_DEV unsigned pack2bf(float lo, float hi) { return (unsigned)f2bf(lo) | ((unsigned)f2bf(hi) << 16); }
 
 PADT_DEV bf16x8 ld_frag(const void* p) { return *reinterpret_cast<const bf16x8*>(p); }
 

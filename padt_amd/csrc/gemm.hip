@@ -16,6 +16,7 @@
 // Replaces: every nn.Linear / Conv3d-as-GEMM on the path — HF ViT qkv/proj/MLP/merger, LLM q/k/v/o/gate/up/down,
 // vis_proj (padt.py:189), PaDT decoder projections and heads (padt_decoder.py:15-18,82-86,142-184).
 #include "common.h"
+#include <stdlib.h>
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
 
@@ -32,27 +33,49 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];   // 256 B
 
 // ---------------------------------------------------------------------------------------------------------------------
 // epilogue for one 16x16 fragment held "swapped": lane has row m, columns n..n+3 in v[0..3]
+PADT_DEV void unpack4(u32x2 v, float* f) {
+    f[0] = __builtin_bit_cast(float, v[0] << 16);
+    f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, v[1] << 16);
+    f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+}
+
 template <int EPI, bool OUT_F32>
 PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
     if (m >= p.M || n >= p.N) return;
-    const bool full = (n + 3 < p.N);
-    float o[4];
+    float o[4] = {v[0], v[1], v[2], v[3]};
+    if (n + 3 < p.N) {                                   // full fragment: 8-byte bias / residual loads, one vector store
+        const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
+        const u32x2 braw = *reinterpret_cast<const u32x2*>(bp);     // both loads are issued before either is consumed
+        u32x2 rraw = u32x2{0u, 0u};
+        if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
+        {
+            float bv[4];
+            unpack4(braw, bv);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float x = v[r];
-        if (p.bias && (n + r < p.N)) x += bf2f(p.bias[n + r]);
-        if (EPI == EPI_GELU) x = gelu_erf(x);
-        if (EPI == EPI_RESID && (n + r < p.N)) x += bf2f(p.R[(long)m * p.ldr + n + r]);
-        o[r] = x;
+            for (int r = 0; r < 4; ++r) o[r] += bv[r];
+        }
+        if (EPI == EPI_GELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+        }
+        if (EPI == EPI_RESID) {
+            float rv[4];
+            unpack4(rraw, rv);
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o[r] += rv[r];
+        }
+        if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        return;
     }
-    if (OUT_F32) {
-        float* c = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-        if (full) *reinterpret_cast<f32x4*>(c) = f32x4{o[0], o[1], o[2], o[3]};
-        else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = o[r];
-    } else {
-        bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
-        if (full) *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-        else for (int r = 0; r < 4 && n + r < p.N; ++r) c[r] = f2bf(o[r]);
+    for (int r = 0; r < 4 && n + r < p.N; ++r) {         // ragged N tail: scalar
+        float x = o[r];
+        if (p.bias) x += bf2f(p.bias[n + r]);
+        if (EPI == EPI_GELU) x = gelu_erf(x);
+        if (EPI == EPI_RESID) x += bf2f(p.R[(long)m * p.ldr + n + r]);
+        if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+        else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
     }
 }
 
@@ -62,13 +85,13 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     if (m >= p.M || n_gate >= p.N) return;
     const int blk = n_gate >> 5, in = n_gate & 15;
     const int no = blk * 16 + in;                       // output column
+    float gb[4], ub[4];
+    const bf16_t* bp = p.bias ? p.bias + n_gate : reinterpret_cast<const bf16_t*>(g_zero_page);
+    unpack4(*reinterpret_cast<const u32x2*>(bp), gb);
+    unpack4(*reinterpret_cast<const u32x2*>(bp + 16), ub);
     float o[4];
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        float gv = g[r], uv = u[r];
-        if (p.bias) { gv += bf2f(p.bias[n_gate + r]); uv += bf2f(p.bias[n_gate + 16 + r]); }
-        o[r] = silu(gv) * uv;
-    }
+    for (int r = 0; r < 4; ++r) o[r] = silu(g[r] + gb[r]) * (u[r] + ub[r]);
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no;
     *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
 }
@@ -152,6 +175,46 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
     }
 
     // epilogue: acc[mi][ni][r] = C[m0 + wm*64 + mi*16 + (lane&15)][n0 + wn*64 + ni*16 + (lane>>4)*4 + r]
+    const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
+    if (interior && EPI != EPI_SWIGLU) {
+        // block-uniform fast path: no per-fragment bounds checks; every bias / residual load is issued up front
+        const int mb = m0 + wm * 64 + frow, nb = n0 + wn * 64 + fq * 4;
+        u32x2 braw[4], rraw[4][4];
+        const bf16_t* bp = p.bias ? p.bias + nb : reinterpret_cast<const bf16_t*>(g_zero_page);
+        const int bstep = p.bias ? 16 : 0;
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) braw[ni] = *reinterpret_cast<const u32x2*>(bp + ni * bstep);
+        if (EPI == EPI_RESID) {
+#pragma unroll
+            for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni)
+                    rraw[mi][ni] = *reinterpret_cast<const u32x2*>(p.R + (long)(mb + mi * 16) * p.ldr + nb + ni * 16);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                float bv[4], o[4];
+                unpack4(braw[ni], bv);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bv[r];
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+                }
+                if (EPI == EPI_RESID) {
+                    float rv[4];
+                    unpack4(rraw[mi][ni], rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                }
+                const long off = (long)(mb + mi * 16) * p.ldc + nb + ni * 16;
+                if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            }
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi) {
         const int m = m0 + wm * 64 + mi * 16 + frow;
@@ -172,20 +235,30 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-// Skinny kernel: M <= 16*MT.  Block = 4 waves, owns NT*16 weight rows; wave w handles K-steps w, w+4, ...
-template <int MT, int NT, int EPI, bool OUT_F32>
-__global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[3][NT * MT][64][4];
+// Skinny kernel: M <= 16*MT.  Block = NW waves, owns NT*16 weight rows; wave w handles K-steps w, w+NW, ...
+// Weights are streamed with non-temporal 16-byte loads (read exactly once per launch); U K-steps are in flight per wave.
+// NORM: the RMSNorm that precedes the projection in the reference (HF:727,744 input/post-attention layernorm) is fused:
+//   y = (x * rsqrt(mean(x^2)+eps) * g) @ W^T  ==  rstd[m] * (x @ (W·diag(g))^T)[m]  — the norm weight g is folded into the
+//   weight matrix once at load time (weights.py), the per-row sum of squares is accumulated from the x fragments the
+//   MFMA consumes anyway, and rstd scales the fp32 accumulator.
+template <int MT, int NT, int NW, int EPI, bool OUT_F32, bool NORM, bool PACKED>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float norm_eps) {
+    __shared__ __attribute__((aligned(16))) float red[NW - 1][NT * MT][64][4];
+    __shared__ float ssq[NW][MT][16];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nks = (p.K + 31) / 32;
+    constexpr int U = (MT == 1) ? 8 : (MT * NT >= 8 ? 2 : 4);   // K-steps in flight per wave (VGPR budget)
 
     f32x4 acc[NT][MT];
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    float ss[MT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j) ss[j] = 0.f;
 
     const bf16_t* wrow[NT];
 #pragma unroll
@@ -203,18 +276,31 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
         xrow[j] = p.A + (long)(xok[j] ? m : 0) * p.lda;
     }
 
-    constexpr int U = 4;                                   // K-steps in flight per wave
-    for (int ks0 = wave; ks0 < nks; ks0 += 4 * U) {
+    // wave w owns groups w, w+NW, ... of U CONSECUTIVE K-steps: one round = U*64 B contiguous per weight row
+    for (int grp = wave; grp * U < nks; grp += NW) {
         bf16x8 wf[U][NT], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ks = ks0 + u * 4;
+            const int ks = grp * U + u;
             const int k = ks * 32 + fq * 8;
             const bool kok = (ks < nks) && (k < p.K);
 #pragma unroll
-            for (int i = 0; i < NT; ++i) wf[u][i] = kok ? ld_frag(wrow[i] + k) : zero_frag();
+            for (int i = 0; i < NT; ++i) {
+                // PACKED: tile (n16, k32) of the fragment-packed image is 1 KiB in lane order → one contiguous wave load
+                const bf16_t* wp = PACKED ? p.W + ((long)(n0 / 16 + i) * (p.ldw / 32) + ks) * 512 + lane * 8 : wrow[i] + k;
+                wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp)) : zero_frag();
+            }
 #pragma unroll
             for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + k) : zero_frag();
+            if (NORM) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    float xv[8];
+                    unpack8(__builtin_bit_cast(u32x4, xf[u][j]), xv);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ss[j] += xv[e] * xv[e];
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
@@ -224,6 +310,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
                 for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[u][i], xf[u][j], acc[i][j]);
     }
 
+    if (NORM) {
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            float t = ss[j];
+            t += __shfl_xor(t, 16, 64);
+            t += __shfl_xor(t, 32, 64);
+            if (fq == 0) ssq[wave][j][frow] = t;
+        }
+    }
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -237,10 +332,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmArgs p) {
 #pragma unroll
             for (int j = 0; j < MT; ++j)
 #pragma unroll
-                for (int w = 0; w < 3; ++w) acc[i][j] += *reinterpret_cast<f32x4*>(&red[w][i * MT + j][lane][0]);
+                for (int w = 0; w < NW - 1; ++w) acc[i][j] += *reinterpret_cast<f32x4*>(&red[w][i * MT + j][lane][0]);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int m = j * 16 + frow;
+            if (NORM) {
+                float t = 0.f;
+#pragma unroll
+                for (int w = 0; w < NW; ++w) t += ssq[w][j][frow];
+                const float rstd = rsqrtf(t / (float)p.K + norm_eps);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] *= rstd;
+            }
             if (EPI == EPI_SWIGLU) {
                 store_swiglu(p, m, n0 + fq * 4, acc[0][j], acc[NT - 1][j]);
             } else {
@@ -267,19 +370,40 @@ static void launch_tile(const GemmArgs& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tile_kernel<EPI, F32>), dim3(ntm * ntn), dim3(256), GEMM_LDS, s, a);
 }
 
-template <int MT, int EPI, bool F32>
-static void launch_skinny(const GemmArgs& a, hipStream_t s) {
+template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false>
+static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, EPI, F32>), dim3(nb), dim3(256), 0, s, a);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED>), dim3(nb), dim3(NW * 64), 0, s, a, eps);
+}
+
+// waves per block: enough waves chip-wide (>= ~2048) to keep HBM busy even when N/16 < #CUs
+template <int MT, int EPI, bool F32, bool NORM, bool PACKED = false>
+static void launch_skinny(const GemmArgs& a, float eps, hipStream_t s) {
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    const int nb = (a.N + 16 * NT - 1) / (16 * NT);
+    const int ksteps = (a.K + 31) / 32;                    // each wave keeps U = 8 K-steps in flight
+    static const int force_nw = getenv("PADT_SKINNY_NW") ? atoi(getenv("PADT_SKINNY_NW")) : 0;   // tuning knob
+    if constexpr (MT == 1 && NT == 1) {
+        if (force_nw == 16 || (!force_nw && nb <= 256 && ksteps >= 128)) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED>(a, eps, s); return; }
+    }
+    if (force_nw == 8 || (!force_nw && nb <= 512 && ksteps >= 64)) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED>(a, eps, s);
+    else launch_skinny_nw<MT, 4, EPI, F32, NORM, PACKED>(a, eps, s);
 }
 
 template <int EPI, bool F32>
 static void dispatch_m(const GemmArgs& a, hipStream_t s) {
-    if (a.M <= 16) launch_skinny<1, EPI, F32>(a, s);
-    else if (a.M <= 32) launch_skinny<2, EPI, F32>(a, s);
-    else if (a.M <= 64) launch_skinny<4, EPI, F32>(a, s);
+    if (a.M <= 16) launch_skinny<1, EPI, F32, false>(a, 0.f, s);
+    else if (a.M <= 32) launch_skinny<2, EPI, F32, false>(a, 0.f, s);
+    else if (a.M <= 64) launch_skinny<4, EPI, F32, false>(a, 0.f, s);
     else launch_tile<EPI, F32>(a, s);
+}
+
+template <int EPI>
+static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
+    if (a.M <= 16) launch_skinny<1, EPI, false, true>(a, eps, s);
+    else if (a.M <= 32) launch_skinny<2, EPI, false, true>(a, eps, s);
+    else launch_skinny<4, EPI, false, true>(a, eps, s);
 }
 
 extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
@@ -291,7 +415,7 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
     }
     const long out_n = (epilogue == EPI_SWIGLU) ? N / 2 : N;
     if ((ldc & 3) || ((uintptr_t)C & 15) || (epilogue == EPI_SWIGLU && ((N & 31) || out_f32)) ||
-        (epilogue == EPI_RESID && R == nullptr) || ldc < out_n) {
+        (epilogue == EPI_RESID && (R == nullptr || (ldr & 3) || ((uintptr_t)R & 7))) || ((uintptr_t)bias & 7) || ldc < out_n) {
         padt_set_error("padt_gemm_bf16: bad C/ldc/epilogue arguments (ldc % 4, C 16-byte aligned, SwiGLU needs N % 32 == 0 and bf16 out)");
         return -1;
     }
@@ -309,6 +433,62 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
         case 6: dispatch_m<EPI_SWIGLU, false>(a, s); break;
         default: padt_set_error("padt_gemm_bf16: unsupported epilogue/out combination"); return -1;
     }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// Fused RMSNorm + projection for decode-sized batches (M <= 64):  C = epi(rstd(A)[m] * (A · W^T)[m] + bias), where
+// rstd = rsqrt(mean(A[m]^2) + eps) and W already carries the norm weight (W·diag(g), folded at load time).
+// epilogue 0 (none) or 3 (SwiGLU).  Replaces {input_layernorm → q/k/v_proj} and {post_attention_layernorm → gate/up_proj}
+// (HF:727-757) for the single-token decode step.
+extern "C" int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, const void* W, long ldw,
+                                      const void* bias, void* C, long ldc, long M, long N, long K, int epilogue) {
+    if (M <= 0 || N <= 0) return 0;
+    if (M > 64 || K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
+        padt_set_error("padt_gemm_rmsnorm_bf16: M <= 64, K/lda/ldw multiples of 8, 16-byte aligned A/W required");
+        return -1;
+    }
+    if ((ldc & 3) || ((uintptr_t)C & 15) || ((uintptr_t)bias & 7) || (epilogue != EPI_NONE && epilogue != EPI_SWIGLU) ||
+        (epilogue == EPI_SWIGLU && (N & 31))) {
+        padt_set_error("padt_gemm_rmsnorm_bf16: bad C/ldc/epilogue (0 or 3; SwiGLU needs N % 32 == 0)");
+        return -1;
+    }
+    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K};
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_SWIGLU) dispatch_norm<EPI_SWIGLU>(a, eps, s);
+    else dispatch_norm<EPI_NONE>(a, eps, s);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// Same kernel over the fragment-packed weight image (see include/padt_hip.h): the decode step's projections.
+template <int EPI, bool NORM>
+static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
+    if (a.M <= 16) launch_skinny<1, EPI, false, NORM, true>(a, eps, s);
+    else if (a.M <= 32) launch_skinny<2, EPI, false, NORM, true>(a, eps, s);
+    else launch_skinny<4, EPI, false, NORM, true>(a, eps, s);
+}
+
+extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
+                                     long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps) {
+    if (M <= 0 || N <= 0) return 0;
+    if (M > 64 || K <= 0 || (K & 7) || K > Kp || (Kp & 31) || (lda & 7) || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) {
+        padt_set_error("padt_gemm_packed_bf16: M <= 64, K % 8 == 0, K <= Kp, Kp % 32 == 0, 16-byte aligned A/Wp required");
+        return -1;
+    }
+    const bool norm = norm_eps >= 0.f;
+    if ((ldc & 3) || ((uintptr_t)C & 15) || ((uintptr_t)bias & 7) || (epilogue != EPI_NONE && epilogue != EPI_RESID && epilogue != EPI_SWIGLU) ||
+        (epilogue == EPI_SWIGLU && (N & 31)) || (epilogue == EPI_RESID && (R == nullptr || (ldr & 3) || ((uintptr_t)R & 7) || norm))) {
+        padt_set_error("padt_gemm_packed_bf16: bad C/ldc/bias/epilogue (0, 2 without norm, or 3 with N % 32 == 0)");
+        return -1;
+    }
+    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)Wp, Kp, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr, (int)M, (int)N, (int)K};
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false>(a, 0.f, s); }
+    else if (epilogue == EPI_RESID) dispatch_packed<EPI_RESID, false>(a, 0.f, s);
+    else { if (norm) dispatch_packed<EPI_NONE, true>(a, norm_eps, s); else dispatch_packed<EPI_NONE, false>(a, 0.f, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

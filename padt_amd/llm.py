@@ -153,26 +153,26 @@ class DecodeSession:
         self.h = z(B, I)
         self.hn = z(B, D)
         self.err = z(1, dt=I32)
+        self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
+        self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
         self.graph: Optional[torch.cuda.CUDAGraph] = None
         self.np_cur = np_max
 
     # one decode step, all on the current stream (eager or under capture)
     def step_kernels(self):
         cfg, W = self.cfg, self.W
-        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        Hq, Hkv, hd, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
         ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x, err_flag=self.err)
+        ops.rope_table(self.pos3, self.inv_freq, self.rope_cs, hd, cfg.mrope_section)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
-            ops.rmsnorm(self.x, W[p + "ln1"], out=self.n, eps=cfg.rms_norm_eps)
-            ops.gemm(self.n, W[p + "qkv.w"], W[p + "qkv.b"], out=self.qkv)
-            ops.llm_qkv_post(self.qkv, self.pos3, self.inv_freq, self.q, self.kc[i], self.vtc[i], Hq, Hkv, hd, self.s_max,
-                             cfg.mrope_section, slot=self.slot)
-            ops.decode_attn(self.q, self.kc[i], self.vtc[i], self.lens, self.att, self.attn_ws, Hq, Hkv, hd, self.s_max,
-                            self.s_max)
-            ops.gemm(self.att, W[p + "o.w"], out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
-            ops.rmsnorm(self.x, W[p + "ln2"], out=self.n, eps=cfg.rms_norm_eps)
-            ops.gemm(self.n, W[p + "gu.w"], out=self.h, epilogue=ops.EPI_SWIGLU)
-            ops.gemm(self.h, W[p + "down.w"], out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+            # 6 launches per layer: [norm+qkv] [rope+append+split attention] [merge] [o+resid] [norm+gate/up+SwiGLU] [down+resid]
+            ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps)
+            ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
+                                 hd, self.s_max, self.s_max)
+            ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+            ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps)
+            ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
         ops.rmsnorm(self.x, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
         self.head_and_select(self.hn, advance=True)
 
@@ -246,13 +246,13 @@ class LanguageModel:
         mx = max(plan.lens)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
-            ops.rmsnorm(x, W[p + "ln1"], out=n, eps=cfg.rms_norm_eps)
+            ops.rmsnorm(x, W["llm.ones"], out=n, eps=cfg.rms_norm_eps)     # norm weight is folded into qkv.w
             ops.gemm(n, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
             ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
-            ops.rmsnorm(x, W[p + "ln2"], out=n, eps=cfg.rms_norm_eps)
+            ops.rmsnorm(x, W["llm.ones"], out=n, eps=cfg.rms_norm_eps)     # norm weight is folded into gu.w
             ops.gemm(n, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU)
             ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
         return ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)

@@ -45,6 +45,45 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     return out
 
 
+def gemm_rmsnorm(a, w, bias=None, out=None, epilogue=EPI_NONE, eps=1e-6):
+    """out = epi(rstd(a) * (a @ w^T) + bias) for decode-sized batches (rows <= 64); w carries the folded norm weight."""
+    lib = _lib.load()
+    _chk_bf16(a, w, bias)
+    M, K, N = a.shape[0], a.shape[1], w.shape[0]
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
+    _lib.check(lib.padt_gemm_rmsnorm_bf16(_stream(), _p(a), a.stride(0), float(eps), _p(w), w.stride(0), _p(bias), _p(out),
+                                          out.stride(0), M, N, K, epilogue), "padt_gemm_rmsnorm_bf16")
+    return out
+
+
+def pack_weight(w):
+    """[N][K] row-major → MFMA-fragment-packed [N/16][K/32][4 (k-quarter)][16 (row)][8] (N, K zero-padded to 16 / 32).
+    One 16x32 tile = 1 KiB in exactly the lane order of the decode kernel's weight fragment load."""
+    N, K = w.shape
+    Np, Kp = (N + 15) // 16 * 16, (K + 31) // 32 * 32
+    if (Np, Kp) != (N, K):
+        wp = w.new_zeros((Np, Kp))
+        wp[:N, :K] = w
+        w = wp
+    return w.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np, Kp)
+
+
+def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None):
+    """Decode-step projection over a pack_weight() image (rows <= 64): out = epi(rstd?(a) * (a @ w^T) + bias)."""
+    lib = _lib.load()
+    _chk_bf16(a, wp, bias, residual)
+    M, K = a.shape
+    n_out = n // 2 if epilogue == EPI_SWIGLU else n
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
+    _lib.check(lib.padt_gemm_packed_bf16(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(bias), _p(out), out.stride(0),
+                                         _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
+                                         -1.0 if norm_eps is None else float(norm_eps)), "padt_gemm_packed_bf16")
+    return out
+
+
 def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None):
     """q/k/v/out: 2-D (tokens, row) bf16 views whose row holds the heads contiguously; cu_*: int32 device tensors."""
     lib = _lib.load()
@@ -69,6 +108,25 @@ def decode_attn(q, k_cache, vt_cache, lens, out, workspace, n_heads, n_kv_heads,
     _lib.check(lib.padt_decode_attn(_stream(), _p(q), _p(k_cache), _p(vt_cache), _p(lens), _p(out), _p(workspace),
                                     q.shape[0], n_heads, n_kv_heads, head_dim, s_max, int(max_len), float(scale)),
                "padt_decode_attn")
+    return out
+
+
+def rope_table(pos3, inv_freq, out, head_dim, sections):
+    lib = _lib.load()
+    assert pos3.dtype == torch.int32 and out.dtype == torch.float32
+    _lib.check(lib.padt_rope_table(_stream(), _p(pos3), _p(inv_freq), _p(out), pos3.shape[1], head_dim, sections[0], sections[1]),
+               "padt_rope_table")
+    return out
+
+
+def decode_attn_rope(qkv, rope_cs, slot, k_cache, vt_cache, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len,
+                     scale=None):
+    lib = _lib.load()
+    _chk_bf16(qkv, k_cache, vt_cache, out)
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(lib.padt_decode_attn_rope(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
+                                         _p(out), _p(workspace), qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max,
+                                         int(max_len), float(scale)), "padt_decode_attn_rope")
     return out
 
 

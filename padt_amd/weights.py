@@ -5,7 +5,8 @@ Input: a state dict with the checkpoint's (HF-4.50) key names — ``visual.*``, 
 ``synthetic_state_dict`` (no checkpoints exist offline).  Output: ``PreparedWeights``, bf16 device tensors laid out for
 the kernels in libpadt_hip.so:
   * every Linear stays [out][in] (K-contiguous = MFMA operand order), conv3d patch-embed flattened to [hidden][C*T*p*p];
-  * LLM q/k/v fused into one [Hq*D + 2*Hkv*D][hidden] matrix (+ fused bias);
+  * LLM q/k/v fused into one [Hq*D + 2*Hkv*D][hidden] matrix (+ fused bias); the LLM's input / post-attention RMSNorm
+    weights folded into the q/k/v and gate/up matrices (W·diag(g));
   * SwiGLU gate/up interleaved in 16-row blocks ([gate16 | up16] ...) so one GEMM tile holds matching gate/up columns
     and the activation is fused into the epilogue; MLP intermediates zero-padded to a multiple of 64 (3420 → 3456).
 """
@@ -235,14 +236,27 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         W["llm.head"] = W["llm.embed"]
     for i in range(cfg.num_hidden_layers):
         s, d = f"model.layers.{i}.", f"llm.{i}."
-        put(d + "ln1", get(s + "input_layernorm.weight"))
-        put(d + "ln2", get(s + "post_attention_layernorm.weight"))
-        put(d + "qkv.w", torch.cat([get(s + "self_attn.q_proj.weight"), get(s + "self_attn.k_proj.weight"), get(s + "self_attn.v_proj.weight")], 0))
+        # RMSNorm weights are folded into the projection that consumes the normalised activations:
+        #   (x·rstd ⊙ g) Wᵀ = rstd · x (W·diag(g))ᵀ  — one rounding of W·g to bf16 at load time, so the decode GEMV can
+        #   fuse the norm (rstd only) and prefill runs a unit-weight RMSNorm in front of the same matrix.
+        g1 = get(s + "input_layernorm.weight").float().to(dev)[None, :]
+        g2 = get(s + "post_attention_layernorm.weight").float().to(dev)[None, :]
+        qkv = torch.cat([get(s + "self_attn.q_proj.weight"), get(s + "self_attn.k_proj.weight"), get(s + "self_attn.v_proj.weight")], 0)
+        put(d + "qkv.w", qkv.to(dev).float() * g1)
         put(d + "qkv.b", torch.cat([get(s + "self_attn.q_proj.bias"), get(s + "self_attn.k_proj.bias"), get(s + "self_attn.v_proj.bias")], 0))
         put(d + "o.w", get(s + "self_attn.o_proj.weight"))
-        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(get(s + "mlp.up_proj.weight"), li_pad)))
+        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight").to(dev).float() * g2, li_pad),
+                                     _pad_rows(get(s + "mlp.up_proj.weight").to(dev).float() * g2, li_pad)))
         put(d + "down.w", _pad_cols(get(s + "mlp.down_proj.weight"), li_pad))
+    # decode-step copies of the LLM matrices in MFMA-fragment order (ops.pack_weight): the single-token GEMVs stream
+    # them with fully coalesced 1 KiB wave loads.  +5.5 GB for PaDT_Pro_3B — HBM capacity is not the constraint here.
+    from .ops import pack_weight
+    for i in range(cfg.num_hidden_layers):
+        d = f"llm.{i}."
+        for nm in ("qkv", "o", "gu", "down"):
+            W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
     put("llm.norm", get("model.norm.weight"))
+    W["llm.ones"] = torch.ones(cfg.hidden_size, device=dev, dtype=BF16)
     if cfg.use_visual_prototype_projection:
         put("proto.norm.w", get("vis_norm.weight"))
         put("proto.norm.b", get("vis_norm.bias"))

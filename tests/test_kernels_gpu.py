@@ -85,6 +85,43 @@ def test_gemm_epilogues(ops, M):
     close_bf16(ops.gemm(a, wi, bi, epilogue=ops.EPI_SWIGLU), ref, f"swiglu M={M}")
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 2560, 2048), (8, 22016, 2048), (8, 2048, 11008), (3, 96, 256), (20, 640, 512), (64, 704, 256)])
+def test_gemm_fused_rmsnorm(ops, M, N, K):
+    """out = rstd(x) * (x @ W^T) + b with W carrying the folded norm weight: the kernel's operands are exactly x and W, so
+    the fp32 statement of the same expression is a 1-ulp reference."""
+    x = rnd(M, K, seed=14)
+    w, b = rnd(N, K, scale=0.05, seed=16), rnd(N, seed=17)
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    close_bf16(ops.gemm_rmsnorm(x, w, b), (xf @ w.float().T) * rstd + b.float(), f"norm+gemm {M}x{N}x{K}")
+    wi = interleave_gate_up(w[: N // 2], w[N // 2:])
+    a_, b_ = (xf @ w[: N // 2].float().T) * rstd, (xf @ w[N // 2:].float().T) * rstd
+    close_bf16(ops.gemm_rmsnorm(x, wi, None, epilogue=ops.EPI_SWIGLU), torch.nn.functional.silu(a_) * b_, f"norm+swiglu {M}x{N}x{K}")
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 2560, 2048), (8, 2048, 2048), (8, 22016, 2048), (8, 2048, 11008), (1, 2048, 3584), (5, 640, 256),
+                                   (16, 512, 2048), (40, 96, 4096), (8, 1008, 6152), (64, 704, 264)])
+def test_gemm_packed_weights(ops, M, N, K):
+    """Decode projections over the fragment-packed weight image: plain / norm+bias / residual in place / norm+SwiGLU."""
+    x = rnd(M, K, seed=18)
+    w, b, r = rnd(N, K, scale=0.05, seed=19), rnd(N, seed=20), rnd(M, N, seed=21)
+    wp = ops.pack_weight(w)
+    xf = x.float()
+    lin = xf @ w.float().T
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    close_bf16(ops.gemm_packed(x, wp, N), lin, f"packed {M}x{N}x{K}")
+    close_bf16(ops.gemm_packed(x, wp, N, b, norm_eps=1e-6), lin * rstd + b.float(), f"packed norm+bias {M}x{N}x{K}")
+    out = r.clone()
+    ops.gemm_packed(x, wp, N, out=out, epilogue=ops.EPI_RESID, residual=out)
+    close_bf16(out, lin + r.float(), f"packed resid {M}x{N}x{K}")
+    if N % 32 == 0:
+        wi = ops.pack_weight(interleave_gate_up(w[: N // 2], w[N // 2:]))
+        bi = interleave_gate_up(b[: N // 2].view(-1, 1), b[N // 2:].view(-1, 1)).view(-1)
+        g_, u_ = (xf @ w[: N // 2].float().T) * rstd + b[: N // 2].float(), (xf @ w[N // 2:].float().T) * rstd + b[N // 2:].float()
+        close_bf16(ops.gemm_packed(x, wi, N, bi, epilogue=ops.EPI_SWIGLU, norm_eps=1e-6), torch.nn.functional.silu(g_) * u_,
+                   f"packed swiglu {M}x{N}x{K}")
+
+
 def test_gemm_strided_views_and_argument_errors(ops):
     from padt_amd._lib import PaDTHipError
     big = rnd(100, 512, seed=12)
@@ -181,6 +218,41 @@ def test_decode_attn(ops, D, Hq, Hkv):
         sc = torch.einsum("hd,hld->hl", q[b].float().view(Hq, D), kk) * D ** -0.5
         ref[b] = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vv).reshape(-1)
     close_bf16(out, ref, "decode attn", ulps=6)
+
+
+@pytest.mark.parametrize("D,Hq,Hkv,sec", [(128, 16, 2, (16, 24, 24)), (32, 4, 2, (4, 6, 6))])
+def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
+    """rope table + (rope, append, split attention) + merge == llm_qkv_post → decode_attn, and the fp32 reference."""
+    B, S_max = 3, 1344
+    slots = [577, 63, 1290]
+    qkv = rnd(B, (Hq + 2 * Hkv) * D, seed=33)
+    kc = rnd(B, Hkv, S_max, D, seed=34)
+    v = rnd(B, Hkv, S_max, D, seed=35)
+    vt = v.transpose(2, 3).contiguous()
+    pos = torch.randint(0, 900, (3, B), dtype=torch.int32, device="cuda")
+    slot_t = torch.tensor(slots, dtype=torch.int32, device="cuda")
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).cuda()
+    kc1, vt1, kc2, vt2 = kc.clone(), vt.clone(), kc.clone(), vt.clone()
+    cs = torch.zeros(B, D // 2, 2, device="cuda")
+    ops.rope_table(pos, inv, cs, D, sec)
+    ws = torch.empty(ops.decode_attn_workspace(B, Hkv, D, S_max), dtype=torch.uint8, device="cuda")
+    out1 = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
+    ops.decode_attn_rope(qkv, cs, slot_t, kc1, vt1, out1, ws, Hq, Hkv, D, S_max, S_max)
+    q2 = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
+    ops.llm_qkv_post(qkv, pos, inv, q2, kc2, vt2, Hq, Hkv, D, S_max, sec, slot=slot_t)
+    assert torch.equal(kc1, kc2) and torch.equal(vt1, vt2), "cache append differs"
+    rep = Hq // Hkv
+    ref = torch.zeros(B, Hq * D, device="cuda")
+    for b in range(B):
+        L = slots[b] + 1
+        kk = kc2[b, :, :L].float().repeat_interleave(rep, 0)
+        vv = vt2[b, :, :, :L].float().transpose(1, 2).repeat_interleave(rep, 0)
+        sc = torch.einsum("hd,hld->hl", q2[b].float().view(Hq, D), kk) * D ** -0.5
+        ref[b] = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vv).reshape(-1)
+    close_bf16(out1, ref, "decode attn + rope", ulps=6)
+    out2 = torch.zeros_like(out1)
+    ops.decode_attn(q2, kc2, vt2, slot_t + 1, out2, ws, Hq, Hkv, D, S_max, max(slots) + 1)
+    assert torch.equal(out1, out2), "fused rope/append path differs from llm_qkv_post + decode_attn"
 
 
 # ------------------------------------------------------------------------------------------------------------ row kernels

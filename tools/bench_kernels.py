@@ -1,0 +1,82 @@
+"""Micro-benchmark of the decode-step kernels in isolation (back-to-back launches, HIP events).
+usage: python tools/bench_kernels.py"""
+import os
+import sys
+import torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from padt_amd import ops
+
+BF = torch.bfloat16
+
+
+def timeit(fn, n=200):
+    if os.environ.get('GRAPH'):
+        return timeit_graph(fn, n)
+    for _ in range(5):
+        fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3   # us
+
+
+def timeit_graph(fn, n):
+    for _ in range(12):
+        fn()
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        for _ in range(n):
+            fn()
+    g.replay()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    g.replay()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e3
+
+
+def main():
+    B = int(os.environ.get("B", 8))
+    x = torch.randn(B, 2048, device="cuda").to(BF)
+    h = torch.randn(B, 11008, device="cuda").to(BF)
+    res = {}
+    for name, N, K, epi, a in (("qkv", 2560, 2048, 0, x), ("o", 2048, 2048, 2, x), ("gu", 22016, 2048, 3, x), ("down", 2048, 11008, 2, h)):
+        ws = [torch.randn(N, K, device="cuda").to(BF) * 0.02 for _ in range(int(os.environ.get('ROT', 6)))]   # rotate weights: defeat L2/MALL reuse
+        out = torch.zeros(B, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
+        i = [0]
+
+        def f():
+            w = ws[i[0] % len(ws)]
+            i[0] += 1
+            if os.environ.get("MFMA"):
+                if epi == 2:
+                    ops.gemm(a, w, out=out, epilogue=2, residual=out)
+                else:
+                    ops.gemm_rmsnorm(a, w, out=out, epilogue=epi)
+            elif epi == 2:
+                ops.gemm_packed(a, w, N, out=out, epilogue=2, residual=out)
+            else:
+                ops.gemm_packed(a, w, N, out=out, epilogue=epi, norm_eps=1e-6)
+        t = timeit(f)
+        mb = N * K * 2 / 1e6
+        print(f"{name:5s} N={N:6d} K={K:6d}: {t:7.2f} us  {mb / t * 1e-3 * 1e3:8.1f} GB/s ({mb:.1f} MB)")
+    # pure streaming read reference: torch sum over a 45 MB bf16 tensor
+    big = [torch.randn(2048, 11008, device="cuda").to(BF) for _ in range(6)]
+    i = [0]
+
+    def g():
+        i[0] += 1
+        return big[i[0] % 6].sum()
+    t = timeit(g)
+    print(f"torch.sum 45MB: {t:.2f} us {45.09 / t * 1e3:.1f} GB/s")
+
+
+if __name__ == "__main__":
+    main()
