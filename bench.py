@@ -119,6 +119,24 @@ def roofline_leg(model, inp, args, cfg):
         ms = ctypes.c_float()
         lib.padt_event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
         total += ms.value
+    if args.breakdown:                                             # per-shape efficiency of the tile kernel (stderr)
+        shapes = {}
+        for c in tile:
+            a, w, bias, out, epi, res, f32, K = c
+            shapes.setdefault((a.shape[0], w.shape[0], K if K is not None else a.shape[1], epi), []).append(c)
+        for key, calls in sorted(shapes.items()):
+            for c in calls[:2]:
+                ops.gemm(c[0], c[1], c[2], out=c[3], epilogue=c[4], residual=c[5], out_f32=c[6], K=c[7])
+            torch.cuda.synchronize()
+            lib.padt_event_record(ev0, stream)
+            for c in calls:
+                ops.gemm(c[0], c[1], c[2], out=c[3], epilogue=c[4], residual=c[5], out_f32=c[6], K=c[7])
+            lib.padt_event_record(ev1, stream)
+            ms = ctypes.c_float()
+            lib.padt_event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
+            fl = 2.0 * key[0] * alg(key[1]) * alg(key[2]) * len(calls)
+            print(f"[gemm shape] M={key[0]:6d} N={key[1]:6d} K={key[2]:6d} epi={key[3]} x{len(calls):3d}: "
+                  f"{ms.value * 1e3 / len(calls):8.1f} us/call {fl / (ms.value * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
     lib.padt_event_destroy(ev0)
     lib.padt_event_destroy(ev1)
     ms_per_pass = total / reps

@@ -9,7 +9,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "padt_hip.h")
-LIB_PATH = os.path.join(HERE, "libpadt_hip.so")
+LIB_PATH = os.environ.get("PADT_HIP_LIB") or os.path.join(HERE, "libpadt_hip.so")
 
 _CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
 

@@ -339,6 +339,8 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     __shared__ __attribute__((aligned(16))) bf16_t Knew[D];
     __shared__ __attribute__((aligned(16))) bf16_t Vnew[D];
     __shared__ __attribute__((aligned(16))) bf16_t Pw[16 * 72];
+    __shared__ __attribute__((aligned(16))) bf16_t Raw[18 * D];
+    __shared__ __attribute__((aligned(16))) float Cs[D];
     const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int group = p.Hq / p.Hkv;
@@ -356,14 +358,59 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     const bool owner = (slot >= k0) && (slot < k0 + 64);
     const float* cs = p.rope_cs + (long)b * HALF * 2;
 
+    // ---- all global loads of the block are issued back to back, then consumed: (1) this (b, g)'s raw q/k/v slice and
+    //      the step's cos/sin table (→ LDS staging), (2) every cache fragment of the split (K: 4 key blocks x KQ,
+    //      V^T: 2 k-steps x NB → registers).  One memory round trip instead of four dependent ones.  The fresh token's
+    //      K row / V^T column is patched from LDS afterwards, so reading the (stale) slot here is harmless.
+    constexpr int CPH = D / 8;                                    // 16-byte chunks per head
+    const int n_raw = (group + 2) * CPH;                          // q heads of the group, then k, then v
+    constexpr int RAW_IT = (18 * CPH + 63) / 64;
+    u32x4 raw[RAW_IT];
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int c = it * 64 + lane;
+        const int hh = c / CPH, cc = c % CPH;
+        const bf16_t* src = hh < group ? row + (long)(g * group + hh) * D
+                                       : (hh == group ? row + (long)(p.Hq + g) * D : row + (long)(p.Hq + p.Hkv + g) * D);
+        raw[it] = (c < n_raw) ? *reinterpret_cast<const u32x4*>(src + cc * 8) : u32x4{0u, 0u, 0u, 0u};
+    }
+    float2 csv[(HALF + 63) / 64];
+#pragma unroll
+    for (int it = 0; it < (HALF + 63) / 64; ++it) {
+        const int d = it * 64 + lane;
+        csv[it] = d < HALF ? *reinterpret_cast<const float2*>(cs + 2 * d) : float2{1.f, 0.f};
+    }
+    u32x4 kraw[4][KQ], vraw[2][NB];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+        const int key = k0 + kb * 16 + frow;
+        const int kcl = key < p.S_max ? key : p.S_max - 1;
+#pragma unroll
+        for (int kk = 0; kk < KQ; ++kk) kraw[kb][kk] = *reinterpret_cast<const u32x4*>(kbase + (long)kcl * D + kk * 32 + fq * 8);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+        for (int i = 0; i < NB; ++i)
+            vraw[ks][i] = *reinterpret_cast<const u32x4*>(vbase + (long)(i * 16 + frow) * p.S_max + k0 + ks * 32 + fq * 8);
+
     for (int i = lane; i < 16 * QROW; i += 64) Qs[i] = 0;
+#pragma unroll
+    for (int it = 0; it < RAW_IT; ++it) {
+        const int c = it * 64 + lane;
+        if (c < n_raw) *reinterpret_cast<u32x4*>(Raw + c * 8) = raw[it];
+    }
+#pragma unroll
+    for (int it = 0; it < (HALF + 63) / 64; ++it) {
+        const int d = it * 64 + lane;
+        if (d < HALF) { Cs[2 * d] = csv[it].x; Cs[2 * d + 1] = csv[it].y; }
+    }
     __syncthreads();
     for (int i = lane; i < (group + 1) * HALF; i += 64) {
         const int hh = i / HALF, d = i % HALF;
-        const float c = cs[2 * d], s = cs[2 * d + 1];
-        const bf16_t* x = (hh < group) ? row + (long)(g * group + hh) * D : row + (long)(p.Hq + g) * D;
-        const float x1 = bf2f(x[d]), x2 = bf2f(x[d + HALF]);
-        const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
+        const float c = Cs[2 * d], sn = Cs[2 * d + 1];
+        const float x1 = bf2f(Raw[hh * D + d]), x2 = bf2f(Raw[hh * D + d + HALF]);
+        const bf16_t o1 = f2bf(x1 * c - x2 * sn), o2 = f2bf(x2 * c + x1 * sn);
         if (hh < group) {
             Qs[hh * QROW + d] = o1; Qs[hh * QROW + d + HALF] = o2;
         } else {
@@ -371,9 +418,8 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
             if (owner) { kbase[(long)slot * D + d] = o1; kbase[(long)slot * D + d + HALF] = o2; }
         }
     }
-    const bf16_t* vsrc = row + (long)(p.Hq + p.Hkv + g) * D;
     for (int d = lane; d < D; d += 64) {
-        const bf16_t v = vsrc[d];
+        const bf16_t v = Raw[(group + 1) * D + d];
         Vnew[d] = v;
         if (owner) vbase[(long)d * p.S_max + slot] = v;
     }
@@ -387,12 +433,10 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     for (int kb = 0; kb < 4; ++kb) {
         s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
         const int key = k0 + kb * 16 + frow;
-        const int kcl = key < p.S_max ? key : p.S_max - 1;
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
-            bf16x8 kf = ld_frag(kbase + (long)kcl * D + kk * 32 + fq * 8);
             const bf16x8 kn = ld_frag(Knew + kk * 32 + fq * 8);
-            kf = (key == slot) ? kn : kf;
+            const bf16x8 kf = (key == slot) ? kn : __builtin_bit_cast(bf16x8, kraw[kb][kk]);
             s[kb] = mfma16(qf[kk], kf, s[kb]);
         }
     }
@@ -447,7 +491,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
 #pragma unroll
         for (int i = 0; i < NB; ++i) {
             const int d = i * 16 + frow;
-            u32x4 vv = *reinterpret_cast<const u32x4*>(vbase + (long)d * p.S_max + kk0);
+            u32x4 vv = vraw[ks][i];
             if (j >= 0 && j < 8) {
                 const unsigned nv = Vnew[d];
                 const int wsel = j >> 1;

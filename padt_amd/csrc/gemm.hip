@@ -17,6 +17,7 @@
 // vis_proj (padt.py:189), PaDT decoder projections and heads (padt_decoder.py:15-18,82-86,142-184).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
 
@@ -98,19 +99,30 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // Tile kernel
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int TILE_BYTES = BM * BK * 2;            // 16 KiB per operand tile
-constexpr int GEMM_LDS = 4 * TILE_BYTES;           // 2 buffers x (A, W)
+constexpr int BM = 128, BN = 128;
+template <int BK> struct TileCfg {
+    static constexpr int ROW_BYTES = BK * 2;                 // bytes of one tile row in LDS (128 or 64)
+    static constexpr int CPR = BK / 8;                       // 16-byte chunks per row (8 or 4)
+    static constexpr int TILE_BYTES = BM * ROW_BYTES;        // one operand tile
+    static constexpr int LDS = 4 * TILE_BYTES;               // 2 buffers x (A, W)
+    static constexpr int ROWS_PER_DMA = 1024 / ROW_BYTES;    // rows covered by one 1-KiB wave DMA (8 or 16)
+    static constexpr int DMA_PER_WAVE = BM / ROWS_PER_DMA / 4;
+    // bank-conflict-free XOR swizzle of the 16-byte chunk index for ds_read_b128 (MI355X lane groups):
+    //   128-byte rows: chunk ^ (row & 7);  64-byte rows: chunk ^ ((row >> 1) & 3)   (searched exhaustively, 0 conflicts)
+    PADT_DEV static int swz(int row, int chunk) { return BK == 64 ? (chunk ^ (row & 7)) : (chunk ^ ((row >> 1) & 3)); }
+};
 
+template <int BK>
 PADT_DEV void stage_tile(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int k0, int K,
                          char* lds_tile, int wave, int lane) {
-    // 16 chunks of 1 KiB (8 rows x 128 B); wave w issues chunks 4w..4w+3.  LDS slot (r, s) holds global chunk s^(r&7).
+    using T = TileCfg<BK>;
+    // LDS slot (r, s) holds global chunk swz(r, s): the DMA image is lane-linear, so the swizzle goes on the SOURCE address
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const int c = wave * 4 + i;
-        const int r = c * 8 + (lane >> 3);
-        const int s = lane & 7;
-        const int j = s ^ (r & 7);
+    for (int i = 0; i < T::DMA_PER_WAVE; ++i) {
+        const int c = wave * T::DMA_PER_WAVE + i;
+        const int r = c * T::ROWS_PER_DMA + lane / T::CPR;
+        const int sl = lane % T::CPR;
+        const int j = T::swz(r, sl);
         int row = row0 + r;
         row = row < nrows ? row : nrows - 1;
         const int k = k0 + j * 8;
@@ -123,8 +135,11 @@ PADT_DEV void stage_tile(const bf16_t* __restrict__ base, long ld, int row0, int
     }
 }
 
-template <int EPI, bool OUT_F32>
+// Measured dead ends on this structure (profiles/r01_gemm_tile_experiments.md): BK = 32 with 3 blocks/CU (-15 %),
+// precomputed per-lane DMA pointers (+50 VGPRs, -9 %), DMA pieces spread between the MFMA groups (-10 %).
+template <int EPI, bool OUT_F32, int BK>
 __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
+    using T = TileCfg<BK>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
@@ -141,8 +156,8 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 
     // LDS: [buf0: A | W][buf1: A | W]
-    stage_tile(p.A, p.lda, m0, p.M, 0, p.K, smem, wave, lane);
-    stage_tile(p.W, p.ldw, n0, p.N, 0, p.K, smem + TILE_BYTES, wave, lane);
+    stage_tile<BK>(p.A, p.lda, m0, p.M, 0, p.K, smem, wave, lane);
+    stage_tile<BK>(p.W, p.ldw, n0, p.N, 0, p.K, smem + T::TILE_BYTES, wave, lane);
 
     const int frow = lane & 15, fq = lane >> 4;
     for (int t = 0; t < nk; ++t) {
@@ -150,22 +165,22 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
         __syncthreads();                                   // tile t landed everywhere; everyone is done reading buf[(t+1)&1]
         const int cur = t & 1;
         if (t + 1 < nk) {
-            char* nxt = smem + (cur ^ 1) * 2 * TILE_BYTES;
-            stage_tile(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, nxt, wave, lane);
-            stage_tile(p.W, p.ldw, n0, p.N, (t + 1) * BK, p.K, nxt + TILE_BYTES, wave, lane);
+            char* nxt = smem + (cur ^ 1) * 2 * T::TILE_BYTES;
+            stage_tile<BK>(p.A, p.lda, m0, p.M, (t + 1) * BK, p.K, nxt, wave, lane);
+            stage_tile<BK>(p.W, p.ldw, n0, p.N, (t + 1) * BK, p.K, nxt + T::TILE_BYTES, wave, lane);
         }
-        const char* a_t = smem + cur * 2 * TILE_BYTES;
-        const char* w_t = a_t + TILE_BYTES;
+        const char* a_t = smem + cur * 2 * T::TILE_BYTES;
+        const char* w_t = a_t + T::TILE_BYTES;
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
+        for (int kk = 0; kk < BK / 32; ++kk) {
             const int j = kk * 4 + fq;
             bf16x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ra = wm * 64 + i * 16 + frow;
-                af[i] = ld_frag(a_t + ra * 128 + ((j ^ (ra & 7)) << 4));
+                af[i] = ld_frag(a_t + ra * T::ROW_BYTES + (T::swz(ra, j) << 4));
                 const int rw = wn * 64 + i * 16 + frow;
-                wf[i] = ld_frag(w_t + rw * 128 + ((j ^ (rw & 7)) << 4));
+                wf[i] = ld_frag(w_t + rw * T::ROW_BYTES + (T::swz(rw, j) << 4));
             }
 #pragma unroll
             for (int mi = 0; mi < 4; ++mi)
@@ -358,16 +373,23 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 // host side
 extern "C" void padt_set_error(const char* msg);
 
-template <int EPI, bool F32>
-static void launch_tile(const GemmArgs& a, hipStream_t s) {
+template <int EPI, bool F32, int BK>
+static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
     static bool attr_done = false;
     if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<EPI, F32>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, GEMM_LDS);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<EPI, F32, BK>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<BK>::LDS);
         attr_done = true;
     }
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
-    hipLaunchKernelGGL((gemm_tile_kernel<EPI, F32>), dim3(ntm * ntn), dim3(256), GEMM_LDS, s, a);
+    hipLaunchKernelGGL((gemm_tile_kernel<EPI, F32, BK>), dim3(ntm * ntn), dim3(256), TileCfg<BK>::LDS, s, a);
+}
+
+template <int EPI, bool F32>
+static void launch_tile(const GemmArgs& a, hipStream_t s) {
+    static const int bk = getenv("PADT_TILE_BK") ? atoi(getenv("PADT_TILE_BK")) : 64;        // tuning knob
+    if (bk == 32) launch_tile_bk<EPI, F32, 32>(a, s);
+    else launch_tile_bk<EPI, F32, 64>(a, s);
 }
 
 template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false>
