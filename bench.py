@@ -38,6 +38,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
+    ap.add_argument("--depth", type=int, default=2, help="batches in flight on separate HIP streams (1 = no overlap)")
     return ap.parse_args()
 
 
@@ -264,12 +265,37 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        run_step(model, inp, args, world)
+    from padt_amd import pipeline
+    runner = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth) if args.depth > 1 else None
+
+    def gather(decoded):
+        if world > 1:
+            packed = pipeline.pack_results(decoded, cap=4 * args.batch, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
+                                           device=inp["pix"].device)
+            pipeline.all_gather_results(packed)
+
+    def run_steps(k):
+        """k steps = k batches through the whole path; with depth > 1 consecutive batches overlap on separate streams
+        (every batch is complete — results on the host side of vl_decode — before this returns)."""
+        last = None
+        if runner is None:
+            for _ in range(k):
+                last = run_step(model, inp, args, world)
+            return last
+        for _ in range(k):
+            r = runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
+            if r is not None:
+                last = r[0]
+                gather(last)
+        for r in runner.flush():
+            last = r[0]
+            gather(last)
+        return last
+
+    run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
-        decoded = run_step(model, inp, args, world)
+    decoded = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -305,7 +331,7 @@ def main():
             "config": {"workload": "PaDT_Pro_3B REC, batch=%d/GPU 640x640 synthetic (grid 46x46, L=577, T_new=%d, 1 obj x 5 VRT, "
                                    "mask head on), bf16, random-init 3.85B weights" % (args.batch, args.tnew)
                        if args.model == "3b" else "small_test_config (plumbing)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}"},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth},
             "alg_tflops_e2e": round(value * ALG_TFLOP_PER_IMAGE, 1) if args.model == "3b" else None,
             "mfma_frac_e2e": round(value * ALG_TFLOP_PER_IMAGE / MFMA_BF16_PEAK_TFLOPS / world, 4) if args.model == "3b" else None,
         }

@@ -219,9 +219,9 @@ class LanguageModel:
         t = ops.gemm(p, W["proto.0.w"])
         return ops.gemm(t, W["proto.1.w"], out=out, epilogue=ops.EPI_RESID, residual=p)
 
-    def session(self, B: int, need_s: int, need_np: int, need_t: int) -> DecodeSession:
+    def session(self, B: int, need_s: int, need_np: int, need_t: int, lane: int = 0) -> DecodeSession:
         s_max = (need_s + 63) // 64 * 64
-        key = B
+        key = (B, lane)
         s = self._sessions.get(key)
         if s is None or s.s_max < s_max or s.np_max < need_np or s.t_max < need_t:
             s = DecodeSession(self.cfg, self.W, B, max(s_max, s.s_max if s else 0), max(need_np, s.np_max if s else 0),

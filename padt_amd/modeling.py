@@ -137,12 +137,24 @@ class PaDTForConditionalGeneration:
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
                  max_new_tokens=1024, do_sample=False, output_hidden_states=True, return_dict_in_generate=True,
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
-                 use_graph: bool = True, **unused):
+                 use_graph: bool = True, lane: int = 0, **unused):
         """Greedy generation over the unified text‖VRT vocabulary.
 
         ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
         VRT rows only, 'e' force EOS, None free — applied where HF's ``logits_processor`` sits (padt.py:717).
+        ``lane`` selects an independent decode session (KV caches, token ring, graph) so several batches can be in
+        flight on different HIP streams (pipeline.PipelinedRunner).
         """
+        ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
+                                   schedule, sync_every, use_graph, lane)
+        return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate)
+
+    @torch.no_grad()
+    def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=False,
+                        schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None):
+        """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
+        the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
+        Returns a context for generate_collect()."""
         if do_sample:
             raise NotImplementedError("sampling (padt.py:740-743) is not on the accelerated path; use do_sample=False")
         if pixel_values is None or image_grid_thw is None:
@@ -154,7 +166,7 @@ class PaDTForConditionalGeneration:
         B = plan.B
         T_max = int(max_new_tokens)
         n_proto = plan.vrt_off[-1]
-        sess = self.lm.session(B, max(plan.lens) + T_max, n_proto, T_max)
+        sess = self.lm.session(B, max(plan.lens) + T_max, n_proto, T_max, lane=lane)
 
         # ---- ViT → prototypes → session table
         low, high, pe = self.visual(pixel_values.to(dev), grid)
@@ -164,31 +176,47 @@ class PaDTForConditionalGeneration:
         if schedule is not None:
             for i, m in enumerate(schedule[: T_max]):
                 st[i] = MODE[m]
-        sess.mode_table[: T_max + 1].copy_(st.to(dev))
+        sess.mode_table[: T_max + 1].copy_(st.to(dev, non_blocking=True))
         off = torch.tensor(plan.vrt_off + [plan.vrt_off[-1]] * (sess.B + 1 - len(plan.vrt_off)), dtype=torch.int32)
-        sess.vrt_off.copy_(off.to(dev))
+        sess.vrt_off.copy_(off.to(dev, non_blocking=True))
         sess.step.zero_()
         sess.unfinished.fill_(1)
         sess.err.zero_()
         lens_t = torch.tensor(plan.lens, dtype=torch.int32)
-        sess.slot.copy_(lens_t.to(dev))                           # next append index
-        sess.lens.copy_((lens_t + 1).to(dev))                     # keys visible to the next token
-        sess.pos3.copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev))
+        sess.slot.copy_(lens_t.to(dev, non_blocking=True))        # next append index
+        sess.lens.copy_((lens_t + 1).to(dev, non_blocking=True))  # keys visible to the next token
+        sess.pos3.copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev, non_blocking=True))
         self.rope_deltas = plan.rope_deltas
 
-        # ---- prefill + first token
+        # ---- prefill + first token, then the first chunk of decode steps (hipGraph replays, no host sync)
         hn_all = self.lm.prefill(plan, low, sess)
         h_last = ops.gather_rows(hn_all, plan.last_idx)
         sess.head_and_select(h_last, advance=False)
-
-        # ---- decode steps: hipGraph replays, host sync every `sync_every` steps
-        done_steps = 1
-        while done_steps < T_max:
-            n = min(sync_every, T_max - done_steps)
+        done = 1
+        n = min(sync_every, T_max - done)
+        if decode_stream is not None:
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(decode_stream):
+                decode_stream.wait_event(ev)
+                sess.run_steps(n, use_graph=use_graph)
+        else:
             sess.run_steps(n, use_graph=use_graph)
+        done += n
+        return dict(plan=plan, sess=sess, low=low, high=high, pe=pe, proto=proto, hn_all=hn_all, done=done, T_max=T_max,
+                    sync_every=sync_every, use_graph=use_graph, input_ids=input_ids, n_proto=n_proto)
+
+    @torch.no_grad()
+    def generate_collect(self, ctx, output_hidden_states=True, return_dict_in_generate=True):
+        """Synchronising half of generate(): remaining decode chunks (host checks `unfinished` between chunks), trimming
+        to the reference's stop rule, output object."""
+        cfg, dev = self.config, self.device
+        plan, sess, T_max = ctx["plan"], ctx["sess"], ctx["T_max"]
+        B = plan.B
+        done_steps = ctx["done"]
+        while done_steps < T_max and bool(sess.unfinished.any()):
+            n = min(ctx["sync_every"], T_max - done_steps)
+            sess.run_steps(n, use_graph=ctx["use_graph"])
             done_steps += n
-            if not bool(sess.unfinished.any()):
-                break
         if int(sess.err) != 0:
             raise AssertionError("input_ids.max() >= extended table rows (padt.py:203)")
         toks = sess.tokens[:, :done_steps].clone()
@@ -198,10 +226,9 @@ class PaDTForConditionalGeneration:
             stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
             toks = toks[:, :stop]
         n_steps = toks.shape[1]
-        sequences = torch.cat([input_ids.to(dev), toks], dim=1)
-        hidden = StepHiddenStates(sess.hidden_buf[:n_steps].clone(), n_steps, hn_all.clone(),
-                                  plan.lens, plan.L_pad)
-        table_rows = cfg.vocab_size + n_proto
+        sequences = torch.cat([ctx["input_ids"].to(dev), toks], dim=1)
+        hidden = StepHiddenStates(sess.hidden_buf[:n_steps].clone(), n_steps, ctx["hn_all"], plan.lens, plan.L_pad)
+        table_rows = cfg.vocab_size + ctx["n_proto"]
 
         def logit_mask():
             m = torch.zeros((B, table_rows), dtype=torch.bool, device=dev)
@@ -213,8 +240,8 @@ class PaDTForConditionalGeneration:
         out = CustomGenerateDecoderOnlyOutput(
             sequences=sequences, scores=None, logits=None, attentions=None,
             hidden_states=hidden if output_hidden_states else None, past_key_values=sess,
-            past_image_embeds=proto.clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=high,
-            past_visual_pe=pe)
+            past_image_embeds=ctx["proto"].clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=ctx["high"],
+            past_visual_pe=ctx["pe"])
         return out if return_dict_in_generate else sequences
 
     # ------------------------------------------------------------------ vl_decode (padt.py:342-412)

@@ -30,6 +30,54 @@ def rec_batch(model, processor, input_ids, attention_mask, pixel_values, image_g
     return decoded, completions, labels, vrts
 
 
+class PipelinedRunner:
+    """Keeps `depth` batches in flight: ViT + prefill of batch i+1 (MFMA-bound) run on a normal-priority HIP stream while
+    the decode steps, parse and PaDT decoder of batch i (HBM- / launch-latency-bound) run on a HIGH-priority stream, each
+    batch with its own decode session ("lane": KV caches, token ring, captured graph).  Results are identical to
+    rec_batch (same kernels, same order within a batch); only the interleaving across batches changes.
+
+        r = PipelinedRunner(model, processor); for b in batches: done = r.submit(**b); ...; rest = r.flush()
+    """
+
+    def __init__(self, model, processor, depth: int = 2):
+        self.model, self.processor, self.depth = model, processor, depth
+        self.prefill_stream = torch.cuda.Stream(device=model.device)
+        # one decode stream per lane: a batch's host-synchronising collect must not queue behind the next batch's decode
+        self.decode_streams = [torch.cuda.Stream(device=model.device, priority=-1) for _ in range(depth)]
+        self.pending = []
+        self.count = 0
+
+    def submit(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, schedule=None,
+               need_thinking_mask=None, sync_every=None):
+        lane = self.count % self.depth
+        self.count += 1
+        self.prefill_stream.wait_stream(torch.cuda.current_stream())   # inputs were produced on the caller's stream
+        ids = self.processor.assign_to_global_vrt_id(input_ids, image_grid_thw)
+        with torch.cuda.stream(self.prefill_stream):
+            ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
+                                             schedule, sync_every or max_new_tokens, True, lane, self.decode_streams[lane])
+        self.pending.append((lane, ctx, input_ids.shape, image_grid_thw, need_thinking_mask))
+        return self._finish_oldest() if len(self.pending) >= self.depth else None
+
+    def _finish_oldest(self):
+        lane, ctx, shape, grid, mask = self.pending.pop(0)
+        B, L = shape
+        with torch.cuda.stream(self.decode_streams[lane]):
+            out = self.model.generate_collect(ctx)
+            seq_local = self.processor.assign_to_local_vrt_id(out["sequences"].cpu(), grid.cpu())
+            m = mask if mask is not None else torch.Tensor([False] * B)
+            completions, feats, labels, vrts, _ = parseVRTintoCompletion(self.processor, seq_local[:, L:], out["hidden_states"], m)
+            decoded = self.model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+        self.decode_streams[lane].synchronize()
+        return decoded, completions, labels, vrts
+
+    def flush(self):
+        res = []
+        while self.pending:
+            res.append(self._finish_oldest())
+        return res
+
+
 # --------------------------------------------------------------------------------------------- result exchange (RCCL)
 def pack_results(decoded: dict, cap: int, mask_hw: int, device) -> dict:
     """Fixed-capacity buffers so every rank contributes the same shapes to one all_gather."""

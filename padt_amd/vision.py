@@ -89,6 +89,7 @@ class VisionEncoder:
         key = tuple(tuple(int(x) for x in r) for r in grid_thw.tolist())
         if key not in self._plans:
             self._plans[key] = VisionPlan(self.cfg, key, self.device)
+            torch.cuda.current_stream().synchronize()        # tables are shared by every stream that runs this grid later
         return self._plans[key]
 
     def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):

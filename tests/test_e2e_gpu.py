@@ -158,3 +158,31 @@ def test_empty_vl_decode_and_error_conventions(setup):
         model.generate(input_ids=bad.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=2)
     assert out["sequences"] is out.sequences and model.config.vision_config.spatial_merge_size == 2
     assert model.model.embed_tokens.weight.shape[0] == cfg.vocab_size
+
+
+def test_pipelined_runner_matches_sequential(setup):
+    """Two batches in flight on two HIP streams (separate decode sessions) give bit-identical results to rec_batch."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    T = 9
+    sched = U.rec_schedule(T, vrt_at=range(3, 6))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = []
+    for s in range(3):
+        grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=7, seed=100 + s, ragged=True)
+        batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
+    ref = [pipeline.rec_batch(model, proc, b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched) for b in batches]
+    runner = pipeline.PipelinedRunner(model, proc, depth=2)
+    got = []
+    for b in batches:
+        r = runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+        if r is not None:
+            got.append(r)
+    got += runner.flush()
+    assert len(got) == 3
+    for (d0, c0, l0, v0), (d1, c1, l1, v1) in zip(ref, got):
+        assert c0 == c1 and v0 == v1
+        assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"])
+        assert torch.equal(d0["pred_score"], d1["pred_score"])
