@@ -142,7 +142,7 @@ def roofline_leg(model, inp, args, cfg):
     lib.padt_event_destroy(ev1)
     ms_per_pass = total / reps
     achieved = flops / (ms_per_pass * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_tile_kernel (bf16 MFMA 16x16x32, 128x128x64 LDS-DMA tiles)",
+    return {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
             "launches_per_step": len(tile), "avg_launch_us": round(ms_per_pass * 1e3 / max(len(tile), 1), 2),

@@ -1,0 +1,299 @@
+// 256x256x64 phase-pipelined bf16 MFMA GEMM for gfx950 (large-N shapes of ViT / prefill):
+//     C[M,N] = epi(A[M,K] · W[N,K]^T + bias)          same operands / epilogues as gemm_tile_kernel (gemm.hip)
+//
+// Why a second tile kernel: the 128^2 two-barrier kernel drains its LDS-DMA at every K-step (s_waitcnt vmcnt(0) +
+// barrier) and tops out at ≈880 TFLOP/s (profiles/r01_gemm_tile_experiments.md).  This one never drains:
+//   * 8 waves (2 x 4), wave tile 128 x 64 → 64 MFMA 16x16x32 per wave per K-tile, issued as 4 PHASES of 16 (one
+//     64 x 32 quadrant each, order (m0,n0) (m0,n1) (m1,n1) (m1,n0) so one operand sub-tile stays in registers between
+//     neighbouring phases: 8 or 4 ds_read_b128 per phase instead of 12);
+//   * LDS holds two K-tiles as 2 x 4 half-tiles of 16 KiB: A-half h = the m-half h rows of every wave, B-half h = the
+//     n-half h columns of every wave — so a half-tile is dead after the last phase that uses it and can be re-staged
+//     while the rest of its K-tile is still being multiplied;
+//   * every phase stages exactly one half-tile of a FUTURE K-tile (2 LDS-DMA pieces per wave):
+//         phase 0 → B1(t+1)   phase 1 → A1(t+1)   phase 2 → A0(t+2)   phase 3 → B0(t+2)
+//     and waits with a COUNTED s_waitcnt vmcnt(6): the three most recent half-tiles stay in flight across barriers,
+//     the data a phase reads was issued >= 5 phases (>= 1300 MFMA cycles) earlier;
+//   * a phase = load segment | raw s_barrier | 16-MFMA segment | raw s_barrier, and the two wave groups (wr = 0 / 1,
+//     i.e. the two waves of every SIMD) run ONE BARRIER APART: while one multiplies, the other stages and reads LDS;
+//   * s_setprio(1) around each 16-MFMA cluster; same source-side XOR swizzle as gemm_tile_kernel (0 bank conflicts).
+#include "common.h"
+#include <stdlib.h>
+#include <type_traits>
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
+
+struct Gemm256Args {
+    const bf16_t* A; long lda;
+    const bf16_t* W; long ldw;
+    const bf16_t* bias;
+    void* C; long ldc;
+    const bf16_t* R; long ldr;
+    int M, N, K;
+};
+
+__device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
+
+namespace {
+constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int HALF_BYTES = 128 * TK * 2;            // 16 KiB: 128 rows x 128 B
+constexpr int LDS_BYTES = 8 * HALF_BYTES;           // 2 K-tiles x {A0, A1, B0, B1}
+
+PADT_DEV char* slot(char* smem, int parity, int is_b, int h) { return smem + ((parity * 4) + is_b * 2 + h) * HALF_BYTES; }
+
+// Per-lane byte offsets (relative to the tile's first row at k = 0) of the two 1-KiB DMA pieces this wave issues for
+// half-tile (is_b, h): piece c = 2*wave + i covers local rows 8c..8c+7; LDS slot (lr, lane & 7) holds source chunk
+// (lane & 7) ^ (lr & 7).  Computed once per block; a K-step only moves the (wave-uniform) base pointer by 128 bytes.
+PADT_DEV unsigned piece_offset(int is_b, int h, int i, int wave, int lane, int row0, int nrows, long ld) {
+    const int c = wave * 2 + i;
+    const int lr = c * 8 + (lane >> 3);
+    const int j = (lane & 7) ^ (lr & 7);
+    int g = is_b ? (lr >> 5) * 64 + h * 32 + (lr & 31) : (lr >> 6) * 128 + h * 64 + (lr & 63);
+    g = (row0 + g < nrows) ? g : nrows - 1 - row0;                // clamp to the last valid row (results are not stored)
+    return (unsigned)(((long)g * ld + j * 8) * 2);
+}
+
+PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, int wave) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off0),
+                                     (__attribute__((address_space(3))) void*)(dst + (wave * 2) * 1024), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off1),
+                                     (__attribute__((address_space(3))) void*)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
+}
+
+PADT_DEV bf16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
+
+PADT_DEV void unpack4b(u32x2 v, float* f) {
+    f[0] = __builtin_bit_cast(float, v[0] << 16);
+    f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
+    f[2] = __builtin_bit_cast(float, v[1] << 16);
+    f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
+}
+}  // namespace
+
+template <int EPI, bool OUT_F32>
+__global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int frow = lane & 15, fq = lane >> 4;
+    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
+    const int id = xcd_remap(blockIdx.x, ntm * ntn);
+    const int tm = id / ntn, tn = id % ntn;
+    const int m0 = tm * TM, n0 = tn * TN;
+    const int wr = wave >> 2, wc = wave & 3;
+    const int nk = (p.K + TK - 1) / TK;
+
+    f32x4 acc[8][4];
+#pragma unroll
+    for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    bf16x8 af[4][2], b0[2][2], b1[2][2];                          // A sub-tile, B n-half 0 (kept all tile), B n-half 1
+
+    unsigned offA[2][2], offB[2][2];                              // [half][piece] per-lane byte offsets, see piece_offset
+#pragma unroll
+    for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            offA[h][i] = piece_offset(0, h, i, wave, lane, m0, p.M, p.lda);
+            offB[h][i] = piece_offset(1, h, i, wave, lane, n0, p.N, p.ldw);
+        }
+    const char* tileA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);     // wave-uniform bases
+    const char* tileW = reinterpret_cast<const char*>(p.W + (long)n0 * p.ldw);
+    auto stage_half = [&](int t, int is_b, int h, char* dst) {    // K % 64 == 0 (dispatcher): no tail, no zero page
+        if (is_b) dma2(tileW + (long)t * (TK * 2), offB[h][0], offB[h][1], dst, wave);
+        else dma2(tileA + (long)t * (TK * 2), offA[h][0], offA[h][1], dst, wave);
+    };
+
+    // ---- prologue: the issue order of the steady state: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
+    stage_half(0, 0, 0, slot(smem, 0, 0, 0));
+    stage_half(0, 1, 0, slot(smem, 0, 1, 0));
+    stage_half(0, 1, 1, slot(smem, 0, 1, 1));
+    stage_half(0, 0, 1, slot(smem, 0, 0, 1));
+    if (nk > 1) {
+        stage_half(1, 0, 0, slot(smem, 1, 0, 0));
+        stage_half(1, 1, 0, slot(smem, 1, 1, 0));
+    }
+    // Stagger: the wr = 1 waves run one barrier (= half a phase) behind the wr = 0 waves, so on every SIMD (waves w and
+    // w + 4) one wave is in its 16-MFMA segment while the other stages / reads LDS.  They make up for it at the end.
+    const int wr_u = __builtin_amdgcn_readfirstlane(wr);          // provably wave-uniform → scalar branch around s_barrier
+    if (wr_u == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // tile 0 complete (A0(1), B0(1) may still fly)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                                 // both groups have waited before anyone reads tile 0
+
+    // Phase PH of K-tile t = LOAD segment | barrier | 16-MFMA segment (+ counted wait) | barrier.
+    //   stage issued per phase:  0 → B1(t+1)   1 → A1(t+1)   2 → A0(t+2)   3 → B0(t+2)
+    //   (every slot is re-staged >= 2 phases after its last ds_read, every half-tile is read >= 5 phases after its issue:
+    //    both survive the half-phase lag between the two wave groups)
+    //   LDS reads per phase:     0 → A m-half 0 (8) + B n-half 0 (4)   1 → B n-half 1 (4)   2 → A m-half 1 (8)   3 → none
+    auto phase = [&](int t, auto ph_tag, auto steady_tag) {
+        constexpr int PH = decltype(ph_tag)::value;
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int par = t & 1;
+        if (PH == 0) { if (STEADY || t + 1 < nk) stage_half(t + 1, 1, 1, slot(smem, par ^ 1, 1, 1)); }
+        if (PH == 1) { if (STEADY || t + 1 < nk) stage_half(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1)); }
+        if (PH == 2) { if (STEADY || t + 2 < nk) stage_half(t + 2, 0, 0, slot(smem, par, 0, 0)); }
+        if (PH == 3) { if (STEADY || t + 2 < nk) stage_half(t + 2, 1, 0, slot(smem, par, 1, 0)); }
+        constexpr int MH = (PH >= 2) ? 1 : 0;                     // quadrant order (0,0) (0,1) (1,1) (1,0)
+        constexpr int NH = (PH == 1 || PH == 2) ? 1 : 0;
+        if (PH == 0 || PH == 2) {
+            const char* ah = slot(smem, par, 0, MH);
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * 64 + i * 16 + frow, kk * 4 + fq);
+        }
+        if (PH == 0) {
+            const char* bh = slot(smem, par, 1, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) b0[i][kk] = rd(bh, wc * 32 + i * 16 + frow, kk * 4 + fq);
+        }
+        if (PH == 1) {
+            const char* bh = slot(smem, par, 1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) b1[i][kk] = rd(bh, wc * 32 + i * 16 + frow, kk * 4 + fq);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j)
+                    acc[MH * 4 + i][NH * 2 + j] = mfma16(NH ? b1[j][kk] : b0[j][kk], af[i][kk], acc[MH * 4 + i][NH * 2 + j]);
+        __builtin_amdgcn_s_setprio(0);
+        // retire this wave's DMA pieces of everything up to 4 stages back: the NEXT-BUT-ONE load segment reads them after
+        // two more barriers, by which time the lagging group has executed the same wait
+        if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    using P2 = std::integral_constant<int, 2>;
+    using P3 = std::integral_constant<int, 3>;
+    int t = 0;
+    for (; t + 2 < nk; ++t) {                                     // steady state: every phase issues a stage
+        phase(t, P0{}, std::true_type{});
+        phase(t, P1{}, std::true_type{});
+        phase(t, P2{}, std::true_type{});
+        phase(t, P3{}, std::true_type{});
+    }
+    for (; t < nk; ++t) {                                         // last two K-tiles: stages run out → drain instead of count
+        phase(t, P0{}, std::false_type{});
+        phase(t, P1{}, std::false_type{});
+        phase(t, P2{}, std::false_type{});
+        phase(t, P3{}, std::false_type{});
+    }
+    if (wr_u == 0) __builtin_amdgcn_s_barrier();                  // matches the extra barrier of the lagging group
+
+    // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
+    const bf16_t* zpage = reinterpret_cast<const bf16_t*>(g_zero_page256);
+#pragma unroll
+    for (int mi = 0; mi < 8; ++mi) {
+        const int m = m0 + wr * 128 + mi * 16 + frow;
+        if (m >= p.M) continue;
+        if (EPI == EPI_SWIGLU) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ni += 2) {
+                const int n = n0 + wc * 64 + ni * 16 + fq * 4;    // interleaved row index of the gate quad
+                if (n >= p.N) continue;
+                const bf16_t* bp = p.bias ? p.bias + n : zpage;
+                float gb[4], ub[4], o[4];
+                unpack4b(*reinterpret_cast<const u32x2*>(bp), gb);
+                unpack4b(*reinterpret_cast<const u32x2*>(bp + (p.bias ? 16 : 0)), ub);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] + gb[r]) * (acc[mi][ni + 1][r] + ub[r]);
+                const int no = (n >> 5) * 16 + (n & 15);
+                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) =
+                    u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            }
+        } else {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) {
+                const int n = n0 + wc * 64 + ni * 16 + fq * 4;
+                if (n + 3 >= p.N) {                               // ragged N tail: scalar
+                    for (int r = 0; r < 4 && n + r < p.N; ++r) {
+                        float x = acc[mi][ni][r];
+                        if (p.bias) x += bf2f(p.bias[n + r]);
+                        if (EPI == EPI_GELU) x = gelu_erf(x);
+                        if (EPI == EPI_RESID) x += bf2f(p.R[(long)m * p.ldr + n + r]);
+                        if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+                        else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
+                    }
+                    continue;
+                }
+                const bf16_t* bp = p.bias ? p.bias + n : zpage;
+                float bv[4], o[4];
+                unpack4b(*reinterpret_cast<const u32x2*>(bp), bv);
+                u32x2 rraw = u32x2{0u, 0u};
+                if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bv[r];
+                if (EPI == EPI_GELU) {
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+                }
+                if (EPI == EPI_RESID) {
+                    float rv[4];
+                    unpack4b(rraw, rv);
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                }
+                if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            }
+        }
+    }
+}
+
+template <int EPI, bool F32>
+static void launch256(const Gemm256Args& a, hipStream_t s) {
+    static bool done = false;
+    if (!done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32>),
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+        done = true;
+    }
+    const int ntm = (a.M + TM - 1) / TM, ntn = (a.N + TN - 1) / TN;
+    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
+}
+
+// Called by padt_gemm_bf16's dispatcher (gemm.hip) for shapes where the 256^2 tiling pays; arguments already validated.
+// Returns 0 when it took the launch, 1 when the shape should stay on the 128^2 kernel.
+extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+                                long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32) {
+    static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
+    if (mode == 0) return 1;
+    const long ntm = (M + TM - 1) / TM, ntn = (N + TN - 1) / TN;
+    if (mode == 1) {
+        // auto: measured on MI355X (profiles/r01_gemm_tile_experiments.md) the phase-pipelined kernel wins or ties on every
+        // ViT / prefill shape of the model once all three dimensions are a few tiles deep; tiny problems keep the 128^2
+        // kernel (2 blocks/CU hide their prologue / epilogue better)
+        if (M < 512 || N < 512 || K < 512) return 1;
+    }
+    if (K % TK) return 1;                                         // no K-tail path in this kernel
+    {
+    }
+    Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
+                  (int)M, (int)N, (int)K};
+    hipStream_t s = (hipStream_t)stream;
+    switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
+        case 0: launch256<EPI_NONE, false>(a, s); break;
+        case 1: launch256<EPI_NONE, true>(a, s); break;
+        case 2: launch256<EPI_GELU, false>(a, s); break;
+        case 3: launch256<EPI_GELU, true>(a, s); break;
+        case 4: launch256<EPI_RESID, false>(a, s); break;
+        case 5: launch256<EPI_RESID, true>(a, s); break;
+        case 6: launch256<EPI_SWIGLU, false>(a, s); break;
+        default: return 1;
+    }
+    return 0;
+}
