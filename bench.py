@@ -37,6 +37,7 @@ def parse_args():
     ap.add_argument("--model", default="3b", choices=["3b", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--timeline", action="store_true", help="print a stream timeline of 4 pipelined steps to stderr")
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight on separate HIP streams (1 = no overlap)")
     return ap.parse_args()
@@ -304,6 +305,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert decoded["pred_boxes"].shape == (args.batch, 4) and torch.isfinite(decoded["pred_boxes"]).all()
+
+    if args.timeline and runner is not None and rank == 0:
+        # stream timeline of a few pipelined steps (events on the prefill / per-lane decode streams), ms from the first mark
+        runner.trace = []
+        torch.cuda.synchronize()
+        w0 = time.perf_counter()
+        run_steps(4)
+        torch.cuda.synchronize()
+        wall = (time.perf_counter() - w0) * 1e3
+        base = runner.trace[0][2]
+        marks = sorted(((base.elapsed_time(e), b, tag) for b, tag, e in runner.trace))
+        b0 = runner.trace[0][0]
+        print(f"[timeline] 4 steps, wall {wall:.1f} ms", file=sys.stderr)
+        for t, b, tag in marks:
+            print(f"[timeline] {t:8.2f} ms  batch {b - b0}  {tag}", file=sys.stderr)
+        runner.trace = None
 
     if args.breakdown and rank == 0:
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]

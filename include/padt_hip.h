@@ -48,9 +48,15 @@ int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, con
  * padt_gemm_bf16 / padt_gemm_rmsnorm_bf16, but W is stored as [N/16][Kp/32][64 lanes][8] so every wave instruction
  * reads 1 KiB contiguous bytes (row-major fragments load 16 rows x 64 B and run the address unit at a quarter rate).
  * Kp = padded K (multiple of 32) of the packed image, N must be a multiple of 16.  epilogue 0 none, 2 += R, 3 SwiGLU;
- * norm_eps >= 0 fuses the preceding RMSNorm as a row scale (folded norm weight), < 0 disables it.  HF:727-757, T = 1. */
+ * norm_eps >= 0 fuses the preceding RMSNorm as a row scale (folded norm weight), < 0 disables it.  HF:727-757, T = 1.
+ * split_k in [2, 8] (epilogue 0 / 2, no norm) spreads K over that many blocks per 16 output columns — for projections
+ * with N/16 < #CUs (down_proj: 128 column blocks) — using `workspace` (padt_gemm_splitk_workspace(N, split_k) bytes,
+ * private to one stream, first 256*ceil(N/16*4/256) bytes ZERO before the first call; the kernel leaves them zero).
+ * split_k <= 1: workspace may be null. */
+long padt_gemm_splitk_workspace(long N, int split_k);
 int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
-                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps);
+                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
+                          int split_k, void* workspace);
 
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
@@ -61,13 +67,16 @@ int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long 
                      int n_kv_heads, int head_dim, float scale, int causal);
 /* Single-token decode attention over the KV cache (K row-major [B][Hkv][S_max][D], V transposed [B][Hkv][D][S_max]),
  * split over 64-key chunks + combine.  lens[b] = valid keys incl. the token just appended; max_len bounds them.
- * Replaces the Lq==1 case of HF:641-689 with DynamicCache. */
+ * Replaces the Lq==1 case of HF:641-689 with DynamicCache.
+ * Workspace contract: padt_decode_attn_workspace() bytes, private to one stream, and its first
+ * 256*ceil(batch*n_kv_heads*4/256) bytes (completion tickets) ZERO before the first call — the kernels leave them zero. */
 long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max);
 int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens, void* out,
                       void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, int max_len,
                       float scale);
 
-/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks + combine.
+/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks; the last
+ * chunk of a (sample, kv head) to finish merges the partials (ticket in the workspace, see above) — one launch.
  * rope_cs = this step's fp32 (cos, sin) table [B][head_dim/2][2] from padt_rope_table; slot[b] = append index (keys
  * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace.  HF:557-599, 641-689, 665-666. */
 int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,

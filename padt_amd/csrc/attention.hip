@@ -1,10 +1,10 @@
 // Varlen flash attention (prefill-style) and split-KV decode attention for gfx950, bf16 MFMA 16x16x32, fp32 softmax.
 //
-// attn_varlen_kernel<D, CAUSAL>: one block (4 waves) = 64 query rows of one (segment, head); K/V tiles of 64 keys are
-//   staged in LDS — K row-major (padded rows, conflict-free ds_read_b128), V TRANSPOSED (MFMA wants both operands
-//   contiguous along the contraction index, which for P·V is the key index).  Online softmax lives in the MFMA C layout
-//   (lane owns 4 rows x 1 column per 16x16 block → row reductions are 4 xor-shuffles inside 16-lane groups); P goes
-//   through a wave-private LDS strip to become an A fragment.  Never materialises S.
+// attn_varlen_kernel<D, CAUSAL, QR>: one block (4 waves) = 64*QR query rows of one (segment, head); K/V tiles of 64
+//   keys are staged in LDS (next tile prefetched into registers) — K row-major (padded rows, conflict-free
+//   ds_read_b128), V TRANSPOSED (MFMA wants both operands contiguous along the contraction index, which for P·V is the
+//   key index).  The whole tile is computed transposed (S^T = K Q^T, O^T = V^T P^T): a lane owns one query column, so
+//   the online softmax is in-lane and P feeds the second MFMA straight from registers.  Never materialises S.
 //   Replaces flash_attn_varlen_func at: HF ViT attention (28 window layers: 36 segments/img of 64/48/36 tokens; 4 full
 //   layers: one 2116-token segment/img), LLM prefill (causal, GQA 16:2, d=128) and PaDTDecoderFlashAttention2.forward
 //   (padt_decoder.py:55: query↔query, query→image, image→query; d=80).
@@ -12,6 +12,7 @@
 //   read straight from the row-major K cache, V from the TRANSPOSED V cache (both 16-byte fragment loads, no LDS
 //   staging: nothing is shared between waves); partial (m, l, O) per split are merged by decode_combine_kernel.
 #include "common.h"
+#include <cstdlib>
 
 struct AttnArgs {
     const bf16_t* q; long ldq;      // token stride (elements); head h at +h*D
@@ -24,163 +25,216 @@ struct AttnArgs {
 };
 
 template <int D> struct AttnCfg {
-    static constexpr int KQ = (D + 31) / 32;          // k-steps for QK^T
-    static constexpr int NB = D / 16;                 // 16-wide d blocks for PV
+    static constexpr int KQ = (D + 31) / 32;          // k-steps for K Q^T
+    static constexpr int NB = D / 16;                 // 16-wide d blocks for V^T P^T
     static constexpr int KROW = D + 8;                // padded K row (elements)
-    static constexpr int VROW = 64 + 8;               // padded V^T / P row (elements)
+    static constexpr int VROW = 64 + 4;               // padded V^T row (elements): 136 B → 8-byte reads spread over banks
+    static constexpr int CPR = D / 8;                 // 16-byte chunks per K/V row
+    static constexpr int NK = (64 * CPR + 255) / 256; // K chunks per thread per tile
+    static constexpr int NV = (32 * CPR + 255) / 256; // V (key-pair, chunk) items per thread per tile
     static constexpr int K_BYTES = 64 * KROW * 2;
     static constexpr int V_BYTES = D * VROW * 2;
-    static constexpr int P_BYTES = 4 * 16 * VROW * 2;
-    static constexpr int LDS = K_BYTES + V_BYTES + P_BYTES;
+    static constexpr int LDS = K_BYTES + V_BYTES;
 };
 
-template <int D, bool CAUSAL>
+// Everything is computed TRANSPOSED so that a lane owns ONE query column: S^T = K Q^T puts the 16 keys of a block on the
+// MFMA rows (lane: keys fq*4..+3, query frow) → the row max / row sum over keys are in-lane (plus two cross-group
+// shuffles for the max; the sum is reduced once at the end), and the 8 probabilities a lane holds per 32 keys ARE a
+// B-operand fragment of O^T = V^T P^T under the key permutation {32ks+4fq+j, 32ks+16+4fq+j} — P never touches LDS; the
+// same permutation is applied to the V^T fragment (two 8-byte LDS reads).  O^T's rescale factor is in-lane as well.
+template <int D, bool CAUSAL, int QR>
 __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     using C = AttnCfg<D>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + C::K_BYTES);
-    bf16_t* Ps = reinterpret_cast<bf16_t*>(smem + C::K_BYTES + C::V_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int seg = blockIdx.z, h = blockIdx.y, tile = blockIdx.x;
     const int q_beg = p.cu_q[seg], Lq = p.cu_q[seg + 1] - q_beg;
     const int k_beg = p.cu_k[seg], Lk = p.cu_k[seg + 1] - k_beg;
-    if (tile * 64 >= Lq) return;
+    constexpr int TQ = 64 * QR;                                   // query rows per block
+    if (tile * TQ >= Lq) return;
     const int hk = h / p.group;
     const int shift = Lk - Lq;                                    // causal: key j visible to query i iff j <= i + shift
+    const int wq0 = tile * TQ + wave * 16 * QR;                   // this wave's first query row
 
-    // ---- Q fragments (A operand): row = this wave's 16 query rows
-    const int qrow = tile * 64 + wave * 16 + frow;                // row inside the segment
-    bf16x8 qf[C::KQ];
+    // ---- Q fragments (B operand): column = query row
+    bf16x8 qf[QR][C::KQ];
 #pragma unroll
-    for (int kk = 0; kk < C::KQ; ++kk) {
-        const int d = kk * 32 + fq * 8;
-        qf[kk] = (qrow < Lq && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + h * D + d) : zero_frag();
+    for (int rb = 0; rb < QR; ++rb)
+#pragma unroll
+        for (int kk = 0; kk < C::KQ; ++kk) {
+            const int qrow = wq0 + rb * 16 + frow;
+            const int d = kk * 32 + fq * 8;
+            qf[rb][kk] = (qrow < Lq && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + h * D + d) : zero_frag();
+        }
+
+    f32x4 o[QR][C::NB];
+    float m_run[QR], l_run[QR];
+#pragma unroll
+    for (int rb = 0; rb < QR; ++rb) {
+        m_run[rb] = -INFINITY;
+        l_run[rb] = 0.f;
+#pragma unroll
+        for (int i = 0; i < C::NB; ++i) o[rb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
-
-    f32x4 o[C::NB];
-#pragma unroll
-    for (int i = 0; i < C::NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
-    float m_run[4], l_run[4];
-#pragma unroll
-    for (int r = 0; r < 4; ++r) { m_run[r] = -INFINITY; l_run[r] = 0.f; }
 
     int nkt = (Lk + 63) / 64;
     if (CAUSAL) {
-        const int last = tile * 64 + 63 + shift;                  // last visible key for this tile
+        const int last = tile * TQ + TQ - 1 + shift;              // last visible key for this block
         int lim = last < 0 ? 0 : (last / 64 + 1);
         nkt = lim < nkt ? lim : nkt;
     }
-    bf16_t* Pw = Ps + wave * 16 * C::VROW;
-    constexpr int CPR = D / 8;                                    // 16-byte chunks per K/V row
+
+    // K/V tile kt+1 is fetched into registers while tile kt is multiplied
+    u32x4 kreg[C::NK], vreg[C::NV][2];
+    auto fetch = [&](int kt) {
+#pragma unroll
+        for (int it = 0; it < C::NK; ++it) {
+            const int idx = it * 256 + tid;
+            const int row = idx / C::CPR, c = idx % C::CPR;
+            const int key = kt * 64 + row;
+            const bool ok = (idx < 64 * C::CPR) && (key < Lk);
+            kreg[it] = ok ? *reinterpret_cast<const u32x4*>(p.k + (long)(k_beg + key) * p.ldk + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
+        }
+#pragma unroll
+        for (int it = 0; it < C::NV; ++it) {
+            const int idx = it * 256 + tid;
+            const int kp = idx / C::CPR, c = idx % C::CPR;
+#pragma unroll
+            for (int e = 0; e < 2; ++e) {
+                const int key = kt * 64 + kp * 2 + e;
+                const bool ok = (idx < 32 * C::CPR) && (key < Lk);
+                vreg[it][e] = ok ? *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
+            }
+        }
+    };
+    if (nkt > 0) fetch(0);
 
     for (int kt = 0; kt < nkt; ++kt) {
         __syncthreads();                                          // previous tile fully consumed
-        for (int idx = tid; idx < 64 * CPR; idx += 256) {
-            const int row = idx / CPR, c = idx % CPR;
-            const int key = kt * 64 + row;
-            u32x4 kv = {0u, 0u, 0u, 0u}, vv = {0u, 0u, 0u, 0u};
-            if (key < Lk) {
-                kv = *reinterpret_cast<const u32x4*>(p.k + (long)(k_beg + key) * p.ldk + hk * D + c * 8);
-                vv = *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8);
-            }
-            *reinterpret_cast<u32x4*>(Ks + row * C::KROW + c * 8) = kv;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                Vt[(c * 8 + 2 * j) * C::VROW + row] = (bf16_t)(vv[j] & 0xffffu);
-                Vt[(c * 8 + 2 * j + 1) * C::VROW + row] = (bf16_t)(vv[j] >> 16);
+        for (int it = 0; it < C::NK; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < 64 * C::CPR) *reinterpret_cast<u32x4*>(Ks + (idx / C::CPR) * C::KROW + (idx % C::CPR) * 8) = kreg[it];
+        }
+#pragma unroll
+        for (int it = 0; it < C::NV; ++it) {
+            const int idx = it * 256 + tid;
+            if (idx < 32 * C::CPR) {
+                const int kp = idx / C::CPR, c = idx % C::CPR;
+                unsigned* dst = reinterpret_cast<unsigned*>(Vt + (c * 8) * C::VROW + kp * 2);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {                     // V^T[d][key pair]: two keys of one d per 4-byte write
+                    const unsigned a = vreg[it][0][j], b = vreg[it][1][j];
+                    dst[(2 * j) * (C::VROW / 2)] = (a & 0xffffu) | (b << 16);
+                    dst[(2 * j + 1) * (C::VROW / 2)] = (a >> 16) | (b & 0xffff0000u);
+                }
             }
         }
         __syncthreads();
+        if (kt + 1 < nkt) fetch(kt + 1);
+        if (CAUSAL && kt * 64 > wq0 + 16 * QR - 1 + shift) continue;   // tile entirely above this wave's diagonal
 
-        // ---- S = Q K^T  (16 x 64 per wave)
-        f32x4 s[4];
+        // ---- S^T = K Q^T: lane holds S[query = frow][key = kt*64 + kb*16 + fq*4 + r]
+        f32x4 s[QR][4];
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb) {
-            s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int rb = 0; rb < QR; ++rb) s[rb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int kk = 0; kk < C::KQ; ++kk) {
                 const int d = kk * 32 + fq * 8;
-                bf16x8 kf = (d < D) ? ld_frag(Ks + (kb * 16 + frow) * C::KROW + d) : zero_frag();
-                s[kb] = mfma16(qf[kk], kf, s[kb]);
+                const bf16x8 kf = (d < D) ? ld_frag(Ks + (kb * 16 + frow) * C::KROW + d) : zero_frag();
+#pragma unroll
+                for (int rb = 0; rb < QR; ++rb) s[rb][kb] = mfma16(kf, qf[rb][kk], s[rb][kb]);
             }
         }
-        // lane holds S[row = fq*4 + r][key = kt*64 + kb*16 + frow]
-        float mloc[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        const bool edge = (kt * 64 + 64 > Lk) || (CAUSAL && kt * 64 + 63 > wq0 + shift);
+        if (edge) {
 #pragma unroll
-        for (int kb = 0; kb < 4; ++kb) {
-            const int key = kt * 64 + kb * 16 + frow;
+            for (int rb = 0; rb < QR; ++rb) {
+                const int qi = wq0 + rb * 16 + frow;
 #pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                float x = s[kb][r] * p.scale_log2;
-                const int qi = tile * 64 + wave * 16 + fq * 4 + r;
-                bool ok = key < Lk;
-                if (CAUSAL) ok = ok && (key <= qi + shift);
-                x = ok ? x : -INFINITY;
-                s[kb][r] = x;
-                mloc[r] = fmaxf(mloc[r], x);
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const int key = kt * 64 + kb * 16 + fq * 4 + r;
+                        bool ok = key < Lk;
+                        if (CAUSAL) ok = ok && (key <= qi + shift);
+                        s[rb][kb][r] = ok ? s[rb][kb][r] : -INFINITY;
+                    }
             }
         }
-        float alpha[4], msafe[4];
+        bf16x8 pf[QR][2];
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float m = mloc[r];
-            m = fmaxf(m, __shfl_xor(m, 1, 64));
-            m = fmaxf(m, __shfl_xor(m, 2, 64));
-            m = fmaxf(m, __shfl_xor(m, 4, 64));
-            m = fmaxf(m, __shfl_xor(m, 8, 64));
-            const float mnew = fmaxf(m_run[r], m);
-            msafe[r] = (mnew == -INFINITY) ? 0.f : mnew;
-            alpha[r] = exp2f(m_run[r] - msafe[r]);                 // m_run = -inf → 0
-            m_run[r] = mnew;
+        for (int rb = 0; rb < QR; ++rb) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) m = fmaxf(m, s[rb][kb][r]);
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));
+            const float mnew = fmaxf(m_run[rb], m);
+            const float msafe = (mnew == -INFINITY) ? 0.f : mnew;
+            const float alpha = __builtin_amdgcn_exp2f((m_run[rb] - msafe) * p.scale_log2);    // m_run = -inf → 0
+            m_run[rb] = mnew;
+            const float mc = -msafe * p.scale_log2;
+            float lsum = 0.f;
+            float pv[16];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float e = __builtin_amdgcn_exp2f(fmaf(s[rb][kb][r], p.scale_log2, mc));   // masked → 0
+                    pv[kb * 4 + r] = e;
+                    lsum += e;
+                }
+            l_run[rb] = l_run[rb] * alpha + lsum;                  // per-lane partial (this lane's 16 keys per tile)
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks)
+                pf[rb][ks] = __builtin_bit_cast(bf16x8, pack8(pv + ks * 8));
+#pragma unroll
+            for (int i = 0; i < C::NB; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[rb][i][r] *= alpha;
         }
-        float lsum[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-        for (int kb = 0; kb < 4; ++kb)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) {
-                const float pv = exp2f(s[kb][r] - msafe[r]);       // masked → exp2(-inf) = 0
-                lsum[r] += pv;
-                Pw[(fq * 4 + r) * C::VROW + kb * 16 + frow] = f2bf(pv);
-            }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            float t = lsum[r];
-            t += __shfl_xor(t, 1, 64);
-            t += __shfl_xor(t, 2, 64);
-            t += __shfl_xor(t, 4, 64);
-            t += __shfl_xor(t, 8, 64);
-            l_run[r] = l_run[r] * alpha[r] + t;
-        }
-#pragma unroll
-        for (int i = 0; i < C::NB; ++i)
-#pragma unroll
-            for (int r = 0; r < 4; ++r) o[i][r] *= alpha[r];
-        __syncthreads();                                          // P strip visible (same wave, but keep it simple)
 
-        // ---- O += P V   (A = P[16 x 64], B = V^T rows)
+        // ---- O^T += V^T P^T   (A = V^T rows d, B = P; contraction slots j<4: key 32ks+4fq+j, j>=4: key 32ks+16+4fq+j-4)
 #pragma unroll
-        for (int ks = 0; ks < 2; ++ks) {
-            const bf16x8 pf = ld_frag(Pw + frow * C::VROW + ks * 32 + fq * 8);
+        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < C::NB; ++i) {
-                const bf16x8 vf = ld_frag(Vt + (i * 16 + frow) * C::VROW + ks * 32 + fq * 8);
-                o[i] = mfma16(pf, vf, o[i]);
+                const bf16_t* vp = Vt + (i * 16 + frow) * C::VROW + ks * 32 + fq * 4;
+                const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
+                const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
+                const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
+                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+#pragma unroll
+                for (int rb = 0; rb < QR; ++rb) o[rb][i] = mfma16(vf, pf[rb][ks], o[rb][i]);
             }
-        }
     }
 
-    // ---- normalise and store: lane holds O[row = fq*4 + r][d = i*16 + frow]
+    // ---- normalise and store: lane holds O[query = frow][d = i*16 + fq*4 + r]
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int qi = tile * 64 + wave * 16 + fq * 4 + r;
+    for (int rb = 0; rb < QR; ++rb) {
+        float l = l_run[rb];
+        l += __shfl_xor(l, 16, 64);
+        l += __shfl_xor(l, 32, 64);
+        const int qi = wq0 + rb * 16 + frow;
         if (qi >= Lq) continue;
-        const float inv = l_run[r] > 0.f ? 1.0f / l_run[r] : 0.f;
-        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + h * D;
+        const float inv = l > 0.f ? 1.0f / l : 0.f;
+        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + h * D + fq * 4;
 #pragma unroll
-        for (int i = 0; i < C::NB; ++i) dst[i * 16 + frow] = f2bf(o[i][r] * inv);
+        for (int i = 0; i < C::NB; ++i) {
+            u32x2 w;
+            w[0] = pack2bf(o[rb][i][0] * inv, o[rb][i][1] * inv);
+            w[1] = pack2bf(o[rb][i][2] * inv, o[rb][i][3] * inv);
+            *reinterpret_cast<u32x2*>(dst + i * 16) = w;
+        }
     }
 }
 
@@ -330,7 +384,48 @@ struct DecodeRopeArgs {
     float* part_o; float* part_ml;
     int B, Hq, Hkv, S_max, nsplit;
     float scale_log2;
+    int* ticket;                      // [B][Hkv], zero between launches (the last block of a (b, g) resets it)
+    bf16_t* out;                      // [B][Hq*D]
 };
+
+// The LAST of a (sample, kv head)'s split blocks to finish merges the partials (flash-decoding reduction) — replaces a
+// second launch.  Partials travel through agent-scope atomics (common.h: st_agent / handoff_arrive / ld_agent).
+template <int D>
+PADT_DEV void decode_finish(const DecodeRopeArgs& p, int b, int g, int lane) {
+    if (!handoff_arrive(&p.ticket[b * p.Hkv + g], p.nsplit, lane)) return;
+    const int group = p.Hq / p.Hkv;
+    const int hrow = lane >> 2;                                   // 16 head rows x 4 lanes, D/4 values per lane
+    if (hrow >= group) return;
+    constexpr int PER = D / 4;
+    const int d0 = (lane & 3) * PER;
+    const long base0 = (((long)b * p.Hkv + g) * p.nsplit) * 16 + hrow;
+    float M = -INFINITY;
+    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, ld_agent(&p.part_ml[(base0 + s * 16) * 2]));
+    float L = 0.f, acc[PER];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
+    for (int s = 0; s < p.nsplit; ++s) {
+        const long base = base0 + s * 16;
+        const float m = ld_agent(&p.part_ml[base * 2]);
+        if (m == -INFINITY) continue;
+        const float w = exp2f(m - M);
+        L += w * ld_agent(&p.part_ml[base * 2 + 1]);
+        const float* po = p.part_o + base * D + d0;
+        float v[PER];
+#pragma unroll
+        for (int i = 0; i < PER; ++i) v[i] = ld_agent(po + i);
+#pragma unroll
+        for (int i = 0; i < PER; ++i) acc[i] += w * v[i];
+    }
+    bf16_t* dst = p.out + (long)b * p.Hq * D + (long)(g * group + hrow) * D + d0;
+#pragma unroll
+    for (int i = 0; i < PER / 8; ++i) {
+        float f[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) f[r] = L > 0.f ? acc[i * 8 + r] / L : 0.f;
+        *reinterpret_cast<u32x4*>(dst + i * 8) = pack8(f);
+    }
+}
 
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) {
@@ -349,7 +444,8 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     const int k0 = split * 64;
     const long pbase = (((long)b * p.Hkv + g) * p.nsplit + split) * 16;
     if (k0 >= len) {
-        if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
+        if (lane < 16) { st_agent(&p.part_ml[(pbase + lane) * 2], -INFINITY); st_agent(&p.part_ml[(pbase + lane) * 2 + 1], 0.f); }
+        decode_finish<D>(p, b, g, lane);
         return;
     }
     const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
@@ -510,23 +606,28 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         const int hrow = fq * 4 + r;
         float* po = p.part_o + (pbase + hrow) * D;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) po[i * 16 + frow] = o[i][r];
-        if (frow == 0) { p.part_ml[(pbase + hrow) * 2] = mrow[r]; p.part_ml[(pbase + hrow) * 2 + 1] = lrow[r]; }
+        for (int i = 0; i < NB; ++i) st_agent(&po[i * 16 + frow], o[i][r]);
+        if (frow == 0) { st_agent(&p.part_ml[(pbase + hrow) * 2], mrow[r]); st_agent(&p.part_ml[(pbase + hrow) * 2 + 1], lrow[r]); }
     }
+    decode_finish<D>(p, b, g, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" void padt_set_error(const char* msg);
 
+template <int D, bool CAUSAL, int QR>
+static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
+    const int tiles = (max_seqlen_q + 64 * QR - 1) / (64 * QR);
+    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+}
+
+// long segments, d <= 80: 32 query rows per wave (each K / V^T fragment read from LDS feeds two MFMAs); at d = 128 the
+// second row block costs the second resident block per CU and loses (measured: prefill 36 vs 43 us)
 template <int D, bool CAUSAL>
-static void launch_attn(const AttnArgs& a, int max_q_tiles, int H, int nseg, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_varlen_kernel<D, CAUSAL>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, AttnCfg<D>::LDS);
-        done = true;
-    }
-    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL>), dim3(max_q_tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+static void launch_attn(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
+    static const int force = getenv("PADT_ATTN_QR") ? atoi(getenv("PADT_ATTN_QR")) : 0;
+    if (force ? force == 2 : (max_seqlen_q >= 256 && D <= 80)) launch_attn_qr<D, CAUSAL, 2>(a, max_seqlen_q, H, nseg, s);
+    else launch_attn_qr<D, CAUSAL, 1>(a, max_seqlen_q, H, nseg, s);
 }
 
 extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
@@ -539,12 +640,11 @@ extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const voi
     }
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, cu_q, cu_k,
                n_heads / n_kv_heads, scale * 1.4426950408889634f};
-    const int tiles = (max_seqlen_q + 63) / 64;
     hipStream_t s = (hipStream_t)stream;
-#define PADT_ATTN_CASE(DD)                                                  \
-    case DD:                                                                \
-        if (causal) launch_attn<DD, true>(a, tiles, n_heads, nseg, s);      \
-        else launch_attn<DD, false>(a, tiles, n_heads, nseg, s);            \
+#define PADT_ATTN_CASE(DD)                                                         \
+    case DD:                                                                       \
+        if (causal) launch_attn<DD, true>(a, max_seqlen_q, n_heads, nseg, s);      \
+        else launch_attn<DD, false>(a, max_seqlen_q, n_heads, nseg, s);            \
         break;
     switch (head_dim) {
         PADT_ATTN_CASE(32)
@@ -559,9 +659,12 @@ extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const voi
     return 0;
 }
 
+// workspace = [tickets: batch*n_kv_heads ints, padded to 256 B][partial O][partial (m, l)]
+static long decode_ticket_bytes(int batch, int n_kv_heads) { return (((long)batch * n_kv_heads * 4 + 255) / 256) * 256; }
+
 extern "C" long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max) {
     const long nsplit = (s_max + 63) / 64;
-    return (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
+    return decode_ticket_bytes(batch, n_kv_heads) + (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
 }
 
 extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens,
@@ -576,7 +679,7 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
     a.q = (const bf16_t*)q; a.kc = (const bf16_t*)k_cache; a.vtc = (const bf16_t*)vt_cache; a.lens = lens;
     a.out = (bf16_t*)out; a.Hq = n_heads; a.Hkv = n_kv_heads; a.S_max = s_max;
     a.nsplit = (max_len + 63) / 64;
-    a.part_o = (float*)workspace;
+    a.part_o = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + decode_ticket_bytes(batch, n_kv_heads));
     a.part_ml = a.part_o + (long)batch * n_kv_heads * a.nsplit * 16 * head_dim;
     a.scale_log2 = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
@@ -605,22 +708,15 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
         return -1;
     }
     const int nsplit = (max_len + 63) / 64;
+    float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + decode_ticket_bytes(batch, n_kv_heads));
     DecodeRopeArgs a{(const bf16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (bf16_t*)k_cache, (bf16_t*)vt_cache,
-                     (float*)workspace, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f};
+                     parts, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f,
+                     reinterpret_cast<int*>(workspace), (bf16_t*)out};
     a.part_ml = a.part_o + (long)batch * n_kv_heads * nsplit * 16 * head_dim;
-    DecodeArgs c;                                              // combine reads the same partial layout
-    c.q = nullptr; c.kc = nullptr; c.vtc = nullptr; c.lens = nullptr; c.part_o = a.part_o; c.part_ml = a.part_ml;
-    c.out = (bf16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
-        case 32:
-            hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
-            hipLaunchKernelGGL(decode_combine_kernel<32>, dim3(n_heads, batch), dim3(32), 0, s, c);
-            break;
-        case 128:
-            hipLaunchKernelGGL(decode_attn_rope_kernel<128>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
-            hipLaunchKernelGGL(decode_combine_kernel<128>, dim3(n_heads, batch), dim3(128), 0, s, c);
-            break;
+        case 32: hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a); break;
+        case 128: hipLaunchKernelGGL(decode_attn_rope_kernel<128>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a); break;
         default: padt_set_error("padt_decode_attn_rope: head_dim must be 32 or 128"); return -1;
     }
     hipError_t e = hipGetLastError();

@@ -31,6 +31,23 @@ PADT_DEV bf16x8 zero_frag() {
 
 PADT_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
+// Cross-block hand-off inside one kernel (split-K / split-KV "last block reduces"): the 8 XCDs have separate L2s, so
+// partials are written and read with agent-scope relaxed atomics (sc1: served at the device coherence point) instead
+// of agent-scope fences, which write back / invalidate whole caches.  Protocol: st_agent(...)*, handoff_arrive(),
+// and in the block that drew the last ticket: ld_agent(...)*.
+PADT_DEV void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+PADT_DEV float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// one-wave blocks (or wave 0 only): returns true in the block that arrives last; the ticket is left at zero
+PADT_DEV bool handoff_arrive(int* ticket, int total, int lane) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's partial stores are acknowledged
+    int old = 0;
+    if (lane == 0) old = __hip_atomic_fetch_add(ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    old = __builtin_amdgcn_readfirstlane(old);
+    if (old != total - 1) return false;
+    if (lane == 0) __hip_atomic_store(ticket, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    return true;
+}
+
 PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 PADT_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 

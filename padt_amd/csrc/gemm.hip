@@ -28,6 +28,9 @@ struct GemmArgs {
     void* C; long ldc;           // bf16 or f32
     const bf16_t* R; long ldr;   // residual (EPI_RESID)
     int M, N, K;
+    float* ws = nullptr;         // split-K (skinny kernel, gridDim.y > 1): partial accumulators [nb][split][frags][64][4]
+    int* ticket = nullptr;       //          and one completion ticket per n-block (zero between launches)
+    int split = 1;
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];   // 256 B of zeros (K-tail source)
@@ -292,7 +295,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     }
 
     // wave w owns groups w, w+NW, ... of U CONSECUTIVE K-steps: one round = U*64 B contiguous per weight row
-    for (int grp = wave; grp * U < nks; grp += NW) {
+    // split-K: gridDim.y blocks share an n-block, block y takes groups y*NW + wave, stepping by NW*gridDim.y
+    for (int grp = blockIdx.y * NW + wave; grp * U < nks; grp += NW * gridDim.y) {
         bf16x8 wf[U][NT], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
@@ -348,6 +352,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             for (int j = 0; j < MT; ++j)
 #pragma unroll
                 for (int w = 0; w < NW - 1; ++w) acc[i][j] += *reinterpret_cast<f32x4*>(&red[w][i * MT + j][lane][0]);
+        if (!NORM && gridDim.y > 1) {
+            // the last of the n-block's split blocks to arrive sums the partials and runs the epilogue
+            const int S = gridDim.y;
+            float* mine = p.ws + (((long)(blockIdx.x * S + blockIdx.y) * (NT * MT)) * 64 + lane) * 4;
+#pragma unroll
+            for (int i = 0; i < NT * MT; ++i)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) st_agent(mine + i * 256 + r, acc[i / MT][i % MT][r]);
+            if (!handoff_arrive(&p.ticket[blockIdx.x], S, lane)) return;
+            for (int y = 0; y < S; ++y) {
+                if (y == (int)blockIdx.y) continue;
+                const float* other = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
+#pragma unroll
+                for (int i = 0; i < NT * MT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) acc[i / MT][i % MT][r] += ld_agent(other + i * 256 + r);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int m = j * 16 + frow;
@@ -399,7 +421,8 @@ template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false>
 static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED>), dim3(nb), dim3(NW * 64), 0, s, a, eps);
+    const int split = (a.ws && !NORM) ? a.split : 1;
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED>), dim3(nb, split), dim3(NW * 64), 0, s, a, eps);
 }
 
 // waves per block: enough waves chip-wide (>= ~2048) to keep HBM busy even when N/16 < #CUs
@@ -407,7 +430,7 @@ template <int MT, int EPI, bool F32, bool NORM, bool PACKED = false>
 static void launch_skinny(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
-    const int ksteps = (a.K + 31) / 32;                    // each wave keeps U = 8 K-steps in flight
+    const int ksteps = (a.K + 31) / 32 / (a.ws ? a.split : 1);   // per block; each wave keeps U = 8 K-steps in flight
     static const int force_nw = getenv("PADT_SKINNY_NW") ? atoi(getenv("PADT_SKINNY_NW")) : 0;   // tuning knob
     if constexpr (MT == 1 && NT == 1) {
         if (force_nw == 16 || (!force_nw && nb <= 256 && ksteps >= 128)) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED>(a, eps, s); return; }
@@ -501,9 +524,20 @@ static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
     else launch_skinny<4, EPI, false, NORM, true>(a, eps, s);
 }
 
+static long splitk_ticket_bytes(long N) { return (((N + 15) / 16 * 4 + 255) / 256) * 256; }
+
+extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
+    return splitk_ticket_bytes(N) + (N + 15) / 16 * (long)split_k * 4 * 64 * 16;   // up to 4 row blocks of fp32 fragments
+}
+
 extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
-                                     long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps) {
+                                     long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
+                                     int split_k, void* workspace) {
     if (M <= 0 || N <= 0) return 0;
+    if (split_k > 1 && (workspace == nullptr || split_k > 8 || norm_eps >= 0.f || epilogue == EPI_SWIGLU)) {
+        padt_set_error("padt_gemm_packed_bf16: split_k in [2, 8] needs a workspace, no fused norm and epilogue 0 or 2");
+        return -1;
+    }
     if (M > 64 || K <= 0 || (K & 7) || K > Kp || (Kp & 31) || (lda & 7) || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) {
         padt_set_error("padt_gemm_packed_bf16: M <= 64, K % 8 == 0, K <= Kp, Kp % 32 == 0, 16-byte aligned A/Wp required");
         return -1;
@@ -515,6 +549,11 @@ extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, cons
         return -1;
     }
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)Wp, Kp, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr, (int)M, (int)N, (int)K};
+    if (split_k > 1) {
+        a.ticket = reinterpret_cast<int*>(workspace);
+        a.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + splitk_ticket_bytes(N));
+        a.split = split_k;
+    }
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false>(a, 0.f, s); }
     else if (epilogue == EPI_RESID) dispatch_packed<EPI_RESID, false>(a, 0.f, s);

@@ -13,6 +13,8 @@ libpadt_hip.so.  Differences from the reference's control flow that do not chang
 from dataclasses import dataclass
 from typing import List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import ops
@@ -139,7 +141,11 @@ class DecodeSession:
         self.nblk = ops.vrt_head_nblk(cfg.vocab_size, np_max)
         self.part_val = z(self.nblk * B, dt=torch.float32)
         self.part_idx = z(self.nblk * B, dt=I32)
-        self.attn_ws = torch.empty(ops.decode_attn_workspace(B, Hkv, hd, s_max), dtype=torch.uint8, device=device)
+        self.attn_ws = ops.new_decode_workspace(B, Hkv, hd, s_max, device)
+        # down_proj has only D/16 column blocks (128 for D = 2048): split K over 2 blocks each to occupy every CU
+        self.down_split = int(os.environ.get("PADT_DOWN_SPLIT", 2))
+        self.o_split = int(os.environ.get("PADT_O_SPLIT", 1))
+        self.splitk_ws = ops.new_splitk_workspace(cfg.hidden_size, max(self.down_split, self.o_split, 1), device)
         half = hd // 2
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(device)
         assert self.inv_freq.numel() == half
@@ -170,9 +176,11 @@ class DecodeSession:
             ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
                                  hd, self.s_max, self.s_max)
-            ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+            ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                            split_k=self.o_split, workspace=self.splitk_ws)
             ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps)
-            ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x)
+            ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                            split_k=self.down_split, workspace=self.splitk_ws)
         ops.rmsnorm(self.x, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
         self.head_and_select(self.hn, advance=True)
 

@@ -70,7 +70,12 @@ def pack_weight(w):
     return w.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np, Kp)
 
 
-def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None):
+def new_splitk_workspace(n, split_k, device):
+    """Zero-initialised split-K workspace (ticket header must start at zero), one per concurrently decoding stream."""
+    return torch.zeros(_lib.load().padt_gemm_splitk_workspace(n, split_k), dtype=torch.uint8, device=device)
+
+
+def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None):
     """Decode-step projection over a pack_weight() image (rows <= 64): out = epi(rstd?(a) * (a @ w^T) + bias)."""
     lib = _lib.load()
     _chk_bf16(a, wp, bias, residual)
@@ -80,7 +85,8 @@ def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None,
         out = torch.empty((M, n_out), device=a.device, dtype=BF16)
     _lib.check(lib.padt_gemm_packed_bf16(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(bias), _p(out), out.stride(0),
                                          _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
-                                         -1.0 if norm_eps is None else float(norm_eps)), "padt_gemm_packed_bf16")
+                                         -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace)),
+               "padt_gemm_packed_bf16")
     return out
 
 
@@ -99,6 +105,11 @@ def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, hea
 
 def decode_attn_workspace(batch, n_kv_heads, head_dim, s_max):
     return _lib.load().padt_decode_attn_workspace(batch, n_kv_heads, head_dim, s_max)
+
+
+def new_decode_workspace(batch, n_kv_heads, head_dim, s_max, device):
+    """Zero-initialised (the ticket header must start at zero), one per stream that decodes concurrently."""
+    return torch.zeros(decode_attn_workspace(batch, n_kv_heads, head_dim, s_max), dtype=torch.uint8, device=device)
 
 
 def decode_attn(q, k_cache, vt_cache, lens, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len, scale=None):

@@ -46,28 +46,41 @@ class PipelinedRunner:
         self.decode_streams = [torch.cuda.Stream(device=model.device, priority=-1) for _ in range(depth)]
         self.pending = []
         self.count = 0
+        self.trace = None          # set to [] to collect (batch, tag, event) marks for a stream timeline (bench.py --timeline)
+
+    def _mark(self, batch, tag, stream):
+        if self.trace is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream)
+            self.trace.append((batch, tag, ev))
 
     def submit(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, schedule=None,
                need_thinking_mask=None, sync_every=None):
         lane = self.count % self.depth
+        bid = self.count
         self.count += 1
         self.prefill_stream.wait_stream(torch.cuda.current_stream())   # inputs were produced on the caller's stream
         ids = self.processor.assign_to_global_vrt_id(input_ids, image_grid_thw)
+        self._mark(bid, "prefill_begin", self.prefill_stream)
         with torch.cuda.stream(self.prefill_stream):
             ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
                                              schedule, sync_every or max_new_tokens, True, lane, self.decode_streams[lane])
-        self.pending.append((lane, ctx, input_ids.shape, image_grid_thw, need_thinking_mask))
+        self._mark(bid, "prefill_end", self.prefill_stream)
+        self._mark(bid, "decode_end", self.decode_streams[lane])
+        self.pending.append((lane, ctx, input_ids.shape, image_grid_thw, need_thinking_mask, bid))
         return self._finish_oldest() if len(self.pending) >= self.depth else None
 
     def _finish_oldest(self):
-        lane, ctx, shape, grid, mask = self.pending.pop(0)
+        lane, ctx, shape, grid, mask, bid = self.pending.pop(0)
         B, L = shape
         with torch.cuda.stream(self.decode_streams[lane]):
             out = self.model.generate_collect(ctx)
             seq_local = self.processor.assign_to_local_vrt_id(out["sequences"].cpu(), grid.cpu())
             m = mask if mask is not None else torch.Tensor([False] * B)
             completions, feats, labels, vrts, _ = parseVRTintoCompletion(self.processor, seq_local[:, L:], out["hidden_states"], m)
+            self._mark(bid, "vl_begin", self.decode_streams[lane])
             decoded = self.model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+            self._mark(bid, "vl_end", self.decode_streams[lane])
         self.decode_streams[lane].synchronize()
         return decoded, completions, labels, vrts
 

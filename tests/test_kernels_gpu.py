@@ -113,6 +113,13 @@ def test_gemm_packed_weights(ops, M, N, K):
     close_bf16(ops.gemm_packed(x, wp, N, b, norm_eps=1e-6), lin * rstd + b.float(), f"packed norm+bias {M}x{N}x{K}")
     out = r.clone()
     ops.gemm_packed(x, wp, N, out=out, epilogue=ops.EPI_RESID, residual=out)
+    for split in (2, 4):                                  # split-K: partials merged by the last block, ticket self-resets
+        ws = ops.new_splitk_workspace(N, split, "cuda")
+        for _ in range(2):
+            o2 = r.clone()
+            ops.gemm_packed(x, wp, N, out=o2, epilogue=ops.EPI_RESID, residual=o2, split_k=split, workspace=ws)
+            close_bf16(o2, lin + r.float(), f"packed split-{split} resid {M}x{N}x{K}")
+        close_bf16(ops.gemm_packed(x, wp, N, b, split_k=split, workspace=ws), lin + b.float(), f"packed split-{split} {M}x{N}x{K}")
     close_bf16(out, lin + r.float(), f"packed resid {M}x{N}x{K}")
     if N % 32 == 0:
         wi = ops.pack_weight(interleave_gate_up(w[: N // 2], w[N // 2:]))
@@ -207,7 +214,7 @@ def test_decode_attn(ops, D, Hq, Hkv):
     v = rnd(B, Hkv, S_max, D, seed=32)
     vt = v.transpose(2, 3).contiguous()
     lens_t = torch.tensor(lens, dtype=torch.int32, device="cuda")
-    ws = torch.empty(ops.decode_attn_workspace(B, Hkv, D, S_max), dtype=torch.uint8, device="cuda")
+    ws = ops.new_decode_workspace(B, Hkv, D, S_max, "cuda")
     out = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
     ops.decode_attn(q, kc, vt, lens_t, out, ws, Hq, Hkv, D, S_max, max(lens))
     rep = Hq // Hkv
@@ -235,7 +242,7 @@ def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     kc1, vt1, kc2, vt2 = kc.clone(), vt.clone(), kc.clone(), vt.clone()
     cs = torch.zeros(B, D // 2, 2, device="cuda")
     ops.rope_table(pos, inv, cs, D, sec)
-    ws = torch.empty(ops.decode_attn_workspace(B, Hkv, D, S_max), dtype=torch.uint8, device="cuda")
+    ws = ops.new_decode_workspace(B, Hkv, D, S_max, "cuda")
     out1 = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
     ops.decode_attn_rope(qkv, cs, slot_t, kc1, vt1, out1, ws, Hq, Hkv, D, S_max, S_max)
     q2 = torch.zeros(B, Hq * D, device="cuda", dtype=BF)

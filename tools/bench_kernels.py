@@ -51,6 +51,8 @@ def main():
         ws = [torch.randn(N, K, device="cuda").to(BF) * 0.02 for _ in range(int(os.environ.get('ROT', 6)))]   # rotate weights: defeat L2/MALL reuse
         out = torch.zeros(B, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
         i = [0]
+        split = int(os.environ.get("SPLIT_" + name.upper(), 1))
+        ws_split = ops.new_splitk_workspace(N, max(split, 2), "cuda")
 
         def f():
             w = ws[i[0] % len(ws)]
@@ -61,7 +63,7 @@ def main():
                 else:
                     ops.gemm_rmsnorm(a, w, out=out, epilogue=epi)
             elif epi == 2:
-                ops.gemm_packed(a, w, N, out=out, epilogue=2, residual=out)
+                ops.gemm_packed(a, w, N, out=out, epilogue=2, residual=out, split_k=split, workspace=ws_split)
             else:
                 ops.gemm_packed(a, w, N, out=out, epilogue=epi, norm_eps=1e-6)
         t = timeit(f)
