@@ -30,13 +30,17 @@ HBM_PEAK_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=32)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tnew", type=int, default=28)
     ap.add_argument("--model", default="3b", choices=["3b", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--merge", type=int, default=4, help="consecutive batches of 8 whose decode steps share one session "
+                    "(in-flight batching; 1 = every batch decodes alone)")
+    ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
+    ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
     ap.add_argument("--timeline", action="store_true", help="print a stream timeline of 4 pipelined steps to stderr")
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight on separate HIP streams (1 = no overlap)")
@@ -267,7 +271,8 @@ def main():
         torch.cuda.synchronize()
 
     from padt_amd import pipeline
-    runner = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth) if args.depth > 1 else None
+    runner = (pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge, shared_prefill_stream=not args.lane_streams)
+              if (args.depth > 1 or args.merge > 1) else None)
 
     def gather(decoded):
         if world > 1:
@@ -275,17 +280,18 @@ def main():
                                            device=inp["pix"].device)
             pipeline.all_gather_results(packed)
 
-    def run_steps(k):
+    def run_steps(k, runner=runner):
         """k steps = k batches through the whole path; with depth > 1 consecutive batches overlap on separate streams
         (every batch is complete — results on the host side of vl_decode — before this returns)."""
         last = None
+        if k <= 0:
+            return last
         if runner is None:
             for _ in range(k):
                 last = run_step(model, inp, args, world)
             return last
         for _ in range(k):
-            r = runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
-            if r is not None:
+            for r in runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]):
                 last = r[0]
                 gather(last)
         for r in runner.flush():
@@ -293,12 +299,28 @@ def main():
             gather(last)
         return last
 
+    if runner is not None:
+        run_steps(args.depth * args.merge)      # one-time: every lane allocates its session and captures its decode graph
     run_steps(args.warmup)
     barrier()
     t0 = time.perf_counter()
     decoded = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    # same workload with every batch decoding alone (merge = 1, two batches in flight), for comparison in the same run
+    alt = None
+    if runner is not None and args.merge > 1 and world == 1 and not args.no_alt:
+        r1 = pipeline.PipelinedRunner(model, inp["proc"], depth=2, merge=1)
+        run_steps(3, r1)
+        barrier()
+        k1 = min(args.steps, 12)
+        t1 = time.perf_counter()
+        run_steps(k1, r1)
+        barrier()
+        e1 = time.perf_counter() - t1
+        alt = {"value": round(args.batch * k1 / e1, 3), "unit": "images/s", "steps": k1, "ms_per_step": round(e1 / k1 * 1e3, 3),
+               "note": "decode groups of ONE batch (8 rows per decode step), 2 batches in flight"}
+        del r1
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
@@ -346,12 +368,17 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
             "config": {"workload": "PaDT_Pro_3B REC, batch=%d/GPU 640x640 synthetic (grid 46x46, L=577, T_new=%d, 1 obj x 5 VRT, "
-                                   "mask head on), bf16, random-init 3.85B weights" % (args.batch, args.tnew)
+                                   "mask head on), bf16, random-init 3.85B weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder "
+                                   "per batch, decode steps of %d consecutive batches share one weight pass (in-flight batching, "
+                                   "per-sample results bit-identical to batch-at-a-time)" % (args.batch, args.tnew, args.batch, args.merge)
                        if args.model == "3b" else "small_test_config (plumbing)",
-                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth},
+                       "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth * args.merge,
+                       "decode_groups_in_flight": args.depth, "batches_per_decode_group": args.merge},
             "alg_tflops_e2e": round(value * ALG_TFLOP_PER_IMAGE, 1) if args.model == "3b" else None,
             "mfma_frac_e2e": round(value * ALG_TFLOP_PER_IMAGE / MFMA_BF16_PEAK_TFLOPS / world, 4) if args.model == "3b" else None,
         }
+        if alt is not None:
+            line["unmerged_decode"] = alt
         if not args.no_roofline:
             line["roofline"] = roofline_leg(model, inp, args, cfg)
         if world == 1 and not args.no_cpu_baseline:

@@ -79,7 +79,9 @@ class PromptPlan:
 
 
 def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
-                grid_thw: torch.Tensor, device) -> PromptPlan:
+                grid_thw: torch.Tensor, device, row0: int = 0, proto_row0: int = 0) -> PromptPlan:
+    """``row0`` / ``proto_row0``: first decode-session row and first prototype-table row of this batch when several
+    batches share one session (merged decode, modeling.generate_launch): KV rows and VRT ids are shifted accordingly."""
     ids_cpu = input_ids.detach().cpu()
     B, L = ids_cpu.shape
     am = attention_mask.detach().cpu() if attention_mask is not None else torch.ones_like(ids_cpu)
@@ -94,12 +96,14 @@ def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Option
     pos, nxt = rope_index_packed(cfg, rows, grids)
     lens = [len(r) for r in rows]
     ids = torch.tensor([t for r in rows for t in r], dtype=torch.int64)
+    if proto_row0:
+        ids = torch.where(ids >= cfg.vocab_size, ids + proto_row0, ids)
     is_img = ids == cfg.image_token_id
     img_index = torch.where(is_img, torch.cumsum(is_img.to(torch.int64), 0) - 1, torch.full_like(ids, -1)).to(I32)
     cu = [0]
     for l in lens:
         cu.append(cu[-1] + l)
-    sample = torch.cat([torch.full((l,), b, dtype=I32) for b, l in enumerate(lens)])
+    sample = torch.cat([torch.full((l,), b + row0, dtype=I32) for b, l in enumerate(lens)])
     slot = torch.cat([torch.arange(l, dtype=I32) for l in lens])
     off = [0]
     for n in merged:
@@ -158,6 +162,7 @@ class DecodeSession:
         self.att = z(B, cfg.num_attention_heads * hd)
         self.h = z(B, I)
         self.hn = z(B, D)
+        self.hn_first = z(B, D)          # last prompt token's post-norm hidden state per row (first-token selection)
         self.err = z(1, dt=I32)
         self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
         self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
@@ -227,10 +232,14 @@ class LanguageModel:
         t = ops.gemm(p, W["proto.0.w"])
         return ops.gemm(t, W["proto.1.w"], out=out, epilogue=ops.EPI_RESID, residual=p)
 
-    def session(self, B: int, need_s: int, need_np: int, need_t: int, lane: int = 0) -> DecodeSession:
+    def session(self, B: int, need_s: int, need_np: int, need_t: int, lane: int = 0, grow: bool = True) -> Optional[DecodeSession]:
+        """The lane's session for B rows, (re)allocated when too small; with grow=False returns None instead (a session
+        that already holds other batches' KV rows must not be replaced)."""
         s_max = (need_s + 63) // 64 * 64
         key = (B, lane)
         s = self._sessions.get(key)
+        if not grow:
+            return s if (s is not None and s.s_max >= s_max and s.np_max >= need_np and s.t_max >= need_t) else None
         if s is None or s.s_max < s_max or s.np_max < need_np or s.t_max < need_t:
             s = DecodeSession(self.cfg, self.W, B, max(s_max, s.s_max if s else 0), max(need_np, s.np_max if s else 0),
                               max(need_t, s.t_max if s else 0), self.device)

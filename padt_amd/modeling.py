@@ -151,10 +151,18 @@ class PaDTForConditionalGeneration:
 
     @torch.no_grad()
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=False,
-                        schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None):
+                        schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
-        Returns a context for generate_collect()."""
+        Returns a group context for generate_collect().
+
+        Merged decode (pipeline.PipelinedRunner(merge=n)): ``n_slots`` batches share ONE decode session of n_slots*B
+        rows — each call adds a batch (its ViT + prefill run now, its KV rows / prototypes land in the shared session),
+        pass the returned context back as ``group`` for the next batch; the decode steps of all of them run together
+        once the group is full (or on launch_decode()).  Every sample's math is unchanged (rows are independent in every
+        decode kernel); the weights are streamed once per step for all rows.  Returns None instead of adding when the
+        batch does not fit the group's session (caller closes the group and starts a new one).
+        """
         if do_sample:
             raise NotImplementedError("sampling (padt.py:740-743) is not on the accelerated path; use do_sample=False")
         if pixel_values is None or image_grid_thw is None:
@@ -162,87 +170,133 @@ class PaDTForConditionalGeneration:
                              "padt.py:292 with image_prototypes unbound)")
         cfg, dev = self.config, self.device
         grid = image_grid_thw.detach().cpu().long()
-        plan = plan_prompt(cfg, input_ids, attention_mask, grid, dev)
-        B = plan.B
+        B = input_ids.shape[0]
         T_max = int(max_new_tokens)
+        k = 0 if group is None else len(group["subs"])
+        row0 = k * B
+        proto_row0 = 0 if group is None else group["proto_rows"]
+        plan = plan_prompt(cfg, input_ids, attention_mask, grid, dev, row0=row0, proto_row0=proto_row0)
         n_proto = plan.vrt_off[-1]
-        sess = self.lm.session(B, max(plan.lens) + T_max, n_proto, T_max, lane=lane)
+        need_s = max(plan.lens) + T_max
+        if group is None:
+            sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
+            group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
+                         use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule)
+            # neutral state for every row; the batches overwrite their own rows (unused rows stay finished / empty)
+            st = torch.zeros(T_max + 1, dtype=torch.int32)
+            if schedule is not None:
+                for i, mm in enumerate(schedule[: T_max]):
+                    st[i] = MODE[mm]
+            sess.mode_table[: T_max + 1].copy_(st.to(dev, non_blocking=True))
+            sess.step.zero_()
+            sess.err.zero_()
+            sess.unfinished.zero_()
+            sess.slot.zero_()
+            sess.lens.fill_(1)
+            sess.pos3.zero_()
+            sess.cur_tok.fill_(cfg.pad_token_id)
+            sess.vrt_off.zero_()
+        else:
+            sess = group["sess"]
+            if (group["launched"] or k >= group["n_slots"] or B != group["B"] or T_max != group["T_max"]
+                    or schedule != group["schedule"] or sess.s_max < need_s or sess.np_max < proto_row0 + n_proto):
+                return None
+        rows = slice(row0, row0 + B)
 
         # ---- ViT → prototypes → session table
         low, high, pe = self.visual(pixel_values.to(dev), grid)
-        proto = self.lm.prototypes(low, out=sess.proto[:n_proto])
-        # ---- per-generate device state
-        st = torch.zeros(T_max + 1, dtype=torch.int32)
-        if schedule is not None:
-            for i, m in enumerate(schedule[: T_max]):
-                st[i] = MODE[m]
-        sess.mode_table[: T_max + 1].copy_(st.to(dev, non_blocking=True))
-        off = torch.tensor(plan.vrt_off + [plan.vrt_off[-1]] * (sess.B + 1 - len(plan.vrt_off)), dtype=torch.int32)
-        sess.vrt_off.copy_(off.to(dev, non_blocking=True))
-        sess.step.zero_()
-        sess.unfinished.fill_(1)
-        sess.err.zero_()
+        proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+        # ---- per-generate device state of this batch's rows
+        off = torch.tensor([proto_row0 + o for o in plan.vrt_off], dtype=torch.int32)
+        sess.vrt_off[row0: row0 + B + 1].copy_(off.to(dev, non_blocking=True))
+        if row0 + B + 1 < sess.vrt_off.numel():
+            sess.vrt_off[row0 + B + 1:].fill_(proto_row0 + n_proto)     # rows not (yet) in use: empty VRT range
+        sess.unfinished[rows].fill_(1)
         lens_t = torch.tensor(plan.lens, dtype=torch.int32)
-        sess.slot.copy_(lens_t.to(dev, non_blocking=True))        # next append index
-        sess.lens.copy_((lens_t + 1).to(dev, non_blocking=True))  # keys visible to the next token
-        sess.pos3.copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev, non_blocking=True))
+        sess.slot[rows].copy_(lens_t.to(dev, non_blocking=True))        # next append index
+        sess.lens[rows].copy_((lens_t + 1).to(dev, non_blocking=True))  # keys visible to the next token
+        sess.pos3[:, rows].copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev, non_blocking=True))
         self.rope_deltas = plan.rope_deltas
 
-        # ---- prefill + first token, then the first chunk of decode steps (hipGraph replays, no host sync)
+        # ---- prefill; the first token is selected together with the other batches of the group (launch_decode)
         hn_all = self.lm.prefill(plan, low, sess)
-        h_last = ops.gather_rows(hn_all, plan.last_idx)
-        sess.head_and_select(h_last, advance=False)
-        done = 1
-        n = min(sync_every, T_max - done)
-        if decode_stream is not None:
-            ev = torch.cuda.current_stream().record_event()
-            with torch.cuda.stream(decode_stream):
-                decode_stream.wait_event(ev)
-                sess.run_steps(n, use_graph=use_graph)
-        else:
-            sess.run_steps(n, use_graph=use_graph)
-        done += n
-        return dict(plan=plan, sess=sess, low=low, high=high, pe=pe, proto=proto, hn_all=hn_all, done=done, T_max=T_max,
-                    sync_every=sync_every, use_graph=use_graph, input_ids=input_ids, n_proto=n_proto)
+        ops.gather_rows(hn_all, plan.last_idx, out=sess.hn_first[rows])
+        group["subs"].append(dict(plan=plan, low=low, high=high, pe=pe, proto=proto, hn_all=hn_all, input_ids=input_ids,
+                                  n_proto=n_proto, row0=row0, proto_row0=proto_row0))
+        group["proto_rows"] = proto_row0 + n_proto
+        if len(group["subs"]) == group["n_slots"]:
+            self.launch_decode(group)
+        return group
 
     @torch.no_grad()
-    def generate_collect(self, ctx, output_hidden_states=True, return_dict_in_generate=True):
+    def launch_decode(self, group):
+        """First-token selection + the first chunk of decode steps (hipGraph replays, no host sync) for every batch of the
+        group; ordered after their prefills (current stream) by an event when a decode stream is used."""
+        if group["launched"]:
+            return
+        group["launched"] = True
+        sess, T_max = group["sess"], group["T_max"]
+        n = min(group["sync_every"], T_max - 1)
+
+        def go():
+            sess.head_and_select(sess.hn_first, advance=False)
+            sess.run_steps(n, use_graph=group["use_graph"])
+        ds = group["decode_stream"]
+        if ds is not None:
+            ev = torch.cuda.current_stream().record_event()
+            with torch.cuda.stream(ds):
+                ds.wait_event(ev)
+                go()
+        else:
+            go()
+        group["done"] = 1 + n
+
+    @torch.no_grad()
+    def generate_collect(self, group, output_hidden_states=True, return_dict_in_generate=True, all_batches=False):
         """Synchronising half of generate(): remaining decode chunks (host checks `unfinished` between chunks), trimming
-        to the reference's stop rule, output object."""
+        to the reference's stop rule, output object — of the group's only batch, or a list over its batches."""
         cfg, dev = self.config, self.device
-        plan, sess, T_max = ctx["plan"], ctx["sess"], ctx["T_max"]
-        B = plan.B
-        done_steps = ctx["done"]
+        self.launch_decode(group)
+        sess, T_max = group["sess"], group["T_max"]
+        done_steps = group["done"]
         while done_steps < T_max and bool(sess.unfinished.any()):
-            n = min(ctx["sync_every"], T_max - done_steps)
-            sess.run_steps(n, use_graph=ctx["use_graph"])
+            n = min(group["sync_every"], T_max - done_steps)
+            sess.run_steps(n, use_graph=group["use_graph"])
             done_steps += n
+        group["done"] = done_steps
         if int(sess.err) != 0:
             raise AssertionError("input_ids.max() >= extended table rows (padt.py:203)")
-        toks = sess.tokens[:, :done_steps].clone()
-        # reference stops right after the step in which the last sequence finished (padt.py:756-757)
-        eos_hit = (toks == cfg.eos_token_id)
-        if bool(eos_hit.any(dim=1).all()):
-            stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
-            toks = toks[:, :stop]
-        n_steps = toks.shape[1]
-        sequences = torch.cat([ctx["input_ids"].to(dev), toks], dim=1)
-        hidden = StepHiddenStates(sess.hidden_buf[:n_steps].clone(), n_steps, ctx["hn_all"], plan.lens, plan.L_pad)
-        table_rows = cfg.vocab_size + ctx["n_proto"]
+        outs = []
+        for sub in group["subs"]:
+            plan, row0, B = sub["plan"], sub["row0"], group["B"]
+            toks = sess.tokens[row0: row0 + B, :done_steps].clone()
+            if sub["proto_row0"]:                                  # back to this batch's own global VRT ids
+                toks = torch.where(toks >= cfg.vocab_size, toks - sub["proto_row0"], toks)
+            # reference stops right after the step in which the last sequence finished (padt.py:756-757)
+            eos_hit = (toks == cfg.eos_token_id)
+            if bool(eos_hit.any(dim=1).all()):
+                stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
+                toks = toks[:, :stop]
+            n_steps = toks.shape[1]
+            sequences = torch.cat([sub["input_ids"].to(dev), toks], dim=1)
+            hidden = StepHiddenStates(sess.hidden_buf[:n_steps, row0: row0 + B].contiguous(), n_steps, sub["hn_all"],
+                                      plan.lens, plan.L_pad)
+            table_rows = cfg.vocab_size + sub["n_proto"]
 
-        def logit_mask():
-            m = torch.zeros((B, table_rows), dtype=torch.bool, device=dev)
-            m[:, : cfg.vocab_size] = True
-            for b in range(B):
-                m[b, cfg.vocab_size + plan.vrt_off[b]: cfg.vocab_size + plan.vrt_off[b + 1]] = True
-            return m
+            def logit_mask(plan=plan, table_rows=table_rows, B=B):
+                m = torch.zeros((B, table_rows), dtype=torch.bool, device=dev)
+                m[:, : cfg.vocab_size] = True
+                for b in range(B):
+                    m[b, cfg.vocab_size + plan.vrt_off[b]: cfg.vocab_size + plan.vrt_off[b + 1]] = True
+                return m
 
-        out = CustomGenerateDecoderOnlyOutput(
-            sequences=sequences, scores=None, logits=None, attentions=None,
-            hidden_states=hidden if output_hidden_states else None, past_key_values=sess,
-            past_image_embeds=ctx["proto"].clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=ctx["high"],
-            past_visual_pe=ctx["pe"])
-        return out if return_dict_in_generate else sequences
+            out = CustomGenerateDecoderOnlyOutput(
+                sequences=sequences, scores=None, logits=None, attentions=None,
+                hidden_states=hidden if output_hidden_states else None, past_key_values=sess,
+                past_image_embeds=sub["proto"].clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=sub["high"],
+                past_visual_pe=sub["pe"])
+            outs.append(out if return_dict_in_generate else sequences)
+        return outs if all_batches else outs[0]
 
     # ------------------------------------------------------------------ vl_decode (padt.py:342-412)
     @torch.no_grad()

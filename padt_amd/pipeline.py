@@ -31,21 +31,32 @@ def rec_batch(model, processor, input_ids, attention_mask, pixel_values, image_g
 
 
 class PipelinedRunner:
-    """Keeps `depth` batches in flight: ViT + prefill of batch i+1 (MFMA-bound) run on a normal-priority HIP stream while
-    the decode steps, parse and PaDT decoder of batch i (HBM- / launch-latency-bound) run on a HIGH-priority stream, each
-    batch with its own decode session ("lane": KV caches, token ring, captured graph).  Results are identical to
-    rec_batch (same kernels, same order within a batch); only the interleaving across batches changes.
+    """Throughput runner: keeps `depth` decode groups in flight, each group = `merge` consecutive batches.
 
-        r = PipelinedRunner(model, processor); for b in batches: done = r.submit(**b); ...; rest = r.flush()
+    * ViT + prefill of a batch (MFMA-bound) run on a normal-priority HIP stream while the decode steps, parse and PaDT
+      decoder of the previous group (HBM- / launch-latency-bound) run on that group's HIGH-priority stream; every group
+      has its own decode session ("lane": KV caches, token ring, captured graph).
+    * merge > 1 (in-flight batching): the decode steps of `merge` consecutive batches share one session of merge*B rows,
+      so every step streams the 5.5 GB of LLM weights ONCE for all of them.  ViT, prefill, parse and the PaDT decoder
+      still run per batch; per-sample results are identical to rec_batch (decode kernels treat rows independently, the
+      GPU tests check bit-equality) — only the interleaving across batches changes.
+
+        r = PipelinedRunner(model, processor); for b in batches: done += r.submit(**b); ...; done += r.flush()
+    submit()/flush() return the (decoded, completions, labels, vrts) tuples of the batches that completed, in order.
     """
 
-    def __init__(self, model, processor, depth: int = 2):
-        self.model, self.processor, self.depth = model, processor, depth
-        self.prefill_stream = torch.cuda.Stream(device=model.device)
-        # one decode stream per lane: a batch's host-synchronising collect must not queue behind the next batch's decode
+    def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True):
+        self.model, self.processor, self.depth, self.merge = model, processor, depth, max(1, merge)
+        # shared_prefill_stream=False gives every lane its own prefill stream: GEMMs of two batches may then co-run and
+        # fill each other's partial waves (152-tile o_proj on 256 CUs), at the price of L2 / HBM contention
+        n_pre = 1 if shared_prefill_stream else depth
+        self.prefill_streams = [torch.cuda.Stream(device=model.device) for _ in range(n_pre)]
+        # one decode stream per lane: a group's host-synchronising collect must not queue behind the next group's decode
         self.decode_streams = [torch.cuda.Stream(device=model.device, priority=-1) for _ in range(depth)]
-        self.pending = []
-        self.count = 0
+        self.pending = []          # launched groups, oldest first
+        self.cur = None            # group still accepting batches
+        self.n_groups = 0
+        self.n_batches = 0
         self.trace = None          # set to [] to collect (batch, tag, event) marks for a stream timeline (bench.py --timeline)
 
     def _mark(self, batch, tag, stream):
@@ -54,40 +65,76 @@ class PipelinedRunner:
             ev.record(stream)
             self.trace.append((batch, tag, ev))
 
+    def _close_cur(self):
+        g = self.cur
+        self.cur = None
+        if g is None:
+            return
+        with torch.cuda.stream(g["pre"]):
+            self.model.launch_decode(g["ctx"])                    # no-op when the group filled up and launched itself
+        self._mark(g["bids"][-1], "decode_end", self.decode_streams[g["lane"]])
+        self.pending.append(g)
+
     def submit(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, schedule=None,
                need_thinking_mask=None, sync_every=None):
-        lane = self.count % self.depth
-        bid = self.count
-        self.count += 1
-        self.prefill_stream.wait_stream(torch.cuda.current_stream())   # inputs were produced on the caller's stream
+        done = []
+        bid = self.n_batches
+        self.n_batches += 1
         ids = self.processor.assign_to_global_vrt_id(input_ids, image_grid_thw)
-        self._mark(bid, "prefill_begin", self.prefill_stream)
-        with torch.cuda.stream(self.prefill_stream):
-            ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
-                                             schedule, sync_every or max_new_tokens, True, lane, self.decode_streams[lane])
-        self._mark(bid, "prefill_end", self.prefill_stream)
-        self._mark(bid, "decode_end", self.decode_streams[lane])
-        self.pending.append((lane, ctx, input_ids.shape, image_grid_thw, need_thinking_mask, bid))
-        return self._finish_oldest() if len(self.pending) >= self.depth else None
+        sched = tuple(schedule) if schedule is not None else None
+        for attempt in range(2):
+            if self.cur is None:
+                while len(self.pending) > self.depth - 1:         # the lane about to be reused must have been collected
+                    done += self._finish_oldest()
+                lane = self.n_groups % self.depth
+                self.n_groups += 1
+                self.cur = dict(lane=lane, ctx=None, meta=[], bids=[], pre=self.prefill_streams[lane % len(self.prefill_streams)])
+            g = self.cur
+            pre = g["pre"]
+            pre.wait_stream(torch.cuda.current_stream())          # inputs were produced on the caller's stream
+            self._mark(bid, "prefill_begin", pre)
+            with torch.cuda.stream(pre):
+                ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
+                                                 sched, sync_every or max_new_tokens, True, g["lane"],
+                                                 self.decode_streams[g["lane"]], group=g["ctx"], n_slots=self.merge)
+            if ctx is not None:
+                break
+            self._close_cur()                                     # batch does not fit this group's session: start a new one
+        if ctx is None:
+            raise RuntimeError("batch rejected by an empty decode group")
+        self._mark(bid, "prefill_end", pre)
+        g["ctx"] = ctx
+        g["meta"].append((input_ids.shape, image_grid_thw, need_thinking_mask))
+        g["bids"].append(bid)
+        if len(g["meta"]) == self.merge:
+            self._close_cur()
+        while len(self.pending) >= self.depth:
+            done += self._finish_oldest()
+        return done
 
     def _finish_oldest(self):
-        lane, ctx, shape, grid, mask, bid = self.pending.pop(0)
-        B, L = shape
+        g = self.pending.pop(0)
+        lane = g["lane"]
+        res = []
         with torch.cuda.stream(self.decode_streams[lane]):
-            out = self.model.generate_collect(ctx)
-            seq_local = self.processor.assign_to_local_vrt_id(out["sequences"].cpu(), grid.cpu())
-            m = mask if mask is not None else torch.Tensor([False] * B)
-            completions, feats, labels, vrts, _ = parseVRTintoCompletion(self.processor, seq_local[:, L:], out["hidden_states"], m)
-            self._mark(bid, "vl_begin", self.decode_streams[lane])
-            decoded = self.model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
-            self._mark(bid, "vl_end", self.decode_streams[lane])
+            outs = self.model.generate_collect(g["ctx"], all_batches=True)
+            for out, (shape, grid, mask), bid in zip(outs, g["meta"], g["bids"]):
+                B, L = shape
+                seq_local = self.processor.assign_to_local_vrt_id(out["sequences"].cpu(), grid.cpu())
+                m = mask if mask is not None else torch.Tensor([False] * B)
+                completions, feats, labels, vrts, _ = parseVRTintoCompletion(self.processor, seq_local[:, L:], out["hidden_states"], m)
+                self._mark(bid, "vl_begin", self.decode_streams[lane])
+                decoded = self.model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+                self._mark(bid, "vl_end", self.decode_streams[lane])
+                res.append((decoded, completions, labels, vrts))
         self.decode_streams[lane].synchronize()
-        return decoded, completions, labels, vrts
+        return res
 
     def flush(self):
         res = []
+        self._close_cur()
         while self.pending:
-            res.append(self._finish_oldest())
+            res += self._finish_oldest()
         return res
 
 

@@ -160,8 +160,11 @@ def test_empty_vl_decode_and_error_conventions(setup):
     assert model.model.embed_tokens.weight.shape[0] == cfg.vocab_size
 
 
-def test_pipelined_runner_matches_sequential(setup):
-    """Two batches in flight on two HIP streams (separate decode sessions) give bit-identical results to rec_batch."""
+@pytest.mark.parametrize("depth,merge", [(2, 1), (2, 2), (1, 3), (2, 4)])
+def test_pipelined_runner_matches_sequential(setup, depth, merge):
+    """Batches in flight on separate HIP streams / decode sessions — and, with merge > 1, decode steps of several batches
+    sharing one session (in-flight batching) — give results bit-identical to one rec_batch call per batch.  Five ragged
+    batches: groups of `merge` do not divide them, so partially filled groups and every row offset are exercised."""
     cfg, w, model, U, oc = setup
     import padt_amd
     from padt_amd import pipeline
@@ -170,18 +173,17 @@ def test_pipelined_runner_matches_sequential(setup):
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
     proc.model_embed_token_size = cfg.vocab_size
     batches = []
-    for s in range(3):
-        grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=7, seed=100 + s, ragged=True)
+    shapes = [[[1, 8, 8], [1, 10, 12]], [[1, 6, 10], [1, 8, 8]], [[1, 10, 12], [1, 10, 12]], [[1, 8, 8], [1, 6, 10]], [[1, 8, 8], [1, 10, 12]]]
+    for s, g in enumerate(shapes):
+        grid, pix, ids, am = U.synthetic_batch(cfg, g, n_pre=5 + s % 2, n_post=7, seed=100 + s, ragged=True)
         batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
     ref = [pipeline.rec_batch(model, proc, b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched) for b in batches]
-    runner = pipeline.PipelinedRunner(model, proc, depth=2)
+    runner = pipeline.PipelinedRunner(model, proc, depth=depth, merge=merge)
     got = []
     for b in batches:
-        r = runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
-        if r is not None:
-            got.append(r)
+        got += runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
     got += runner.flush()
-    assert len(got) == 3
+    assert len(got) == len(batches)
     for (d0, c0, l0, v0), (d1, c1, l1, v1) in zip(ref, got):
         assert c0 == c1 and v0 == v1
         assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"])
