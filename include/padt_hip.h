@@ -67,16 +67,14 @@ int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long 
                      int n_kv_heads, int head_dim, float scale, int causal);
 /* Single-token decode attention over the KV cache (K row-major [B][Hkv][S_max][D], V transposed [B][Hkv][D][S_max]),
  * split over 64-key chunks + combine.  lens[b] = valid keys incl. the token just appended; max_len bounds them.
- * Replaces the Lq==1 case of HF:641-689 with DynamicCache.
- * Workspace contract: padt_decode_attn_workspace() bytes, private to one stream, and its first
- * 256*ceil(batch*n_kv_heads*4/256) bytes (completion tickets) ZERO before the first call — the kernels leave them zero. */
+ * Replaces the Lq==1 case of HF:641-689 with DynamicCache.  Workspace: padt_decode_attn_workspace() bytes, private to
+ * one stream (partial O / (m, l) of the splits). */
 long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max);
 int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens, void* out,
                       void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, int max_len,
                       float scale);
 
-/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks; the last
- * chunk of a (sample, kv head) to finish merges the partials (ticket in the workspace, see above) — one launch.
+/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks + combine.
  * rope_cs = this step's fp32 (cos, sin) table [B][head_dim/2][2] from padt_rope_table; slot[b] = append index (keys
  * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace.  HF:557-599, 641-689, 665-666. */
 int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,

@@ -384,48 +384,7 @@ struct DecodeRopeArgs {
     float* part_o; float* part_ml;
     int B, Hq, Hkv, S_max, nsplit;
     float scale_log2;
-    int* ticket;                      // [B][Hkv], zero between launches (the last block of a (b, g) resets it)
-    bf16_t* out;                      // [B][Hq*D]
 };
-
-// The LAST of a (sample, kv head)'s split blocks to finish merges the partials (flash-decoding reduction) — replaces a
-// second launch.  Partials travel through agent-scope atomics (common.h: st_agent / handoff_arrive / ld_agent).
-template <int D>
-PADT_DEV void decode_finish(const DecodeRopeArgs& p, int b, int g, int lane) {
-    if (!handoff_arrive(&p.ticket[b * p.Hkv + g], p.nsplit, lane)) return;
-    const int group = p.Hq / p.Hkv;
-    const int hrow = lane >> 2;                                   // 16 head rows x 4 lanes, D/4 values per lane
-    if (hrow >= group) return;
-    constexpr int PER = D / 4;
-    const int d0 = (lane & 3) * PER;
-    const long base0 = (((long)b * p.Hkv + g) * p.nsplit) * 16 + hrow;
-    float M = -INFINITY;
-    for (int s = 0; s < p.nsplit; ++s) M = fmaxf(M, ld_agent(&p.part_ml[(base0 + s * 16) * 2]));
-    float L = 0.f, acc[PER];
-#pragma unroll
-    for (int i = 0; i < PER; ++i) acc[i] = 0.f;
-    for (int s = 0; s < p.nsplit; ++s) {
-        const long base = base0 + s * 16;
-        const float m = ld_agent(&p.part_ml[base * 2]);
-        if (m == -INFINITY) continue;
-        const float w = exp2f(m - M);
-        L += w * ld_agent(&p.part_ml[base * 2 + 1]);
-        const float* po = p.part_o + base * D + d0;
-        float v[PER];
-#pragma unroll
-        for (int i = 0; i < PER; ++i) v[i] = ld_agent(po + i);
-#pragma unroll
-        for (int i = 0; i < PER; ++i) acc[i] += w * v[i];
-    }
-    bf16_t* dst = p.out + (long)b * p.Hq * D + (long)(g * group + hrow) * D + d0;
-#pragma unroll
-    for (int i = 0; i < PER / 8; ++i) {
-        float f[8];
-#pragma unroll
-        for (int r = 0; r < 8; ++r) f[r] = L > 0.f ? acc[i * 8 + r] / L : 0.f;
-        *reinterpret_cast<u32x4*>(dst + i * 8) = pack8(f);
-    }
-}
 
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) {
@@ -444,8 +403,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     const int k0 = split * 64;
     const long pbase = (((long)b * p.Hkv + g) * p.nsplit + split) * 16;
     if (k0 >= len) {
-        if (lane < 16) { st_agent(&p.part_ml[(pbase + lane) * 2], -INFINITY); st_agent(&p.part_ml[(pbase + lane) * 2 + 1], 0.f); }
-        decode_finish<D>(p, b, g, lane);
+        if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
         return;
     }
     const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
@@ -606,10 +564,9 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         const int hrow = fq * 4 + r;
         float* po = p.part_o + (pbase + hrow) * D;
 #pragma unroll
-        for (int i = 0; i < NB; ++i) st_agent(&po[i * 16 + frow], o[i][r]);
-        if (frow == 0) { st_agent(&p.part_ml[(pbase + hrow) * 2], mrow[r]); st_agent(&p.part_ml[(pbase + hrow) * 2 + 1], lrow[r]); }
+        for (int i = 0; i < NB; ++i) po[i * 16 + frow] = o[i][r];
+        if (frow == 0) { p.part_ml[(pbase + hrow) * 2] = mrow[r]; p.part_ml[(pbase + hrow) * 2 + 1] = lrow[r]; }
     }
-    decode_finish<D>(p, b, g, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -659,12 +616,9 @@ extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const voi
     return 0;
 }
 
-// workspace = [tickets: batch*n_kv_heads ints, padded to 256 B][partial O][partial (m, l)]
-static long decode_ticket_bytes(int batch, int n_kv_heads) { return (((long)batch * n_kv_heads * 4 + 255) / 256) * 256; }
-
 extern "C" long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max) {
     const long nsplit = (s_max + 63) / 64;
-    return decode_ticket_bytes(batch, n_kv_heads) + (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
+    return (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
 }
 
 extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens,
@@ -679,7 +633,7 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
     a.q = (const bf16_t*)q; a.kc = (const bf16_t*)k_cache; a.vtc = (const bf16_t*)vt_cache; a.lens = lens;
     a.out = (bf16_t*)out; a.Hq = n_heads; a.Hkv = n_kv_heads; a.S_max = s_max;
     a.nsplit = (max_len + 63) / 64;
-    a.part_o = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + decode_ticket_bytes(batch, n_kv_heads));
+    a.part_o = (float*)workspace;
     a.part_ml = a.part_o + (long)batch * n_kv_heads * a.nsplit * 16 * head_dim;
     a.scale_log2 = scale * 1.4426950408889634f;
     hipStream_t s = (hipStream_t)stream;
@@ -708,15 +662,24 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
         return -1;
     }
     const int nsplit = (max_len + 63) / 64;
-    float* parts = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + decode_ticket_bytes(batch, n_kv_heads));
     DecodeRopeArgs a{(const bf16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (bf16_t*)k_cache, (bf16_t*)vt_cache,
-                     parts, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f,
-                     reinterpret_cast<int*>(workspace), (bf16_t*)out};
+                     (float*)workspace, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f};
     a.part_ml = a.part_o + (long)batch * n_kv_heads * nsplit * 16 * head_dim;
     hipStream_t s = (hipStream_t)stream;
+    // A fused "last split block merges" variant (agent-scope hand-off of the partials) was measured and rejected: the
+    // cross-XCD partial stores / loads cost 28 us per call against 12.7 us for the two launches below.
+    DecodeArgs c;                                              // the merge reads the same partial layout
+    c.q = nullptr; c.kc = nullptr; c.vtc = nullptr; c.lens = nullptr; c.part_o = a.part_o; c.part_ml = a.part_ml;
+    c.out = (bf16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
     switch (head_dim) {
-        case 32: hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a); break;
-        case 128: hipLaunchKernelGGL(decode_attn_rope_kernel<128>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a); break;
+        case 32:
+            hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<32>, dim3(n_heads, batch), dim3(32), 0, s, c);
+            break;
+        case 128:
+            hipLaunchKernelGGL(decode_attn_rope_kernel<128>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
+            hipLaunchKernelGGL(decode_combine_kernel<128>, dim3(n_heads, batch), dim3(128), 0, s, c);
+            break;
         default: padt_set_error("padt_decode_attn_rope: head_dim must be 32 or 128"); return -1;
     }
     hipError_t e = hipGetLastError();

@@ -267,7 +267,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nks = (p.K + 31) / 32;
-    constexpr int U = (MT == 1) ? 8 : (MT * NT >= 8 ? 2 : 4);   // K-steps in flight per wave (VGPR budget)
+    constexpr int U = (MT <= 2) ? 8 : (MT * NT >= 8 ? 2 : 4);   // K-steps in flight per wave (VGPR budget)
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -310,7 +310,11 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
                 wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp)) : zero_frag();
             }
 #pragma unroll
+#ifdef SKINNY_XCONTIG   /* timing experiment only: wrong results, x fragment read as 1 KiB contiguous */
+            for (int j = 0; j < MT; ++j) xf[u][j] = kok ? ld_frag(p.A + ((long)(ks * MT + j) * 64 + lane) * 8) : zero_frag();
+#else
             for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + k) : zero_frag();
+#endif
             if (NORM) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {

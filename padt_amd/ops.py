@@ -108,7 +108,7 @@ def decode_attn_workspace(batch, n_kv_heads, head_dim, s_max):
 
 
 def new_decode_workspace(batch, n_kv_heads, head_dim, s_max, device):
-    """Zero-initialised (the ticket header must start at zero), one per stream that decodes concurrently."""
+    """Split-attention partials; one per stream that decodes concurrently."""
     return torch.zeros(decode_attn_workspace(batch, n_kv_heads, head_dim, s_max), dtype=torch.uint8, device=device)
 
 

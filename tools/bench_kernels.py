@@ -69,6 +69,30 @@ def main():
         t = timeit(f)
         mb = N * K * 2 / 1e6
         print(f"{name:5s} N={N:6d} K={K:6d}: {t:7.2f} us  {mb / t * 1e-3 * 1e3:8.1f} GB/s ({mb:.1f} MB)")
+    # decode attention (rope + append + split attention + merge), Pro_3B heads, ~600 cached tokens
+    Hq, Hkv, D, S_max = 16, 2, 128, 640
+    qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device="cuda").to(BF)
+    kcs = [torch.randn(B, Hkv, S_max, D, device="cuda").to(BF) for _ in range(4)]
+    vts = [torch.randn(B, Hkv, D, S_max, device="cuda").to(BF) for _ in range(4)]
+    cs = torch.randn(B, D // 2, 2, device="cuda")
+    slot = torch.full((B,), 600, dtype=torch.int32, device="cuda")
+    att = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
+    wsd = ops.new_decode_workspace(B, Hkv, D, S_max, "cuda")
+    j = [0]
+
+    def fa():
+        j[0] += 1
+        ops.decode_attn_rope(qkv, cs, slot, kcs[j[0] % 4], vts[j[0] % 4], att, wsd, Hq, Hkv, D, S_max, S_max)
+    print(f"decode_attn_rope B={B}: {timeit(fa):7.2f} us")
+    hid = torch.randn(B, 2048, device="cuda").to(BF)
+    table = (torch.randn(151936, 2048, device="cuda") * 0.02).to(BF)
+    proto = (torch.randn(4232 * max(1, B // 8), 2048, device="cuda") * 0.02).to(BF)
+    voff = torch.arange(0, B + 1, dtype=torch.int32, device="cuda") * 529
+    nblk = ops.vrt_head_nblk(151936, proto.shape[0])
+    pv = torch.zeros(nblk * B, device="cuda")
+    pi = torch.zeros(nblk * B, dtype=torch.int32, device="cuda")
+    t = timeit(lambda: ops.vrt_head(hid, table, proto, voff, pv, pi, 151645), 50)
+    print(f"vrt_head B={B}: {t:7.2f} us  {(table.numel() + proto.numel()) * 2 / t * 1e-3:7.1f} GB/s")
     # pure streaming read reference: torch sum over a 45 MB bf16 tensor
     big = [torch.randn(2048, 11008, device="cuda").to(BF) for _ in range(6)]
     i = [0]
