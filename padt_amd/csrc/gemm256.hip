@@ -44,11 +44,16 @@ PADT_DEV char* slot(char* smem, int parity, int is_b, int h) { return smem + ((p
 // Per-lane byte offsets (relative to the tile's first row at k = 0) of the two 1-KiB DMA pieces this wave issues for
 // half-tile (is_b, h): piece c = 2*wave + i covers local rows 8c..8c+7; LDS slot (lr, lane & 7) holds source chunk
 // (lane & 7) ^ (lr & 7).  Computed once per block; a K-step only moves the (wave-uniform) base pointer by 128 bytes.
+template <int MF>
 PADT_DEV unsigned piece_offset(int is_b, int h, int i, int wave, int lane, int row0, int nrows, long ld) {
     const int c = wave * 2 + i;
     const int lr = c * 8 + (lane >> 3);
     const int j = (lane & 7) ^ (lr & 7);
-    int g = is_b ? (lr >> 5) * 64 + h * 32 + (lr & 31) : (lr >> 6) * 128 + h * 64 + (lr & 63);
+    // A half-tile h = rows [h*16*MF, (h+1)*16*MF) of each wave-row group's 32*MF rows; with MF < 4 the upper slots of the
+    // 128-row LDS half are unused and their pieces re-read a valid row (keeps every wave at 2 pieces per stage, so the
+    // counted vmcnt stays uniform)
+    const int lra = lr < 32 * MF ? lr : 32 * MF - 1;
+    int g = is_b ? (lr >> 5) * 64 + h * 32 + (lr & 31) : (lra / (16 * MF)) * (32 * MF) + h * (16 * MF) + lra % (16 * MF);
     g = (row0 + g < nrows) ? g : nrows - 1 - row0;                // clamp to the last valid row (results are not stored)
     return (unsigned)(((long)g * ld + j * 8) * 2);
 }
@@ -70,12 +75,15 @@ PADT_DEV void unpack4b(u32x2 v, float* f) {
 }
 }  // namespace
 
-template <int EPI, bool OUT_F32>
+// MF = 16-row MFMA blocks per wave per m-half: tile height 64*MF (256, 192 or 128 rows) x 256 columns.  The shorter tiles
+// exist for wave quantisation: 4616 prompt rows x 2048 columns are 152 tiles of 256^2 on 256 CUs but 200 of 192x256.
+template <int EPI, bool OUT_F32, int MF>
 __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
+    constexpr int TMV = 64 * MF;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
-    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TM - 1) / TM;
+    const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TMV - 1) / TMV;
     // Each XCD owns a contiguous run of tile ids (xcd_remap) and its 32 CUs work on ~32 consecutive ids at a time; walking
     // the ids in group_m x (32 / group_m) patches makes those tiles share group_m A panels and 32/group_m W panels in the
     // XCD's 4 MiB L2 instead of 1 + 32 (measured FETCH_SIZE of the gate/up GEMM: 7x its algorithmic bytes when row-major).
@@ -85,24 +93,24 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     const int first_m = (id / per_group) * gm;
     const int gsz = (ntm - first_m) < gm ? (ntm - first_m) : gm;
     const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
-    const int m0 = tm * TM, n0 = tn * TN;
+    const int m0 = tm * TMV, n0 = tn * TN;
     const int wr = wave >> 2, wc = wave & 3;
     const int nk = (p.K + TK - 1) / TK;
 
-    f32x4 acc[8][4];
+    f32x4 acc[2 * MF][4];
 #pragma unroll
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 2 * MF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[4][2], b0[2][2], b1[2][2];                          // A sub-tile, B n-half 0 (kept all tile), B n-half 1
+    bf16x8 af[MF][2], b0[2][2], b1[2][2];                          // A sub-tile, B n-half 0 (kept all tile), B n-half 1
 
     unsigned offA[2][2], offB[2][2];                              // [half][piece] per-lane byte offsets, see piece_offset
 #pragma unroll
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            offA[h][i] = piece_offset(0, h, i, wave, lane, m0, p.M, p.lda);
-            offB[h][i] = piece_offset(1, h, i, wave, lane, n0, p.N, p.ldw);
+            offA[h][i] = piece_offset<MF>(0, h, i, wave, lane, m0, p.M, p.lda);
+            offB[h][i] = piece_offset<MF>(1, h, i, wave, lane, n0, p.N, p.ldw);
         }
     const char* tileA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);     // wave-uniform bases
     const char* tileW = reinterpret_cast<const char*>(p.W + (long)n0 * p.ldw);
@@ -162,9 +170,9 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         if (PH == 0 || PH == 2) {
             const char* ah = slot(smem, par, 0, MH);
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * 64 + i * 16 + frow, kk * 4 + fq);
+                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, kk * 4 + fq);
         }
         __builtin_amdgcn_sched_barrier(0);                        // ds_reads are issued BEFORE the LDS-DMA pieces (measured +4-8 %:
         stage();                                                  // the reads' latency hides behind the DMA issue cost)
@@ -175,10 +183,10 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
         for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
-                    acc[MH * 4 + i][NH * 2 + j] = mfma16(NH ? b1[j][kk] : b0[j][kk], af[i][kk], acc[MH * 4 + i][NH * 2 + j]);
+                    acc[MH * MF + i][NH * 2 + j] = mfma16(NH ? b1[j][kk] : b0[j][kk], af[i][kk], acc[MH * MF + i][NH * 2 + j]);
         __builtin_amdgcn_s_setprio(0);
         // retire this wave's DMA pieces of everything up to 4 stages back: the NEXT-BUT-ONE load segment reads them after
         // two more barriers, by which time the lagging group has executed the same wait
@@ -209,8 +217,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
     const bf16_t* zpage = reinterpret_cast<const bf16_t*>(g_zero_page256);
 #pragma unroll
-    for (int mi = 0; mi < 8; ++mi) {
-        const int m = m0 + wr * 128 + mi * 16 + frow;
+    for (int mi = 0; mi < 2 * MF; ++mi) {
+        const int m = m0 + wr * (32 * MF) + mi * 16 + frow;
         if (m >= p.M) continue;
         if (EPI == EPI_SWIGLU) {
 #pragma unroll
@@ -266,16 +274,37 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     }
 }
 
-template <int EPI, bool F32>
-static void launch256(const Gemm256Args& a, hipStream_t s) {
+template <int EPI, bool F32, int MF>
+static void launch256_mf(const Gemm256Args& a, hipStream_t s) {
     static bool done = false;
     if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32>),
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32, MF>),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
         done = true;
     }
-    const int ntm = (a.M + TM - 1) / TM, ntn = (a.N + TN - 1) / TN;
-    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
+    const int ntm = (a.M + 64 * MF - 1) / (64 * MF), ntn = (a.N + TN - 1) / TN;
+    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32, MF>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
+}
+
+// Tile height by a wave-quantisation cost model: rounds of 256 co-resident tiles x tile height, with a small penalty for the
+// shorter tiles (fewer MFMAs per staged B half-tile).
+template <int EPI, bool F32>
+static void launch256(const Gemm256Args& a, hipStream_t s) {
+    const char* fe = getenv("PADT_GEMM_MF");                      // tuning / test knob, read per call
+    const int force = fe ? atoi(fe) : 0;
+    const long ntn = (a.N + TN - 1) / TN;
+    int best = 4;
+    double best_cost = 1e30;
+    const double penalty[5] = {0, 0, 1.35, 1.12, 1.0};           // measured at 8192^3: 980 / 1163 / 1349 TFLOP/s
+    for (int mf = 4; mf >= 2; --mf) {
+        const long tiles = ((a.M + 64 * mf - 1) / (64 * mf)) * ntn;
+        const double cost = (double)((tiles + 255) / 256) * mf * penalty[mf];
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = mf; }
+    }
+    if (force >= 2 && force <= 4) best = force;
+    if (best == 4) launch256_mf<EPI, F32, 4>(a, s);
+    else if (best == 3) launch256_mf<EPI, F32, 3>(a, s);
+    else launch256_mf<EPI, F32, 2>(a, s);
 }
 
 // Called by padt_gemm_bf16's dispatcher (gemm.hip) for shapes where the 256^2 tiling pays; arguments already validated.
@@ -284,7 +313,6 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32) {
     static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
-    const long ntm = (M + TM - 1) / TM, ntn = (N + TN - 1) / TN;
     if (mode == 1) {
         // auto: measured on MI355X (profiles/r01_gemm_tile_experiments.md) the phase-pipelined kernel wins or ties on every
         // ViT / prefill shape of the model once all three dimensions are a few tiles deep; tiny problems keep the 128^2

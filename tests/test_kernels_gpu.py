@@ -68,6 +68,30 @@ def test_gemm_plain_bias(ops, M, N, K):
     close_f32(out32[:, :N], a.float() @ w.float().T, f"gemm f32 {M}x{N}x{K}", rel=2e-5)
 
 
+@pytest.mark.parametrize("mf", [2, 3, 4])
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 1280), (577, 768, 512), (2116, 512, 3456)])
+def test_gemm_tile256_heights(ops, mf, M, N, K, monkeypatch):
+    """The phase-pipelined kernel at every tile height (128 / 192 / 256 rows x 256 columns): ragged M and N tails, all
+    epilogues, f32 output."""
+    monkeypatch.setenv("PADT_GEMM_MF", str(mf))
+    a, w, b, r = rnd(M, K, seed=41), rnd(N, K, scale=0.05, seed=42), rnd(N, seed=43), rnd(M, N, seed=44)
+    lin = a.float() @ w.float().T + b.float()
+    close_bf16(ops.gemm(a, w, b), lin, f"mf{mf} plain {M}x{N}x{K}")
+    out = r.clone()
+    ops.gemm(a, w, b, out=out, epilogue=ops.EPI_RESID, residual=out)
+    close_bf16(out, lin + r.float(), f"mf{mf} resid {M}x{N}x{K}")
+    close_bf16(ops.gemm(a, w, b, epilogue=ops.EPI_GELU), torch.nn.functional.gelu(lin), f"mf{mf} gelu {M}x{N}x{K}")
+    out32 = torch.zeros((M, N), device="cuda", dtype=torch.float32)
+    ops.gemm(a, w, None, out=out32, out_f32=True)
+    close_f32(out32, a.float() @ w.float().T, f"mf{mf} f32 {M}x{N}x{K}", rel=2e-5)
+    n2 = N // 2
+    wg, wu = w[:n2].contiguous(), w[n2:].contiguous()
+    wi = interleave_gate_up(wg, wu)
+    bi = interleave_gate_up(b[:n2].reshape(n2, 1), b[n2:].reshape(n2, 1)).view(-1)
+    ref = torch.nn.functional.silu(a.float() @ wg.float().T + b[:n2].float()) * (a.float() @ wu.float().T + b[n2:].float())
+    close_bf16(ops.gemm(a, wi, bi, epilogue=ops.EPI_SWIGLU), ref, f"mf{mf} swiglu {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("M", [7, 40, 700])
 def test_gemm_epilogues(ops, M):
     K, N = 256, 384
