@@ -52,11 +52,16 @@ int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, con
  * split_k in [2, 8] (epilogue 0 / 2, no norm) spreads K over that many blocks per 16 output columns — for projections
  * with N/16 < #CUs (down_proj: 128 column blocks) — using `workspace` (padt_gemm_splitk_workspace(N, split_k) bytes,
  * private to one stream, first 256*ceil(N/16*4/256) bytes ZERO before the first call; the kernel leaves them zero).
- * split_k <= 1: workspace may be null. */
+ * split_k <= 1: workspace may be null.
+ * act_packed: bit 0 = A, bit 1 = C and R are in the FRAGMENT-PACKED ACTIVATION layout: rows in blocks of 16, element (m, k)
+ * of a [rows][ld] matrix at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8, buffers sized for whole 16-row blocks — the x
+ * fragment of a K-step is then 1 KiB contiguous per wave instruction (row-major: 16 rows x 64 B, quarter-rate address
+ * unit, the limiter when 32 rows decode together).  padt_pack_rows converts either way. */
 long padt_gemm_splitk_workspace(long N, int split_k);
 int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
                           long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
-                          int split_k, void* workspace);
+                          int split_k, void* workspace, int act_packed);
+int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long ld_dst, long M, long K, int to_packed);
 
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
@@ -76,10 +81,11 @@ int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const vo
 
 /* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks + combine.
  * rope_cs = this step's fp32 (cos, sin) table [B][head_dim/2][2] from padt_rope_table; slot[b] = append index (keys
- * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace.  HF:557-599, 641-689, 665-666. */
+ * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace; out_packed: write `out` in the fragment-packed
+ * activation layout (see padt_gemm_packed_bf16).  HF:557-599, 641-689, 665-666. */
 int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,
                           void* vt_cache, void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,
-                          int s_max, int max_len, float scale);
+                          int s_max, int max_len, float scale, int out_packed);
 /* rope_cs[b][d] = (cos, sin)(pos3[axis(d)][b] * inv_freq[d]) with mRoPE sections (sec0, sec1, rest).  HF:525-538,589-595. */
 int padt_rope_table(void* stream, const int* pos3, const void* inv_freq, void* rope_cs, int batch, int head_dim, int sec0,
                     int sec1);

@@ -250,6 +250,7 @@ struct DecodeArgs {
     bf16_t* out;            // [B][Hq*D]
     int Hq, Hkv, S_max, nsplit;
     float scale_log2;
+    int out_packed = 0;     // out in the 16-row fragment-packed activation layout (row length Hq*D)
 };
 
 template <int D>
@@ -365,7 +366,10 @@ __global__ void decode_combine_kernel(DecodeArgs p) {
         L += w * p.part_ml[base * 2 + 1];
         acc += w * p.part_o[base * D + d];
     }
-    p.out[(long)b * p.Hq * D + hq * D + d] = f2bf(L > 0.f ? acc / L : 0.f);
+    const long ld = (long)p.Hq * D;
+    const int n = hq * D + d;
+    const long o = p.out_packed ? (long)(b >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (b & 15)) * 8 + (n & 7) : (long)b * ld + n;
+    p.out[o] = f2bf(L > 0.f ? acc / L : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -655,7 +659,7 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
 
 extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot,
                                      void* k_cache, void* vt_cache, void* out, void* workspace, int batch, int n_heads,
-                                     int n_kv_heads, int head_dim, int s_max, int max_len, float scale) {
+                                     int n_kv_heads, int head_dim, int s_max, int max_len, float scale, int out_packed) {
     if (batch <= 0) return 0;
     if (n_heads % n_kv_heads || n_heads / n_kv_heads > 16 || (s_max & 63) || (ld_qkv & 7) || max_len > s_max || max_len <= 0) {
         padt_set_error("padt_decode_attn_rope: need heads/kv_heads <= 16, s_max % 64 == 0, ld_qkv % 8 == 0, 0 < max_len <= s_max");
@@ -671,6 +675,7 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
     DecodeArgs c;                                              // the merge reads the same partial layout
     c.q = nullptr; c.kc = nullptr; c.vtc = nullptr; c.lens = nullptr; c.part_o = a.part_o; c.part_ml = a.part_ml;
     c.out = (bf16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
+    c.out_packed = out_packed;
     switch (head_dim) {
         case 32:
             hipLaunchKernelGGL(decode_attn_rope_kernel<32>, dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);

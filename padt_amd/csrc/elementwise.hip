@@ -1,6 +1,7 @@
 // HBM-bound row kernels for gfx950: norms, rotary embeddings, gathers, KV-cache append, PaDT decoder glue.
 // All bf16 traffic is 16-byte vectorised (8 elements per lane per access); reductions are wave64 xor-shuffles.
 #include "common.h"
+#include <cstdint>
 
 extern "C" void padt_set_error(const char* msg);
 
@@ -138,16 +139,85 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
     }
 }
 
+// 16-byte path (D/2 and every stride a multiple of 8): a lane rotates 8 (d, d + D/2) pairs of one (token, head).
+__global__ __launch_bounds__(256) void rope_half_vec_kernel(bf16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
+                                                            const float* __restrict__ sn, long ld_cs, long T, int nh, int D) {
+    const int half = D >> 1, cph = half >> 3;                     // 8-wide chunks per half head
+    const long total = T * nh * cph;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int c = (int)(i % cph);
+        const long th = i / cph;
+        const int h = (int)(th % nh);
+        const long t = th / nh;
+        bf16_t* p = x + t * ldx + (long)h * D + c * 8;
+        const u32x4 r1 = *reinterpret_cast<const u32x4*>(p), r2 = *reinterpret_cast<const u32x4*>(p + half);
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + t * ld_cs + c * 8), c1 = *reinterpret_cast<const f32x4*>(cs + t * ld_cs + c * 8 + 4);
+        const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + t * ld_cs + c * 8), s1 = *reinterpret_cast<const f32x4*>(sn + t * ld_cs + c * 8 + 4);
+        float x1[8], x2[8], o1[8], o2[8];
+        unpack8(r1, x1);
+        unpack8(r2, x2);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
+            o1[e] = x1[e] * cc - x2[e] * ss;
+            o2[e] = x2[e] * cc + x1[e] * ss;
+        }
+        *reinterpret_cast<u32x4*>(p) = pack8(o1);
+        *reinterpret_cast<u32x4*>(p + half) = pack8(o2);
+    }
+}
+
 extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T,
                               int n_heads, int head_dim) {
     if (T <= 0) return 0;
     if (head_dim & 1) { padt_set_error("padt_rope_half: head_dim must be even"); return -1; }
+    if ((head_dim % 16) == 0 && (ldx % 8) == 0 && (ld_cs % 4) == 0 && ((uintptr_t)x % 16) == 0 &&
+        ((uintptr_t)cos_t % 16) == 0 && ((uintptr_t)sin_t % 16) == 0) {
+        const long tv = T * n_heads * (head_dim / 16);
+        long bv = (tv + 255) / 256;
+        if (bv > 32768) bv = 32768;
+        hipLaunchKernelGGL(rope_half_vec_kernel, dim3((unsigned)bv), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+                           (const float*)cos_t, (const float*)sin_t, ld_cs, T, n_heads, head_dim);
+        PADT_CHECK_LAUNCH("rope_half");
+        return 0;
+    }
     const long total = T * n_heads * (head_dim / 2);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
                        (const float*)cos_t, (const float*)sin_t, ld_cs, T, n_heads, head_dim);
     PADT_CHECK_LAUNCH("rope_half");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Row-major [M][K] <-> 16-row fragment-packed activation layout (padt_hip.h), 16-byte chunks.  Once per decode step on each
+// side of the layer loop (embedding output in, final hidden state out); inside the loop the projections read and write the
+// packed form directly.
+__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ dst,
+                                                        long ld_dst, int M, int chunks, int to_packed) {
+    const long total = (long)M * chunks;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / chunks), c = (int)(i % chunks);
+        const long rm = (long)m * (to_packed ? ld_src : ld_dst) + c * 8;
+        const long pk = (long)(m >> 4) * 16 * (to_packed ? ld_dst : ld_src) + ((long)c * 16 + (m & 15)) * 8;
+        if (to_packed) *reinterpret_cast<u32x4*>(dst + pk) = *reinterpret_cast<const u32x4*>(src + rm);
+        else *reinterpret_cast<u32x4*>(dst + rm) = *reinterpret_cast<const u32x4*>(src + pk);
+    }
+}
+
+extern "C" int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long ld_dst, long M, long K, int to_packed) {
+    if (M <= 0 || K <= 0) return 0;
+    if ((K & 7) || (ld_src & 7) || (ld_dst & 7) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15)) {
+        padt_set_error("padt_pack_rows: K and strides must be multiples of 8, pointers 16-byte aligned");
+        return -1;
+    }
+    const long total = M * (K / 8);
+    long blocks = (total + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
+                       (bf16_t*)dst, ld_dst, (int)M, (int)(K / 8), to_packed);
+    PADT_CHECK_LAUNCH("pack_rows");
     return 0;
 }
 

@@ -31,7 +31,14 @@ struct GemmArgs {
     float* ws = nullptr;         // split-K (skinny kernel, gridDim.y > 1): partial accumulators [nb][split][frags][64][4]
     int* ticket = nullptr;       //          and one completion ticket per n-block (zero between launches)
     int split = 1;
+    int a_pack = 0;              // skinny kernel: A / (C and R) stored in the 16-row fragment-packed activation layout
+    int c_pack = 0;              //   element (m, k) at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8   (see padt_hip.h)
 };
+
+// offset of element (m, n) of a row-major or fragment-packed [rows][ld] activation matrix (n % 4 == 0 keeps 4 elements together)
+PADT_DEV long act_index(int m, int n, long ld, int packed) {
+    return packed ? (long)(m >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (m & 15)) * 8 + (n & 7) : (long)m * ld + n;
+}
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];   // 256 B of zeros (K-tail source)
 
@@ -52,7 +59,7 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
         const u32x2 braw = *reinterpret_cast<const u32x2*>(bp);     // both loads are issued before either is consumed
         u32x2 rraw = u32x2{0u, 0u};
-        if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
+        if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + act_index(m, n, p.ldr, p.c_pack));
         {
             float bv[4];
             unpack4(braw, bv);
@@ -70,7 +77,7 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
             for (int r = 0; r < 4; ++r) o[r] += rv[r];
         }
         if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
-        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + act_index(m, n, p.ldc, p.c_pack)) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         return;
     }
     for (int r = 0; r < 4 && n + r < p.N; ++r) {         // ragged N tail: scalar
@@ -96,7 +103,7 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     float o[4];
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = silu(g[r] + gb[r]) * (u[r] + ub[r]);
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no;
+    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
     *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
 }
 
@@ -285,13 +292,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
         n = n < p.N ? n : p.N - 1;
         wrow[i] = p.W + (long)n * p.ldw;
     }
+    // x fragment of K-step ks = 16 bytes at xrow[j] + ks * xstep.  Row-major activations: 16 rows x 64 B per wave
+    // instruction (address unit at a quarter rate — the limiter once 32 rows are decoded together); packed activations
+    // (a_pack): the same fragment is 1 KiB contiguous in lane order.
     const bf16_t* xrow[MT];
     bool xok[MT];
+    const int xstep = p.a_pack ? 512 : 32;
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = j * 16 + frow;
-        xok[j] = m < p.M;
-        xrow[j] = p.A + (long)(xok[j] ? m : 0) * p.lda;
+        xok[j] = p.a_pack ? true : (m < p.M);
+        xrow[j] = p.a_pack ? p.A + (long)j * 16 * p.lda + lane * 8 : p.A + (long)(xok[j] ? m : 0) * p.lda + fq * 8;
     }
 
     // wave w owns groups w, w+NW, ... of U CONSECUTIVE K-steps: one round = U*64 B contiguous per weight row
@@ -310,11 +321,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
                 wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp)) : zero_frag();
             }
 #pragma unroll
-#ifdef SKINNY_XCONTIG   /* timing experiment only: wrong results, x fragment read as 1 KiB contiguous */
-            for (int j = 0; j < MT; ++j) xf[u][j] = kok ? ld_frag(p.A + ((long)(ks * MT + j) * 64 + lane) * 8) : zero_frag();
-#else
-            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + k) : zero_frag();
-#endif
+            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
             if (NORM) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
@@ -536,8 +543,12 @@ extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
 
 extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
                                      long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
-                                     int split_k, void* workspace) {
+                                     int split_k, void* workspace, int act_packed) {
     if (M <= 0 || N <= 0) return 0;
+    if ((act_packed & ~3) || ((act_packed & 1) && (lda & 7)) || ((act_packed & 2) && ((ldc & 7) || (R != nullptr && ldr != ldc)))) {
+        padt_set_error("padt_gemm_packed_bf16: act_packed bit 0 = A packed (lda % 8), bit 1 = C and R packed (ldc % 8, ldr == ldc)");
+        return -1;
+    }
     if (split_k > 1 && (workspace == nullptr || split_k > 8 || norm_eps >= 0.f || epilogue == EPI_SWIGLU)) {
         padt_set_error("padt_gemm_packed_bf16: split_k in [2, 8] needs a workspace, no fused norm and epilogue 0 or 2");
         return -1;
@@ -553,6 +564,8 @@ extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, cons
         return -1;
     }
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)Wp, Kp, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr, (int)M, (int)N, (int)K};
+    a.a_pack = act_packed & 1;
+    a.c_pack = (act_packed >> 1) & 1;
     if (split_k > 1) {
         a.ticket = reinterpret_cast<int*>(workspace);
         a.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + splitk_ticket_bytes(N));

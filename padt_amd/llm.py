@@ -154,13 +154,17 @@ class DecodeSession:
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(device)
         assert self.inv_freq.numel() == half
         # decode-step activations (static addresses → graph-replayable)
+        # x / att / h are in the 16-row fragment-packed activation layout (include/padt_hip.h): every projection reads its
+        # input fragments as 1 KiB contiguous wave loads; x_rm is the row-major copy at the two ends of the layer loop
         I = W.llm_ipad
-        self.x = z(B, D)
+        B16 = (B + 15) // 16 * 16
+        self.x = z(B16, D)
+        self.x_rm = z(B, D)
         self.n = z(B, D)
         self.qkv = z(B, (cfg.num_attention_heads + 2 * Hkv) * hd)
         self.q = z(B, cfg.num_attention_heads * hd)
-        self.att = z(B, cfg.num_attention_heads * hd)
-        self.h = z(B, I)
+        self.att = z(B16, cfg.num_attention_heads * hd)
+        self.h = z(B16, I)
         self.hn = z(B, D)
         self.hn_first = z(B, D)          # last prompt token's post-norm hidden state per row (first-token selection)
         self.err = z(1, dt=I32)
@@ -173,20 +177,25 @@ class DecodeSession:
     def step_kernels(self):
         cfg, W = self.cfg, self.W
         Hq, Hkv, hd, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
-        ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x, err_flag=self.err)
+        B = self.B
+        ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x_rm, err_flag=self.err)
+        ops.pack_rows(self.x_rm, self.x, B, to_packed=True)
         ops.rope_table(self.pos3, self.inv_freq, self.rope_cs, hd, cfg.mrope_section)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
             # 6 launches per layer: [norm+qkv] [rope+append+split attention] [merge] [o+resid] [norm+gate/up+SwiGLU] [down+resid]
-            ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps)
+            ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps,
+                            a_packed=True, rows=B)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
-                                 hd, self.s_max, self.s_max)
+                                 hd, self.s_max, self.s_max, out_packed=True)
             ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                            split_k=self.o_split, workspace=self.splitk_ws)
-            ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps)
+                            split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+            ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps,
+                            a_packed=True, c_packed=True, rows=B)
             ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                            split_k=self.down_split, workspace=self.splitk_ws)
-        ops.rmsnorm(self.x, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
+                            split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+        ops.pack_rows(self.x, self.x_rm, B, to_packed=False)
+        ops.rmsnorm(self.x_rm, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
         self.head_and_select(self.hn, advance=True)
 
     def head_and_select(self, hn, advance: bool):

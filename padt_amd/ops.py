@@ -75,18 +75,30 @@ def new_splitk_workspace(n, split_k, device):
     return torch.zeros(_lib.load().padt_gemm_splitk_workspace(n, split_k), dtype=torch.uint8, device=device)
 
 
-def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None):
-    """Decode-step projection over a pack_weight() image (rows <= 64): out = epi(rstd?(a) * (a @ w^T) + bias)."""
+def pack_rows(src, dst, M, to_packed=True):
+    """Row-major (M, K) <-> 16-row fragment-packed activation layout (buffers hold whole 16-row blocks)."""
+    K = src.shape[1]
+    _lib.check(_lib.load().padt_pack_rows(_stream(), _p(src), src.stride(0), _p(dst), dst.stride(0), M, K, 1 if to_packed else 0),
+               "padt_pack_rows")
+    return dst
+
+
+def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None,
+                a_packed=False, c_packed=False, rows=None):
+    """Decode-step projection over a pack_weight() image (rows <= 64): out = epi(rstd?(a) * (a @ w^T) + bias).
+    a_packed / c_packed: a / (out and residual) are fragment-packed activation buffers holding `rows` valid rows."""
     lib = _lib.load()
     _chk_bf16(a, wp, bias, residual)
     M, K = a.shape
+    if rows is not None:
+        M = rows
     n_out = n // 2 if epilogue == EPI_SWIGLU else n
     if out is None:
         out = torch.empty((M, n_out), device=a.device, dtype=BF16)
     _lib.check(lib.padt_gemm_packed_bf16(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(bias), _p(out), out.stride(0),
                                          _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
-                                         -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace)),
-               "padt_gemm_packed_bf16")
+                                         -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace),
+                                         (1 if a_packed else 0) | (2 if c_packed else 0)), "padt_gemm_packed_bf16")
     return out
 
 
@@ -131,13 +143,13 @@ def rope_table(pos3, inv_freq, out, head_dim, sections):
 
 
 def decode_attn_rope(qkv, rope_cs, slot, k_cache, vt_cache, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len,
-                     scale=None):
+                     scale=None, out_packed=False):
     lib = _lib.load()
     _chk_bf16(qkv, k_cache, vt_cache, out)
     scale = head_dim ** -0.5 if scale is None else scale
     _lib.check(lib.padt_decode_attn_rope(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
                                          _p(out), _p(workspace), qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max,
-                                         int(max_len), float(scale)), "padt_decode_attn_rope")
+                                         int(max_len), float(scale), 1 if out_packed else 0), "padt_decode_attn_rope")
     return out
 
 

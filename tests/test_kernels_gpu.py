@@ -251,6 +251,45 @@ def test_decode_attn(ops, D, Hq, Hkv):
     close_bf16(out, ref, "decode attn", ulps=6)
 
 
+@pytest.mark.parametrize("M,N,K", [(8, 2048, 2048), (16, 2560, 2048), (32, 2048, 11008), (21, 704, 512), (40, 640, 256)])
+def test_gemm_packed_activations(ops, M, N, K):
+    """Fragment-packed activation layout (A and/or C, R): bit-identical to the row-major path on the same operands."""
+    x = rnd(M, K, seed=61)
+    w, b, r = rnd(N, K, scale=0.05, seed=62), rnd(N, seed=63), rnd(M, N, seed=64)
+    wp = ops.pack_weight(w)
+    M16 = (M + 15) // 16 * 16
+    xp = torch.zeros(M16, K, device="cuda", dtype=BF)
+    ops.pack_rows(x, xp, M, to_packed=True)
+    back = torch.zeros_like(x)
+    ops.pack_rows(xp, back, M, to_packed=False)
+    assert torch.equal(back, x), "pack/unpack round trip"
+    ref_plain = ops.gemm_packed(x, wp, N, b, norm_eps=1e-6)
+    got = ops.gemm_packed(xp, wp, N, b, norm_eps=1e-6, a_packed=True, rows=M)
+    assert torch.equal(got, ref_plain), "A packed, C row-major"
+    ref_res = r.clone()
+    ops.gemm_packed(x, wp, N, out=ref_res, epilogue=ops.EPI_RESID, residual=ref_res)
+    rp = torch.zeros(M16, N, device="cuda", dtype=BF)
+    ops.pack_rows(r, rp, M, to_packed=True)
+    ws = ops.new_splitk_workspace(N, 2, "cuda")
+    for split in (1, 2):
+        cp = rp.clone()
+        ops.gemm_packed(xp, wp, N, out=cp, epilogue=ops.EPI_RESID, residual=cp, a_packed=True, c_packed=True, rows=M,
+                        split_k=split, workspace=ws)
+        un = torch.zeros(M, N, device="cuda", dtype=BF)
+        ops.pack_rows(cp, un, M, to_packed=False)
+        if split == 1:
+            assert torch.equal(un, ref_res), "A, C, R packed"
+        else:
+            close_bf16(un, x.float() @ w.float().T + r.float(), "packed split-K")
+    if N % 32 == 0:
+        ref_sw = ops.gemm_packed(x, wp, N, b, epilogue=ops.EPI_SWIGLU, norm_eps=1e-6)
+        hp = torch.zeros(M16, N // 2, device="cuda", dtype=BF)
+        ops.gemm_packed(xp, wp, N, b, out=hp, epilogue=ops.EPI_SWIGLU, norm_eps=1e-6, a_packed=True, c_packed=True, rows=M)
+        un = torch.zeros(M, N // 2, device="cuda", dtype=BF)
+        ops.pack_rows(hp, un, M, to_packed=False)
+        assert torch.equal(un, ref_sw), "SwiGLU into a packed buffer"
+
+
 @pytest.mark.parametrize("D,Hq,Hkv,sec", [(128, 16, 2, (16, 24, 24)), (32, 4, 2, (4, 6, 6))])
 def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     """rope table + (rope, append, split attention) + merge == llm_qkv_post → decode_attn, and the fp32 reference."""
@@ -284,6 +323,11 @@ def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     out2 = torch.zeros_like(out1)
     ops.decode_attn(q2, kc2, vt2, slot_t + 1, out2, ws, Hq, Hkv, D, S_max, max(slots) + 1)
     assert torch.equal(out1, out2), "fused rope/append path differs from llm_qkv_post + decode_attn"
+    outp = torch.zeros(16, Hq * D, device="cuda", dtype=BF)          # same call writing the fragment-packed layout
+    ops.decode_attn_rope(qkv, cs, slot_t, kc.clone(), vt.clone(), outp, ws, Hq, Hkv, D, S_max, S_max, out_packed=True)
+    un = torch.zeros_like(out1)
+    ops.pack_rows(outp, un, B, to_packed=False)
+    assert torch.equal(un, out1)
 
 
 # ------------------------------------------------------------------------------------------------------------ row kernels
