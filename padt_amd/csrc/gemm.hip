@@ -407,7 +407,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
-                                long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32);
+                                long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                                long* rows_done);
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -479,10 +480,18 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
         return -1;
     }
     if (epilogue < 0 || epilogue > 3) { padt_set_error("padt_gemm_bf16: unknown epilogue"); return -1; }
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32) == 0) {
-        hipError_t e = hipGetLastError();
-        if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
-        return 0;
+    long done = 0;
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, &done) == 0) {
+        if (done >= M) {
+            hipError_t e = hipGetLastError();
+            if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+            return 0;
+        }
+        // a peeled ragged tail (<= 64 rows): the rest of this function streams it through the skinny kernel
+        A = (const bf16_t*)A + done * lda;
+        C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
+        if (R) R = (const bf16_t*)R + done * ldr;
+        M -= done;
     }
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
                (int)M, (int)N, (int)K};

@@ -286,31 +286,50 @@ static void launch256_mf(const Gemm256Args& a, hipStream_t s) {
     hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32, MF>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
 }
 
-// Tile height by a wave-quantisation cost model: rounds of 256 co-resident tiles x tile height, with a small penalty for the
-// shorter tiles (fewer MFMAs per staged B half-tile).
+// Tile height by a wave-quantisation cost model: rounds of 256 co-resident tiles x tile height, with a penalty for the
+// shorter tiles (fewer MFMAs per staged B half-tile).  A ragged last tile row of <= 64 rows can be PEELED off (returned to
+// the caller, who streams it through the skinny kernel) when that saves a whole round: the ViT gate/up GEMM is
+// 16928 = 66 x 256 + 32 rows x 27 tile columns → 1809 tiles = 8 rounds, 1782 tiles = 7 rounds without the 32-row tail.
 template <int EPI, bool F32>
-static void launch256(const Gemm256Args& a, hipStream_t s) {
-    const char* fe = getenv("PADT_GEMM_MF");                      // tuning / test knob, read per call
+static long launch256(Gemm256Args a, hipStream_t s) {
+    const char* fe = getenv("PADT_GEMM_MF");                      // tuning / test knobs, read per call
     const int force = fe ? atoi(fe) : 0;
+    const char* pe = getenv("PADT_GEMM_PEEL");
+    const bool allow_peel = pe ? atoi(pe) != 0 : true;            // 0 never, 1 cost model (default), 2 always when a tail exists (tests)
+    const bool force_peel = pe && atoi(pe) == 2;
     const long ntn = (a.N + TN - 1) / TN;
     int best = 4;
+    long best_rows = a.M;
     double best_cost = 1e30;
     const double penalty[5] = {0, 0, 1.35, 1.12, 1.0};           // measured at 8192^3: 980 / 1163 / 1349 TFLOP/s
     for (int mf = 4; mf >= 2; --mf) {
-        const long tiles = ((a.M + 64 * mf - 1) / (64 * mf)) * ntn;
-        const double cost = (double)((tiles + 255) / 256) * mf * penalty[mf];
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = mf; }
+        if (force >= 2 && force <= 4 && mf != force) continue;
+        const long th = 64 * mf;
+        const long tiles = ((a.M + th - 1) / th) * ntn;
+        double cost = (double)((tiles + 255) / 256) * mf * penalty[mf];
+        long rows = a.M;
+        const long tail = a.M % th;
+        if (allow_peel && tail > 0 && tail <= 64 && a.M > th) {
+            // skinny pass over `tail` rows ≈ 6 us + N*K*2 B at 4 TB/s; one cost unit = a 64-row tile slab ≈ K * 0.0082 us
+            const double skinny_units = (6.0 + (double)a.N * a.K * 2.0 / 4.0e6) / (a.K * 0.0082);
+            const double c2 = (double)(((a.M / th) * ntn + 255) / 256) * mf * penalty[mf] + skinny_units;
+            if (c2 < cost || force_peel) { cost = c2; rows = a.M - tail; }
+        }
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = mf; best_rows = rows; }
     }
-    if (force >= 2 && force <= 4) best = force;
+    a.M = (int)best_rows;
     if (best == 4) launch256_mf<EPI, F32, 4>(a, s);
     else if (best == 3) launch256_mf<EPI, F32, 3>(a, s);
     else launch256_mf<EPI, F32, 2>(a, s);
+    return best_rows;
 }
 
 // Called by padt_gemm_bf16's dispatcher (gemm.hip) for shapes where the 256^2 tiling pays; arguments already validated.
 // Returns 0 when it took the launch, 1 when the shape should stay on the 128^2 kernel.
+// *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
-                                long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32) {
+                                long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                                long* rows_done) {
     static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -325,13 +344,13 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
                   (int)M, (int)N, (int)K, group_m < 1 ? 1 : group_m};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
-        case 0: launch256<EPI_NONE, false>(a, s); break;
-        case 1: launch256<EPI_NONE, true>(a, s); break;
-        case 2: launch256<EPI_GELU, false>(a, s); break;
-        case 3: launch256<EPI_GELU, true>(a, s); break;
-        case 4: launch256<EPI_RESID, false>(a, s); break;
-        case 5: launch256<EPI_RESID, true>(a, s); break;
-        case 6: launch256<EPI_SWIGLU, false>(a, s); break;
+        case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;
+        case 1: *rows_done = launch256<EPI_NONE, true>(a, s); break;
+        case 2: *rows_done = launch256<EPI_GELU, false>(a, s); break;
+        case 3: *rows_done = launch256<EPI_GELU, true>(a, s); break;
+        case 4: *rows_done = launch256<EPI_RESID, false>(a, s); break;
+        case 5: *rows_done = launch256<EPI_RESID, true>(a, s); break;
+        case 6: *rows_done = launch256<EPI_SWIGLU, false>(a, s); break;
         default: return 1;
     }
     return 0;

@@ -92,6 +92,30 @@ def test_gemm_tile256_heights(ops, mf, M, N, K, monkeypatch):
     close_bf16(ops.gemm(a, wi, bi, epilogue=ops.EPI_SWIGLU), ref, f"mf{mf} swiglu {M}x{N}x{K}")
 
 
+@pytest.mark.parametrize("mf", [3, 4])
+def test_gemm_tile256_peeled_tail(ops, mf, monkeypatch):
+    """Ragged last tile row (<= 64 rows) peeled off to the skinny kernel: same results as the un-peeled launch."""
+    monkeypatch.setenv("PADT_GEMM_MF", str(mf))
+    M, N, K = 2 * 64 * mf + 24, 1024, 640
+    a, w, b, r = rnd(M, K, seed=45), rnd(N, K, scale=0.05, seed=46), rnd(N, seed=47), rnd(M, N, seed=48)
+    wi = interleave_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous())
+    outs = {}
+    for peel in ("0", "2"):
+        monkeypatch.setenv("PADT_GEMM_PEEL", peel)
+        o1 = r.clone()
+        ops.gemm(a, w, b, out=o1, epilogue=ops.EPI_RESID, residual=o1)
+        o32 = torch.zeros((M, N), device="cuda", dtype=torch.float32)
+        ops.gemm(a, w, None, out=o32, out_f32=True)
+        outs[peel] = (o1, ops.gemm(a, wi, None, epilogue=ops.EPI_SWIGLU), o32)
+    lin = a.float() @ w.float().T
+    close_bf16(outs["2"][0], lin + b.float() + r.float(), "peeled resid")
+    close_f32(outs["2"][2], lin, "peeled f32", rel=2e-5)
+    body = 2 * 64 * mf
+    for x0, x2 in zip(outs["0"], outs["2"]):
+        assert torch.equal(x0[:body], x2[:body]), "tile rows must not change"
+        close_bf16(x2[body:].float(), x0[body:].float(), "tail rows (skinny vs tile kernel)", ulps=2)
+
+
 @pytest.mark.parametrize("M", [7, 40, 700])
 def test_gemm_epilogues(ops, M):
     K, N = 256, 384
