@@ -188,3 +188,78 @@ def test_pipelined_runner_matches_sequential(setup, depth, merge):
         assert c0 == c1 and v0 == v1
         assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"])
         assert torch.equal(d0["pred_score"], d1["pred_score"])
+
+
+@pytest.mark.parametrize("variant", ["untied_head_gqa2_multi_object", "no_prototype_projection_no_mask_head"])
+def test_generate_config_variants(variant):
+    """The other configurations the reference ships (BASELINE.json configs 3-5): untied lm_head + a GQA group of 2 with an
+    OVD-style completion holding TWO VRT runs per image (7B-style head, padt.py:292-297), and
+    use_visual_prototype_projection=False (padt.py:191) with the mask head off (padt_decoder.py:235-236)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dataclasses
+    import padt_amd
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    import parity_util as U
+    O = U.O
+    cfg = padt_amd.small_test_config()
+    if variant == "untied_head_gqa2_multi_object":
+        cfg = dataclasses.replace(cfg, tie_word_embeddings=False, num_attention_heads=4, num_key_value_heads=2, hidden_size=512)
+        cfg = dataclasses.replace(cfg, vision_config=dataclasses.replace(cfg.vision_config, out_hidden_size=512))
+    else:
+        cfg = dataclasses.replace(cfg, use_visual_prototype_projection=False,
+                                  vl_decoder=dict(cfg.vl_decoder, use_mask_loss=False))
+    w = U.bf16_weights(cfg, seed=9, std=0.05)
+    oc = U.oracle_config(cfg)
+    model = PaDTForConditionalGeneration(cfg, w, device="cuda")
+    grids = [[1, 8, 8], [1, 10, 12]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=5, n_post=8, ragged=True)
+    T = 14
+    sched = ["t"] * T
+    for i in (2, 3, 4, 8, 9):
+        sched[i] = "v"                                               # two VRT runs → two objects per image
+    sched[-1] = "e"
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid,
+                         max_new_tokens=T, schedule=sched)
+    seq = out.sequences.cpu()
+    L = ids.shape[1]
+    toks = seq[:, L:]
+    V = cfg.vocab_size
+    ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    n_tie = 0
+    for t in range(T):                                              # margin rule, as in the main parity test
+        lg = ores["logits"][t]
+        top2 = lg.topk(2, dim=-1).values
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        floor = 2e-2 * lg[torch.isfinite(lg)].abs().max().item()
+        for b in range(2):
+            second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
+            if (top2[b, 0] - second).item() > floor:
+                assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
+            else:
+                n_tie += 1
+                assert (top2[b, 0] - chosen[b]).item() <= floor
+    assert n_tie <= T
+    hid = out.hidden_states.last_layer_rows().cpu().float()
+    for t in range(T):
+        mx, rms = rel_err(hid[t], ores["hidden"][t][:, -1].float())
+        assert rms < 2e-2 and mx < 8e-2, f"hidden step {t}: rel err max {mx:.3e} rms {rms:.3e}"
+    n_m = [g[1] * g[2] // 4 for g in grids]
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, max(n_m)), 2)
+    proc.model_embed_token_size = V
+    local = proc.assign_to_local_vrt_id(seq.clone(), grid)[:, L:]
+    comps, feats, labels, vrts, _ = padt_amd.parseVRTintoCompletion(proc, local, out["hidden_states"], torch.Tensor([False] * 2))
+    assert [len(f) for f in feats] == [2, 2] and [f.shape[0] for f in feats[0]] == [3, 2]
+    dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+    odec = O.vl_decode(w, oc, [[f.cpu().float() for f in fs] for fs in feats], out.past_image_embeds.cpu().float(),
+                       out.past_high_res_image_embeds.cpu().float(), grid,
+                       (out.past_visual_pe[0].cpu(), out.past_visual_pe[1].cpu()))
+    assert dec["sample_idx"] == odec["sample_idx"] == [0, 0, 1, 1]
+    assert (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item() < 2e-3
+    assert (dec["pred_score"].cpu().float() - odec["pred_score"]).abs().max().item() < 5e-2 * (odec["pred_score"].abs().max().item() + 1)
+    if variant == "untied_head_gqa2_multi_object":
+        mx, rms = rel_err(dec["pred_mask"], odec["pred_mask"])
+        assert rms < 2e-2 and mx < 1e-1
+        assert torch.equal(dec["pred_mask_valid_hw"][0].cpu(), odec["pred_mask_valid_hw"][0])
+    else:
+        assert dec["pred_mask"] is None and odec["pred_mask"] is None and dec["pred_mask_valid_hw"] == ()
