@@ -141,6 +141,15 @@ int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, 
                       int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok, int* step, int* slot,
                       int* lens, int* pos3, const void* hidden, void* hidden_buf, int advance);
 
+/* ---- caller-side post-processing --------------------------------------------------------------- */
+/* out[o][y][x] = sigmoid(bilinear(masks[o][:src_h[o]][:src_w[o]] → dst_h[o] x dst_w[o], align_corners=False))[y][x] > 0.5,
+ * one byte per pixel; masks fp32 logits as returned by vl_decode (src_h = 4*H, src_w = 4*W of pred_mask_valid_hw).
+ * up_f32 (optional) receives the up-sampled logits.  eval/evaluation_scripts/utils.py:262, eval/test_demo.py:153. */
+int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj, long ld_row, const int* src_h,
+                                const int* src_w, const int* dst_h, const int* dst_w, void* out_u8, long out_ld_obj,
+                                long out_ld_row, void* up_f32, long up_ld_obj, long up_ld_row, int n_obj, int max_dst_h,
+                                int max_dst_w);
+
 #ifdef __cplusplus
 }
 #endif

@@ -644,6 +644,62 @@ def vl_decode(w, cfg: OracleConfig, object_vp_feats: List[List[Tensor]], low_res
 
 
 # --------------------------------------------------------------------------- synthetic weights
+# ---------------------------------------------------------------------------------------------------------------------
+# Caller-side post-processing: eval/evaluation_scripts/utils.py:252-266 (same expressions at
+# eval/test_demo.py:145-161 with the resized image size).  The reference writes these inline in its eval loop; restated
+# here expression by expression.  RLE: pycocotools (setup.py:31, unpinned, not in the container) — `cocomask.encode` of a
+# Fortran-ordered uint8 mask = run lengths in column-major order starting with the zero run; the compressed `counts`
+# string follows the published COCO maskApi `rleToString` (parity unpinned for the string form; the run lengths are exact).
+def mask_rle_counts(mask_u8) -> List[int]:
+    import numpy as np
+    flat = np.asarray(mask_u8, dtype=np.uint8).flatten(order="F")
+    if flat.size == 0:
+        return []
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    bounds = np.concatenate([[0], change, [flat.size]])
+    runs = np.diff(bounds).tolist()
+    return runs if flat[0] == 0 else [0] + runs
+
+
+def rle_counts_to_string(counts: Sequence[int]) -> str:
+    out = []
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(chr(ch + 48))
+    return "".join(out)
+
+
+def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]]) -> List[Dict]:
+    """utils.py:252-266: per object → score = sigmoid(logit); bbox = cxcywh → clamped xywh, scaled by the image's (w, h) and
+    rounded with Python's round(); mask = bilinear up-sample of the valid 4H x 4W logits to (h, w), sigmoid > 0.5, uint8."""
+    res = []
+    if decoded["pred_boxes"].shape[0] == 0:
+        return res
+    hw = torch.stack([decoded["pred_mask_valid_hw"][0], decoded["pred_mask_valid_hw"][1]], dim=-1)
+    flat_labels = sum(labels, [])
+    for box, score, label, mask, mask_hw, si in zip(decoded["pred_boxes"], decoded["pred_score"].sigmoid(), flat_labels,
+                                                    decoded["pred_mask"], hw, decoded["sample_idx"]):
+        eval_box = (max(box[0].item() - box[2].item() / 2, 0), max(box[1].item() - box[3].item() / 2, 0),
+                    min(box[2].item(), 1), min(box[3].item(), 1))
+        w, h = image_sizes[si]
+        eval_box = (round(eval_box[0] * w), round(eval_box[1] * h), round(eval_box[2] * w), round(eval_box[3] * h))
+        up = F.interpolate(mask[None, None, :mask_hw[0] * 4, :mask_hw[1] * 4], size=(h, w), mode="bilinear")[0, 0]
+        m = (up.sigmoid() > 0.5).cpu().numpy().astype("uint8")
+        counts = mask_rle_counts(m)
+        res.append({"sample_idx": int(si), "score": score.item(), "category": label, "bbox": eval_box, "mask": m,
+                    "mask_logits_up": up, "rle": {"size": [h, w], "counts": rle_counts_to_string(counts)}, "rle_counts": counts})
+    return res
+
+
 def weight_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     """Checkpoint key -> shape for the whole path (HF-4.50 layout + PaDT extras)."""
     s: Dict[str, Tuple[int, ...]] = {}

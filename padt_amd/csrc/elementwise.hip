@@ -489,3 +489,57 @@ extern "C" int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const
     PADT_CHECK_LAUNCH("mask_scatter");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Caller-side mask post-processing (eval/evaluation_scripts/utils.py:262, eval/test_demo.py:153):
+//     F.interpolate(mask[None, None, :4H, :4W], size=(h, w), mode='bilinear')[0, 0].sigmoid() > 0.5
+// fused into one pass: fp32 bilinear resize (align_corners=False; source index = max(scale*(dst+0.5)-0.5, 0), scale =
+// in/out as float, the same expression order as torch's upsample_bilinear2d) of each object's valid logit region to its
+// image size, fp32 sigmoid, threshold, one byte per pixel.  Optionally also stores the up-sampled logits (tests).
+struct MaskPostArgs {
+    const float* masks; long ld_obj, ld_row;
+    const int* src_h; const int* src_w;
+    const int* dst_h; const int* dst_w;
+    unsigned char* out; long out_ld_obj, out_ld_row;
+    float* up; long up_ld_obj, up_ld_row;
+};
+
+__global__ __launch_bounds__(256) void mask_upsample_binarize_kernel(MaskPostArgs p) {
+    const int o = blockIdx.z;
+    const int H = p.dst_h[o], W = p.dst_w[o], hs = p.src_h[o], ws = p.src_w[o];
+    const int y = blockIdx.y;
+    if (y >= H) return;
+    const float sy = (float)hs / (float)H, sx = (float)ws / (float)W;
+    float fy = sy * ((float)y + 0.5f) - 0.5f;
+    fy = fy < 0.f ? 0.f : fy;
+    const int y0 = (int)fy;
+    const int y1 = y0 + (y0 < hs - 1 ? 1 : 0);
+    const float ly1 = fy - (float)y0, ly0 = 1.f - ly1;
+    const float* r0 = p.masks + (long)o * p.ld_obj + (long)y0 * p.ld_row;
+    const float* r1 = p.masks + (long)o * p.ld_obj + (long)y1 * p.ld_row;
+    for (int x = blockIdx.x * blockDim.x + threadIdx.x; x < W; x += gridDim.x * blockDim.x) {
+        float fx = sx * ((float)x + 0.5f) - 0.5f;
+        fx = fx < 0.f ? 0.f : fx;
+        const int x0 = (int)fx;
+        const int x1 = x0 + (x0 < ws - 1 ? 1 : 0);
+        const float lx1 = fx - (float)x0, lx0 = 1.f - lx1;
+        const float v = ly0 * (lx0 * r0[x0] + lx1 * r0[x1]) + ly1 * (lx0 * r1[x0] + lx1 * r1[x1]);
+        const float sg = 1.f / (1.f + expf(-v));
+        p.out[(long)o * p.out_ld_obj + (long)y * p.out_ld_row + x] = sg > 0.5f ? 1 : 0;
+        if (p.up) p.up[(long)o * p.up_ld_obj + (long)y * p.up_ld_row + x] = v;
+    }
+}
+
+extern "C" int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj, long ld_row, const int* src_h,
+                                           const int* src_w, const int* dst_h, const int* dst_w, void* out_u8,
+                                           long out_ld_obj, long out_ld_row, void* up_f32, long up_ld_obj, long up_ld_row,
+                                           int n_obj, int max_dst_h, int max_dst_w) {
+    if (n_obj <= 0 || max_dst_h <= 0 || max_dst_w <= 0) return 0;
+    if (n_obj > 65535 || max_dst_h > 65535) { padt_set_error("padt_mask_upsample_binarize: n_obj and max_dst_h must be <= 65535"); return -1; }
+    MaskPostArgs a{(const float*)masks_f32, ld_obj, ld_row, src_h, src_w, dst_h, dst_w, (unsigned char*)out_u8, out_ld_obj,
+                   out_ld_row, (float*)up_f32, up_ld_obj, up_ld_row};
+    const int bx = (max_dst_w + 255) / 256;
+    hipLaunchKernelGGL(mask_upsample_binarize_kernel, dim3(bx, max_dst_h, n_obj), dim3(256), 0, (hipStream_t)stream, a);
+    PADT_CHECK_LAUNCH("mask_upsample_binarize");
+    return 0;
+}

@@ -288,6 +288,23 @@ def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens
                                     _p(hidden), _p(hidden_buf), 1 if advance else 0), "padt_greedy_step")
 
 
+def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want_logits=False):
+    """masks (n_obj, Hm, Wm) fp32 logits; src/dst sizes int32 device tensors (n_obj,) → uint8 (n_obj, max_h, max_w)
+    [, fp32 up-sampled logits]."""
+    lib = _lib.load()
+    assert masks.dtype == torch.float32 and masks.stride(-1) == 1
+    n = masks.shape[0]
+    out = torch.zeros((n, max_h, max_w), dtype=torch.uint8, device=masks.device)
+    up = torch.zeros((n, max_h, max_w), dtype=torch.float32, device=masks.device) if want_logits else None
+    for t in (src_h, src_w, dst_h, dst_w):
+        assert t.dtype == torch.int32 and t.numel() == n
+    _lib.check(lib.padt_mask_upsample_binarize(_stream(), _p(masks), masks.stride(0), masks.stride(1), _p(src_h), _p(src_w),
+                                               _p(dst_h), _p(dst_w), _p(out), out.stride(0), out.stride(1), _p(up),
+                                               up.stride(0) if up is not None else 0, up.stride(1) if up is not None else 0,
+                                               n, int(max_h), int(max_w)), "padt_mask_upsample_binarize")
+    return (out, up) if want_logits else out
+
+
 def memset(t, value=0):
     lib = _lib.load()
     _lib.check(lib.padt_memset(_stream(), _p(t), value, t.numel() * t.element_size()), "padt_memset")

@@ -1,0 +1,79 @@
+"""Caller-side post-processing of vl_decode's output: what the reference's eval loop does inline at
+eval/evaluation_scripts/utils.py:252-266 (and eval/test_demo.py:145-161) — score sigmoid, box cxcywh → clamped, image-scaled,
+rounded xywh, mask bilinear up-sampling + sigmoid > 0.5, COCO RLE.
+
+The 4-number box arithmetic stays on the host in Python floats with Python's round() — exactly the reference's expressions, so
+the integers are bit-identical.  The mask resize + threshold (h*w pixels per object) is one HIP kernel
+(padt_mask_upsample_binarize).  RLE run lengths are integer work on the binary mask (column-major, zero run first, as
+pycocotools' `encode(np.asfortranarray(mask))`); the compressed `counts` string follows COCO maskApi's rleToString.
+"""
+from typing import Dict, List, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import ops
+
+
+def rle_counts(mask_u8: np.ndarray) -> List[int]:
+    flat = np.asarray(mask_u8, dtype=np.uint8).flatten(order="F")
+    if flat.size == 0:
+        return []
+    change = np.flatnonzero(flat[1:] != flat[:-1]) + 1
+    runs = np.diff(np.concatenate([[0], change, [flat.size]])).tolist()
+    return runs if flat[0] == 0 else [0] + runs
+
+
+def rle_string(counts: Sequence[int]) -> str:
+    out = []
+    for i, c in enumerate(counts):
+        x = int(c)
+        if i > 2:
+            x -= int(counts[i - 2])
+        more = True
+        while more:
+            ch = x & 0x1F
+            x >>= 5
+            more = (x != -1) if (ch & 0x10) else (x != 0)
+            if more:
+                ch |= 0x20
+            out.append(chr(ch + 48))
+    return "".join(out)
+
+
+def box_to_pixels(box: Sequence[float], w: int, h: int) -> Tuple[int, int, int, int]:
+    """utils.py:258-260 verbatim semantics (Python floats, Python round)."""
+    b0, b1, b2, b3 = (float(v) for v in box)
+    e = (max(b0 - b2 / 2, 0), max(b1 - b3 / 2, 0), min(b2, 1), min(b3, 1))
+    return (round(e[0] * w), round(e[1] * h), round(e[2] * w), round(e[3] * h))
+
+
+def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]], rle: bool = True) -> List[Dict]:
+    """decoded: vl_decode's dict; labels: parseVRTintoCompletion's per-sample label lists; image_sizes: (w, h) per sample
+    (PIL order, as `images[sample_idx].size`).  → one dict per object: sample_idx, score, category, bbox, mask (uint8 numpy
+    (h, w)), rle {size, counts}."""
+    n = decoded["pred_boxes"].shape[0]
+    if n == 0:
+        return []
+    boxes = decoded["pred_boxes"].float().cpu()
+    scores = decoded["pred_score"].float().sigmoid().reshape(-1).cpu()
+    flat_labels = sum(labels, [])
+    sidx = list(decoded["sample_idx"])
+    sizes = [image_sizes[s] for s in sidx]
+    res = [{"sample_idx": int(s), "score": scores[i].item(), "category": flat_labels[i],
+            "bbox": box_to_pixels(boxes[i].tolist(), sizes[i][0], sizes[i][1])} for i, s in enumerate(sidx)]
+    masks = decoded.get("pred_mask")
+    if masks is not None:
+        dev = masks.device
+        hs = (decoded["pred_mask_valid_hw"][0].to(torch.int32) * 4).to(dev)
+        ws = (decoded["pred_mask_valid_hw"][1].to(torch.int32) * 4).to(dev)
+        dh = torch.tensor([s[1] for s in sizes], dtype=torch.int32, device=dev)
+        dw = torch.tensor([s[0] for s in sizes], dtype=torch.int32, device=dev)
+        mh, mw = max(s[1] for s in sizes), max(s[0] for s in sizes)
+        binm = ops.mask_upsample_binarize(masks.float().contiguous(), hs, ws, dh, dw, mh, mw).cpu().numpy()
+        for i, r in enumerate(res):
+            m = binm[i, : sizes[i][1], : sizes[i][0]]
+            r["mask"] = m
+            if rle:
+                r["rle"] = {"size": [sizes[i][1], sizes[i][0]], "counts": rle_string(rle_counts(m))}
+    return res

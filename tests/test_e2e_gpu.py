@@ -263,3 +263,32 @@ def test_generate_config_variants(variant):
         assert torch.equal(dec["pred_mask_valid_hw"][0].cpu(), odec["pred_mask_valid_hw"][0])
     else:
         assert dec["pred_mask"] is None and odec["pred_mask"] is None and dec["pred_mask_valid_hw"] == ()
+
+
+def test_postprocess_results_end_to_end(setup):
+    """vl_decode output → padt_amd.postprocess (HIP mask kernel + host box / RLE logic) vs the oracle's restatement of the
+    reference's eval-loop expressions on the SAME decoded tensors: boxes / RLE run lengths bit-exact, masks identical."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline, postprocess
+    grids = [[1, 10, 12], [1, 8, 8]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=5, n_post=7, ragged=True)
+    T = 10
+    sched = U.rec_schedule(T, vrt_at=range(3, 7))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    decoded, comps, labels, vrts = pipeline.rec_batch(model, proc, ids.cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+    sizes = [(173, 140), (112, 112)]                               # (w, h) of the original images
+    got = postprocess.postprocess_results(decoded, labels, sizes)
+    cpu = {"pred_boxes": decoded["pred_boxes"].float().cpu(), "pred_score": decoded["pred_score"].float().cpu(),
+           "pred_mask": decoded["pred_mask"].float().cpu(),
+           "pred_mask_valid_hw": tuple(t.cpu() for t in decoded["pred_mask_valid_hw"]), "sample_idx": decoded["sample_idx"]}
+    ref = U.O.postprocess_results(cpu, labels, sizes)
+    assert len(got) == len(ref) == 2
+    for g, r in zip(got, ref):
+        assert g["bbox"] == r["bbox"] and g["category"] == r["category"] and g["sample_idx"] == r["sample_idx"]
+        assert abs(g["score"] - r["score"]) < 1e-6
+        diff = g["mask"] != r["mask"]
+        assert (r["mask_logits_up"].abs().numpy()[diff] < 1e-5).all() and diff.sum() <= 1
+        if not diff.any():
+            assert g["rle"] == r["rle"]

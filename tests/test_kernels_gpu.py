@@ -7,6 +7,7 @@ attention, does), which adds up to 2^-8 relative error per probability on top of
 Integer outputs are bit-exact.
 """
 import math
+import os
 
 import pytest
 import torch
@@ -543,3 +544,41 @@ def test_vrt_head_tie_breaks_to_lowest_index(ops):
     ops.greedy_step(pv, pi, nblk, h, torch.zeros(2, 1, D, device="cuda", dtype=BF), st[0], st[1], st[2], st[3],
                     z[:1].clone(), z[:1].clone(), z.clone(), 1, 0)
     assert int(st[2]) == 5
+
+
+def test_mask_upsample_binarize_against_reference_expression(ops):
+    """padt_mask_upsample_binarize vs F.interpolate(bilinear).sigmoid() > 0.5 on the golden inputs + a ragged extra case:
+    up-sampled logits to fp32 rounding, binary masks identical wherever the logit is not within rounding of the threshold."""
+    import numpy as np
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess.npz"))
+    masks = torch.from_numpy(z["masks"]).cuda()
+    sizes = [tuple(int(v) for v in r) for r in z["image_sizes"]]
+    sidx = z["sample_idx"].tolist()
+    hs = torch.from_numpy(z["valid_h"]).to(torch.int32).cuda() * 4
+    ws = torch.from_numpy(z["valid_w"]).to(torch.int32).cuda() * 4
+    dh = torch.tensor([sizes[s][1] for s in sidx], dtype=torch.int32, device="cuda")
+    dw = torch.tensor([sizes[s][0] for s in sidx], dtype=torch.int32, device="cuda")
+    out, up = ops.mask_upsample_binarize(masks, hs, ws, dh, dw, int(dh.max()), int(dw.max()), want_logits=True)
+    o, n_flip = 0, 0
+    for i, s in enumerate(sidx):
+        w, h = sizes[s]
+        ref_up = torch.nn.functional.interpolate(masks[i][None, None, : int(hs[i]), : int(ws[i])].cpu(), size=(h, w), mode="bilinear")[0, 0]
+        exp_up = torch.from_numpy(z["exp_up"][o:o + h * w]).view(h, w)
+        o += h * w
+        assert torch.equal(ref_up, exp_up)                             # same torch → the fixture is what the expression gives
+        got_up = up[i, :h, :w].cpu()
+        assert (got_up - ref_up).abs().max().item() <= 2e-6 * ref_up.abs().max().item() + 1e-6
+        ref_bin = (ref_up.sigmoid() > 0.5)
+        diff = (out[i, :h, :w].cpu().bool() != ref_bin)
+        assert (ref_up.abs()[diff] < 1e-5).all(), "binary mask differs away from the threshold"
+        n_flip += int(diff.sum())
+        assert (out[i, h:, :] == 0).all() and (out[i, :, w:] == 0).all()
+    assert n_flip <= 2
+    # down-sampling and non-square, single object
+    m = torch.randn(1, 40, 24, device="cuda")
+    one = lambda v: torch.tensor([v], dtype=torch.int32, device="cuda")
+    o2, u2 = ops.mask_upsample_binarize(m, one(37), one(21), one(19), one(50), 19, 50, want_logits=True)
+    r2 = torch.nn.functional.interpolate(m[:, None, :37, :21].cpu(), size=(19, 50), mode="bilinear")[0, 0]
+    assert (u2[0].cpu() - r2).abs().max().item() < 1e-5
+    d2 = o2[0].cpu().bool() != (r2.sigmoid() > 0.5)
+    assert (r2.abs()[d2] < 1e-5).all()

@@ -1,0 +1,78 @@
+"""Post-processing: oracle vs the golden fixture, host integer logic of the product module."""
+import os
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def load():
+    z = np.load(os.path.join(HERE, "golden", "postprocess.npz"))
+    decoded = {"pred_boxes": torch.from_numpy(z["boxes"]), "pred_score": torch.from_numpy(z["scores"]),
+               "pred_mask": torch.from_numpy(z["masks"]),
+               "pred_mask_valid_hw": (torch.from_numpy(z["valid_h"]), torch.from_numpy(z["valid_w"])),
+               "sample_idx": z["sample_idx"].tolist()}
+    labels = [s.split(";") for s in z["labels"].tolist()]
+    sizes = [tuple(int(v) for v in r) for r in z["image_sizes"]]
+    return z, decoded, labels, sizes
+
+
+def split(flat, lens):
+    out, o = [], 0
+    for l in lens:
+        out.append(flat[o:o + l])
+        o += l
+    return out
+
+
+def rle_decode_string(s):
+    """Inverse of COCO's rleToString (rleFrString), written independently of the encoder: checks the pair is consistent."""
+    counts, p = [], 0
+    while p < len(s):
+        x, k, more = 0, 0, True
+        while more:
+            c = ord(s[p]) - 48
+            x |= (c & 0x1F) << (5 * k)
+            more = bool(c & 0x20)
+            p += 1
+            k += 1
+            if not more and (c & 0x10):
+                x |= -1 << (5 * k)
+        if len(counts) > 2:
+            x += counts[-2]
+        counts.append(x)
+    return counts
+
+
+def test_oracle_postprocess_matches_golden():
+    import padt_oracle as O
+    z, decoded, labels, sizes = load()
+    res = O.postprocess_results(decoded, labels, sizes)
+    assert [list(r["bbox"]) for r in res] == z["exp_box"].tolist()
+    assert np.allclose([r["score"] for r in res], z["exp_score"], rtol=0, atol=1e-7)
+    assert [r["category"] for r in res] == ["person", "dog", "cat", "bus"]
+    bits = split(z["exp_bits"], z["exp_bits_len"])
+    counts = split(z["exp_counts"], z["exp_counts_len"])
+    for r, b, c, s in zip(res, bits, counts, z["exp_str"].tolist()):
+        assert np.array_equal(np.packbits(r["mask"].flatten()), b)
+        assert r["rle_counts"] == c.tolist() and r["rle"]["counts"] == s
+        assert sum(r["rle_counts"]) == r["mask"].size
+        assert rle_decode_string(s) == c.tolist()                   # encoder/decoder pair consistent
+
+
+def test_host_box_and_rle_logic_matches_golden():
+    from padt_amd import postprocess as P
+    z, decoded, labels, sizes = load()
+    for box, si, exp in zip(z["boxes"], z["sample_idx"], z["exp_box"].tolist()):
+        assert list(P.box_to_pixels(box.tolist(), *sizes[si])) == exp
+    assert P.box_to_pixels([0.5, 0.5, 0.25, 0.5], 10, 10) == (4, 2, 2, 5)          # 3.75→4, 2.5→2 (half-even), 2.5→2, 5.0→5
+    bits = split(z["exp_bits"], z["exp_bits_len"])
+    counts = split(z["exp_counts"], z["exp_counts_len"])
+    for b, c, s, si in zip(bits, counts, z["exp_str"].tolist(), z["sample_idx"]):
+        w, h = sizes[si]
+        m = np.unpackbits(b)[: h * w].reshape(h, w)
+        assert P.rle_counts(m) == c.tolist() and P.rle_string(c.tolist()) == s
+    assert P.rle_counts(np.ones((2, 2), np.uint8)) == [0, 4] and P.rle_counts(np.zeros((0, 0), np.uint8)) == []
+    assert P.rle_counts(np.array([[0, 1], [1, 1]], np.uint8)) == [1, 3]            # column-major: 0,1 | 1,1
+    assert P.postprocess_results({"pred_boxes": torch.zeros(0, 4)}, [[]], []) == []
