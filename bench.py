@@ -102,7 +102,7 @@ def roofline_leg(model, inp, args, cfg):
                 return 2 * true
         return n
     flops = 0.0
-    for (a, w, bias, out, epi, res, f32, K) in tile:
+    for (a, w, bias, out, epi, res, f32, K, rs) in tile:
         k = K if K is not None else a.shape[1]
         flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(k)
     import ctypes
@@ -112,8 +112,8 @@ def roofline_leg(model, inp, args, cfg):
     stream = torch.cuda.current_stream().cuda_stream
 
     def replay():
-        for (a, w, bias, out, epi, res, f32, K) in tile:
-            ops.gemm(a, w, bias, out=out, epilogue=epi, residual=res, out_f32=f32, K=K)
+        for (a, w, bias, out, epi, res, f32, K, rs) in tile:
+            ops.gemm(a, w, bias, out=out, epilogue=epi, residual=res, out_f32=f32, K=K, row_scale=rs)
     replay()
     torch.cuda.synchronize()
     reps, best = 3, None

@@ -28,14 +28,18 @@ int         padt_event_record(void* ev, void* stream);
 int         padt_event_elapsed_ms(void* start, void* stop, float* ms);
 int         padt_event_destroy(void* ev);
 
-/* ---- GEMM: C[M,N] = epi(A[M,K] · W[N,K]^T + bias) ------------------------------------------------------------------
+/* ---- GEMM: C[M,N] = epi(row_scale[m] * (A[M,K] · W[N,K]^T) + bias) ---------------------------------------------------
  * epilogue: 0 none, 1 exact-erf GELU, 2 += R (residual), 3 SwiGLU (W rows interleaved gate16|up16; C has N/2 columns).
- * out_f32: C is float instead of bf16.  M <= 64 takes the weight-streaming (HBM-bound) kernel, else the 128x128x64
- * LDS-DMA MFMA tile kernel.  Replaces every nn.Linear / Conv3d-as-GEMM: HF:116-122 (patch embed), HF:219-220,85-96,
+ * out_f32: C is float instead of bf16.  M <= 64 takes the weight-streaming (HBM-bound) kernel, else the phase-pipelined
+ * 256/192/128x256x64 (or the 128x128x64) LDS-DMA MFMA tile kernel.  row_scale (fp32 [M], may be null) scales the
+ * accumulator before the bias: with padt_row_rstd and the norm weight folded into W this is RMSNorm → Linear
+ * (HF:74-79 + the projections of HF:219-220, 85-96, 727-757) without materialising the normalised activations.  Replaces every nn.Linear / Conv3d-as-GEMM: HF:116-122 (patch embed), HF:219-220,85-96,
  * 141-151 (ViT qkv/proj/MLP/merger), HF:630-633,545-553 (LLM), padt.py:189 (vis_proj), padt_decoder.py:15-18,82-86,
  * 142-184 (decoder projections, MLPs, heads). */
 int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
-                   const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32);
+                   const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32, const void* row_scale);
+/* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above). */
+int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 
 /* Decode-sized (M <= 64) projection with the preceding RMSNorm fused into the prologue:
  * C = epi(rstd(A)[m] * (A · W^T)[m] + bias), rstd = rsqrt(mean(A[m]^2)+eps); W carries the norm weight (W·diag(g), folded

@@ -191,6 +191,36 @@ extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// rstd[row] = rsqrt(mean(x[row]^2) + eps): the statistics half of an RMSNorm whose weight is folded into the following
+// projection (y = rstd[m] * (x @ (W·diag(g))^T)[m] + b) — the GEMM then reads x itself and scales its accumulator
+// (padt_gemm_bf16 row_scale), so the normalised copy of x is never written or re-read.  One wave per row.
+__global__ __launch_bounds__(256) void row_rstd_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ out, int rows,
+                                                       int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 8; c < D; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) ss += f[i] * f[i];
+    }
+    ss = wave_sum(ss);
+    if (lane == 0) out[row] = rsqrtf(ss / (float)D + eps);
+}
+
+extern "C" int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps) {
+    if (rows <= 0) return 0;
+    if ((D & 7) || (ldx & 7) || ((uintptr_t)x & 15)) { padt_set_error("padt_row_rstd: D, ldx multiples of 8, x 16-byte aligned"); return -1; }
+    hipLaunchKernelGGL(row_rstd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (float*)out_f32, (int)rows, (int)D, eps);
+    PADT_CHECK_LAUNCH("row_rstd");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // Row-major [M][K] <-> 16-row fragment-packed activation layout (padt_hip.h), 16-byte chunks.  Once per decode step on each
 // side of the layer loop (embedding output in, final hidden state out); inside the loop the projections read and write the
 // packed form directly.

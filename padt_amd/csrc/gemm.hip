@@ -31,6 +31,7 @@ struct GemmArgs {
     float* ws = nullptr;         // split-K (skinny kernel, gridDim.y > 1): partial accumulators [nb][split][frags][64][4]
     int* ticket = nullptr;       //          and one completion ticket per n-block (zero between launches)
     int split = 1;
+    const float* rs = nullptr;   // optional per-row scale applied to the accumulator before bias (fused RMSNorm: rstd[m])
     int a_pack = 0;              // skinny kernel: A / (C and R) stored in the 16-row fragment-packed activation layout
     int c_pack = 0;              //   element (m, k) at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8   (see padt_hip.h)
 };
@@ -55,6 +56,11 @@ template <int EPI, bool OUT_F32>
 PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
     if (m >= p.M || n >= p.N) return;
     float o[4] = {v[0], v[1], v[2], v[3]};
+    if (p.rs) {
+        const float sc = p.rs[m];
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= sc;
+    }
     if (n + 3 < p.N) {                                   // full fragment: 8-byte bias / residual loads, one vector store
         const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
         const u32x2 braw = *reinterpret_cast<const u32x2*>(bp);     // both loads are issued before either is consumed
@@ -101,8 +107,9 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     unpack4(*reinterpret_cast<const u32x2*>(bp), gb);
     unpack4(*reinterpret_cast<const u32x2*>(bp + 16), ub);
     float o[4];
+    const float sc = p.rs ? p.rs[m] : 1.0f;
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = silu(g[r] + gb[r]) * (u[r] + ub[r]);
+    for (int r = 0; r < 4; ++r) o[r] = silu(g[r] * sc + gb[r]) * (u[r] * sc + ub[r]);
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
     *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
 }
@@ -216,6 +223,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
                 for (int ni = 0; ni < 4; ++ni)
                     rraw[mi][ni] = *reinterpret_cast<const u32x2*>(p.R + (long)(mb + mi * 16) * p.ldr + nb + ni * 16);
         }
+        float rsc[4];
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) rsc[mi] = p.rs ? p.rs[mb + mi * 16] : 1.0f;
 #pragma unroll
         for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
@@ -223,7 +233,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
                 float bv[4], o[4];
                 unpack4(braw[ni], bv);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bv[r];
+                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc[mi] + bv[r];
                 if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
@@ -408,7 +418,7 @@ extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                long* rows_done);
+                                const float* row_scale, long* rows_done);
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -467,7 +477,8 @@ static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
 }
 
 extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
-                              long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32) {
+                              long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                              const void* row_scale) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         padt_set_error("padt_gemm_bf16: K, lda, ldw must be multiples of 8 and A, W 16-byte aligned");
@@ -481,7 +492,8 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
     }
     if (epilogue < 0 || epilogue > 3) { padt_set_error("padt_gemm_bf16: unknown epilogue"); return -1; }
     long done = 0;
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, &done) == 0) {
+    const float* rs = (const float*)row_scale;
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &done) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -491,10 +503,12 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
         A = (const bf16_t*)A + done * lda;
         C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
         if (R) R = (const bf16_t*)R + done * ldr;
+        if (rs) rs += done;
         M -= done;
     }
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
                (int)M, (int)N, (int)K};
+    a.rs = rs;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: dispatch_m<EPI_NONE, false>(a, s); break;

@@ -29,6 +29,7 @@ struct Gemm256Args {
     void* C; long ldc;
     const bf16_t* R; long ldr;
     int M, N, K;
+    const float* rs;                // optional per-row scale of the accumulator (fused RMSNorm rstd), applied before bias
     int group_m;                    // tile rasterisation: ids walk down group_m tile rows, then to the next tile column
 };
 
@@ -220,6 +221,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     for (int mi = 0; mi < 2 * MF; ++mi) {
         const int m = m0 + wr * (32 * MF) + mi * 16 + frow;
         if (m >= p.M) continue;
+        const float rsc = p.rs ? p.rs[m] : 1.0f;
         if (EPI == EPI_SWIGLU) {
 #pragma unroll
             for (int ni = 0; ni < 4; ni += 2) {
@@ -230,7 +232,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 unpack4b(*reinterpret_cast<const u32x2*>(bp), gb);
                 unpack4b(*reinterpret_cast<const u32x2*>(bp + (p.bias ? 16 : 0)), ub);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] + gb[r]) * (acc[mi][ni + 1][r] + ub[r]);
+                for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] * rsc + gb[r]) * (acc[mi][ni + 1][r] * rsc + ub[r]);
                 const int no = (n >> 5) * 16 + (n & 15);
                 *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) =
                     u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
@@ -241,7 +243,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 const int n = n0 + wc * 64 + ni * 16 + fq * 4;
                 if (n + 3 >= p.N) {                               // ragged N tail: scalar
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
-                        float x = acc[mi][ni][r];
+                        float x = acc[mi][ni][r] * rsc;
                         if (p.bias) x += bf2f(p.bias[n + r]);
                         if (EPI == EPI_GELU) x = gelu_erf(x);
                         if (EPI == EPI_RESID) x += bf2f(p.R[(long)m * p.ldr + n + r]);
@@ -256,7 +258,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 u32x2 rraw = u32x2{0u, 0u};
                 if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] + bv[r];
+                for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc + bv[r];
                 if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
@@ -329,7 +331,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 // *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                long* rows_done) {
+                                const float* row_scale, long* rows_done) {
     static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -341,7 +343,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     static const int group_m = getenv("PADT_GEMM_GROUP_M") ? atoi(getenv("PADT_GEMM_GROUP_M")) : 8;   // tuning knob
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, group_m < 1 ? 1 : group_m};
+                  (int)M, (int)N, (int)K, row_scale, group_m < 1 ? 1 : group_m};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;

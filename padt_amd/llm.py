@@ -264,6 +264,7 @@ class LanguageModel:
         bf = torch.bfloat16
         x = ops.embed_tokens(plan.ids, plan.img_index, W["llm.embed"], sess.proto, image_embeds, err_flag=sess.err)
         n = torch.empty_like(x)
+        rstd = torch.empty((T,), device=dev, dtype=torch.float32)
         qkv = torch.empty((T, (Hq + 2 * Hkv) * hd), device=dev, dtype=bf)
         q = torch.empty((T, Hq * hd), device=dev, dtype=bf)
         kp = torch.empty((T, Hkv * hd), device=dev, dtype=bf)
@@ -272,13 +273,13 @@ class LanguageModel:
         mx = max(plan.lens)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
-            ops.rmsnorm(x, W["llm.ones"], out=n, eps=cfg.rms_norm_eps)     # norm weight is folded into qkv.w
-            ops.gemm(n, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv)
+            ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)                # norm weight is folded into qkv.w
+            ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
             ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
-            ops.rmsnorm(x, W["llm.ones"], out=n, eps=cfg.rms_norm_eps)     # norm weight is folded into gu.w
-            ops.gemm(n, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU)
+            ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)                # norm weight is folded into gu.w
+            ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
             ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
         return ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)

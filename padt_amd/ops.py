@@ -25,8 +25,17 @@ def _chk_bf16(*ts):
 GEMM_LOG = None   # bench.py sets this to a list to record (and later replay) every GEMM launch of one step
 
 
-def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=False, K=None):
-    """out[M,N'] = epi(a[M,K] @ w[N,K]^T + bias).  a/w/out may be row-strided 2-D views.  N' = N/2 for SwiGLU."""
+def row_rstd(x, eps=1e-6, out=None):
+    """fp32 rsqrt(mean(x^2) + eps) per row — feeds gemm(..., row_scale=) for an RMSNorm whose weight is folded into W."""
+    M, D = x.shape
+    if out is None:
+        out = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().padt_row_rstd(_stream(), _p(x), x.stride(0), _p(out), M, D, float(eps)), "padt_row_rstd")
+    return out
+
+
+def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=False, K=None, row_scale=None):
+    """out[M,N'] = epi(row_scale[m] * (a[M,K] @ w[N,K]^T) + bias).  a/w/out may be row-strided 2-D views.  N' = N/2 for SwiGLU."""
     lib = _lib.load()
     _chk_bf16(a, w, bias, residual)
     M = a.shape[0]
@@ -37,11 +46,13 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     if out is None:
         out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else BF16)
     assert out.stride(-1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
+    if row_scale is not None:
+        assert row_scale.dtype == torch.float32 and row_scale.numel() >= M and row_scale.is_contiguous()
     if GEMM_LOG is not None:
-        GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K))
+        GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K, row_scale))
     _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
                                   _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
-                                  1 if out_f32 else 0), "padt_gemm_bf16")
+                                  1 if out_f32 else 0, _p(row_scale)), "padt_gemm_bf16")
     return out
 
 

@@ -105,6 +105,7 @@ class VisionEncoder:
         x0 = ops.gemm(pix, W["vit.patch_embed"])                               # conv3d-as-GEMM (HF:116-122)
         x = ops.gather_rows(x0, plan.patch_perm)                               # window order
         n = torch.empty_like(x)
+        rstd = torch.empty((P,), device=x.device, dtype=torch.float32)
         qkv = torch.empty((P, 3 * vh), device=x.device, dtype=x.dtype)
         att = torch.empty_like(x)
         hbuf = torch.empty((P, W.vit_ipad), device=x.device, dtype=x.dtype)
@@ -112,13 +113,13 @@ class VisionEncoder:
             p = f"vit.{i}."
             full = i in v.fullatt_block_indexes
             cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
-            ops.rmsnorm(x, W[p + "norm1"], out=n)
-            ops.gemm(n, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv)
+            ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
+            ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)                 # q and k heads are adjacent
             ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
             ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
-            ops.rmsnorm(x, W[p + "norm2"], out=n)
-            ops.gemm(n, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU)
+            ops.row_rstd(x, out=rstd)
+            ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
             ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
         high = x
         ops.rmsnorm(x, W["vit.merger.ln_q"], out=n)

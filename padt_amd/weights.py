@@ -212,13 +212,16 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
     put("vit.patch_embed", get("visual.patch_embed.proj.weight").reshape(v.hidden_size, -1))
     for i in range(v.depth):
         s, d = f"visual.blocks.{i}.", f"vit.{i}."
-        put(d + "norm1", get(s + "norm1.weight"))
-        put(d + "norm2", get(s + "norm2.weight"))
-        put(d + "qkv.w", get(s + "attn.qkv.weight"))
+        # norm1 / norm2 weights folded into qkv / gate-up like the LLM's (below): the GEMM reads x itself and scales its
+        # accumulator with rstd[row] (ops.row_rstd + gemm(row_scale=)) — the normalised activations are never materialised
+        n1 = get(s + "norm1.weight").float().to(dev)[None, :]
+        n2 = get(s + "norm2.weight").float().to(dev)[None, :]
+        put(d + "qkv.w", get(s + "attn.qkv.weight").to(dev).float() * n1)
         put(d + "qkv.b", get(s + "attn.qkv.bias"))
         put(d + "proj.w", get(s + "attn.proj.weight"))
         put(d + "proj.b", get(s + "attn.proj.bias"))
-        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight"), vi_pad), _pad_rows(get(s + "mlp.up_proj.weight"), vi_pad)))
+        put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight").to(dev).float() * n2, vi_pad),
+                                     _pad_rows(get(s + "mlp.up_proj.weight").to(dev).float() * n2, vi_pad)))
         put(d + "gu.b", interleave16(_pad_rows(get(s + "mlp.gate_proj.bias"), vi_pad), _pad_rows(get(s + "mlp.up_proj.bias"), vi_pad)))
         put(d + "down.w", _pad_cols(get(s + "mlp.down_proj.weight"), vi_pad))
         put(d + "down.b", get(s + "mlp.down_proj.bias"))
@@ -238,7 +241,7 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         s, d = f"model.layers.{i}.", f"llm.{i}."
         # RMSNorm weights are folded into the projection that consumes the normalised activations:
         #   (x·rstd ⊙ g) Wᵀ = rstd · x (W·diag(g))ᵀ  — one rounding of W·g to bf16 at load time, so the decode GEMV can
-        #   fuse the norm (rstd only) and prefill runs a unit-weight RMSNorm in front of the same matrix.
+        #   fuse the norm (rstd only) and prefill scales the GEMM accumulator with rstd[row] (ops.row_rstd + row_scale).
         g1 = get(s + "input_layernorm.weight").float().to(dev)[None, :]
         g2 = get(s + "post_attention_layernorm.weight").float().to(dev)[None, :]
         qkv = torch.cat([get(s + "self_attn.q_proj.weight"), get(s + "self_attn.k_proj.weight"), get(s + "self_attn.v_proj.weight")], 0)

@@ -41,7 +41,7 @@ def test_every_extern_c_symbol_is_declared(lib):
 
 def test_argument_validation_without_device(lib):
     # K not a multiple of 8 → -1 with a message, before any launch
-    st = lib.padt_gemm_bf16(None, 16, 100, 16, 100, None, 16, 8, None, 0, 4, 8, 100, 0, 0)
+    st = lib.padt_gemm_bf16(None, 16, 100, 16, 100, None, 16, 8, None, 0, 4, 8, 100, 0, 0, None)
     assert st == -1 and b"multiples of 8" in lib.padt_last_error()
     st = lib.padt_attn_varlen(None, 16, 7, 16, 8, 16, 8, 16, 8, None, None, 1, 4, 2, 2, 80, 0.1, 0)
     assert st == -1
@@ -50,7 +50,7 @@ def test_argument_validation_without_device(lib):
     assert lib.padt_vrt_head_nblk(151936, 529) == (151936 + 529 + 15) // 16
     assert lib.padt_decode_attn_workspace(8, 2, 128, 640) == 8 * 2 * 10 * 16 * 130 * 4
     # zero-sized work is a no-op success
-    assert lib.padt_gemm_bf16(None, None, 8, None, 8, None, None, 8, None, 0, 0, 8, 8, 0, 0) == 0
+    assert lib.padt_gemm_bf16(None, None, 8, None, 8, None, None, 8, None, 0, 0, 8, 8, 0, 0, None) == 0
 
 
 def test_missing_library_fails_loudly(monkeypatch, tmp_path):

@@ -117,6 +117,27 @@ def test_gemm_tile256_peeled_tail(ops, mf, monkeypatch):
         close_bf16(x2[body:].float(), x0[body:].float(), "tail rows (skinny vs tile kernel)", ulps=2)
 
 
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 1280), (40, 640, 512), (300, 200, 136), (2116 + 24, 768, 640)])
+def test_gemm_row_scale_is_folded_rmsnorm(ops, M, N, K):
+    """row_rstd + gemm(row_scale=) == RMSNorm (unit weight) → Linear, on every kernel family (256-row phase kernel,
+    128^2 kernel, skinny kernel, peeled tails), plain / residual / SwiGLU epilogues."""
+    x, w, b, r = rnd(M, K, seed=51), rnd(N, K, scale=0.05, seed=52), rnd(N, seed=53), rnd(M, N, seed=54)
+    rstd = ops.row_rstd(x, eps=1e-6)
+    ref_rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    assert (rstd - ref_rstd).abs().max().item() <= 2e-6 * ref_rstd.abs().max().item()
+    lin = (x.float() @ w.float().T) * ref_rstd[:, None]
+    close_bf16(ops.gemm(x, w, b, row_scale=rstd), lin + b.float(), f"row_scale plain {M}x{N}x{K}")
+    out = r.clone()
+    ops.gemm(x, w, b, out=out, epilogue=ops.EPI_RESID, residual=out, row_scale=rstd)
+    close_bf16(out, lin + b.float() + r.float(), f"row_scale resid {M}x{N}x{K}")
+    if N % 32 == 0:
+        n2 = N // 2
+        wi = interleave_gate_up(w[:n2].contiguous(), w[n2:].contiguous())
+        bi = interleave_gate_up(b[:n2].reshape(n2, 1), b[n2:].reshape(n2, 1)).view(-1)
+        ref = torch.nn.functional.silu(lin[:, :n2] + b[:n2].float()) * (lin[:, n2:] + b[n2:].float())
+        close_bf16(ops.gemm(x, wi, bi, epilogue=ops.EPI_SWIGLU, row_scale=rstd), ref, f"row_scale swiglu {M}x{N}x{K}")
+
+
 @pytest.mark.parametrize("M", [7, 40, 700])
 def test_gemm_epilogues(ops, M):
     K, N = 256, 384
