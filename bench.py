@@ -39,6 +39,7 @@ def parse_args():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--merge", type=int, default=4, help="consecutive batches of 8 whose decode steps share one session "
                     "(in-flight batching; 1 = every batch decodes alone)")
+    ap.add_argument("--no-graph", action="store_true", help="sequential mode only: launch decode steps eagerly (profiling aid)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
     ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
     ap.add_argument("--timeline", action="store_true", help="print a stream timeline of 4 pipelined steps to stderr")
@@ -73,7 +74,7 @@ def run_step(model, inp, args, world):
     from padt_amd import pipeline
     decoded, completions, labels, vrts = pipeline.rec_batch(
         model, inp["proc"], inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew,
-        schedule=inp["sched"], sync_every=args.tnew)
+        schedule=inp["sched"], sync_every=args.tnew, use_graph=not args.no_graph)
     if world > 1:
         packed = pipeline.pack_results(decoded, cap=4 * args.batch, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
                                        device=inp["pix"].device)
@@ -102,9 +103,13 @@ def roofline_leg(model, inp, args, cfg):
                 return 2 * true
         return n
     flops = 0.0
+    alg_bytes = 0.0
     for (a, w, bias, out, epi, res, f32, K, rs) in tile:
         k = K if K is not None else a.shape[1]
         flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(k)
+        n_out = alg(w.shape[0]) // (2 if epi == 3 else 1)
+        alg_bytes += 2.0 * (a.shape[0] * alg(k) + alg(w.shape[0]) * alg(k)) + (4.0 if f32 else 2.0) * a.shape[0] * n_out \
+            + (2.0 * a.shape[0] * n_out if res is not None else 0.0)
     import ctypes
     ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
     lib.padt_event_create(ctypes.byref(ev0))
@@ -147,9 +152,19 @@ def roofline_leg(model, inp, args, cfg):
     lib.padt_event_destroy(ev1)
     ms_per_pass = total / reps
     achieved = flops / (ms_per_pass * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
+    # HBM-side bytes per launch of the same 293 launches from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction +
+    # WRITE_SIZE), collected separately and committed under profiles/ — only quoted for the workload they were measured on
+    traffic, traffic_src = None, None
+    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    if os.path.exists(tp):
+        tj = json.load(open(tp))
+        wl = tj.get("workload", {})
+        if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and tj.get("launches") == len(tile):
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+    return {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": None,
+            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
+            "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes / max(len(tile), 1), 0),
             "launches_per_step": len(tile), "avg_launch_us": round(ms_per_pass * 1e3 / max(len(tile), 1), 2),
             "alg_tflop_per_step": round(flops / 1e12, 3), "ms_per_step_in_kernel": round(ms_per_pass, 3)}
 
