@@ -1,9 +1,9 @@
 // Varlen flash attention (prefill-style) and split-KV decode attention for gfx950, bf16 MFMA 16x16x32, fp32 softmax.
 //
 // attn_varlen_kernel<D, CAUSAL, QR>: one block (4 waves) = 64*QR query rows of one (segment, head); K/V tiles of 64
-//   keys are staged in LDS (next tile prefetched into registers) — K row-major (padded rows, conflict-free
-//   ds_read_b128), V TRANSPOSED (MFMA wants both operands contiguous along the contraction index, which for P·V is the
-//   key index).  The whole tile is computed transposed (S^T = K Q^T, O^T = V^T P^T): a lane owns one query column, so
+//   keys are staged in LDS (next tile prefetched into registers), both row-major with conflict-free row strides; V is
+//   consumed through ds_read_b64_tr_b16 (MFMA wants both operands contiguous along the contraction index, which for
+//   P·V is the key index: the transpose read delivers 4 keys of one d column per lane).  The whole tile is computed transposed (S^T = K Q^T, O^T = V^T P^T): a lane owns one query column, so
 //   the online softmax is in-lane and P feeds the second MFMA straight from registers.  Never materialises S.
 //   Replaces flash_attn_varlen_func at: HF ViT attention (28 window layers: 36 segments/img of 64/48/36 tokens; 4 full
 //   layers: one 2116-token segment/img), LLM prefill (causal, GQA 16:2, d=128) and PaDTDecoderFlashAttention2.forward
@@ -13,6 +13,9 @@
 //   staging: nothing is shared between waves); partial (m, l, O) per split are merged by decode_combine_kernel.
 #include "common.h"
 #include <cstdlib>
+
+typedef short v4s_t __attribute__((ext_vector_type(4)));
+typedef v4s_t __attribute__((address_space(3))) v4s_lds;
 
 struct AttnArgs {
     const bf16_t* q; long ldq;      // token stride (elements); head h at +h*D
@@ -27,13 +30,17 @@ struct AttnArgs {
 template <int D> struct AttnCfg {
     static constexpr int KQ = (D + 31) / 32;          // k-steps for K Q^T
     static constexpr int NB = D / 16;                 // 16-wide d blocks for V^T P^T
-    static constexpr int KROW = D + 8;                // padded K row (elements)
-    static constexpr int VROW = 64 + 4;               // padded V^T row (elements): 136 B → 8-byte reads spread over banks
+    static constexpr int KROW = (D == 128) ? 144 : (D == 32 ? 48 : 80);   // K row stride (elements): the strides ≡ 16 (mod 32)
+                                                      // elements are the conflict-free ones for the ds_read_b128 lane groups
+    // V is staged ROW-major like K and read with the LDS transpose read (ds_read_b64_tr_b16): a 16-lane group hands in the
+    // 16 8-byte chunks of a [4 keys][16 d] block and lane i gets column i (4 keys) — two of them are one A fragment of
+    // O^T = V^T P^T.  Row stride ≡ 16/48/80/112 (mod 128) elements puts the 8 key rows x 32 B a half-wave touches on
+    // 8 disjoint bank windows.
+    static constexpr int VROW = (D == 128) ? 144 : (D == 32 ? 48 : 80);
     static constexpr int CPR = D / 8;                 // 16-byte chunks per K/V row
-    static constexpr int NK = (64 * CPR + 255) / 256; // K chunks per thread per tile
-    static constexpr int NV = (32 * CPR + 255) / 256; // V (key-pair, chunk) items per thread per tile
+    static constexpr int NK = (64 * CPR + 255) / 256; // K (and V) chunks per thread per tile
     static constexpr int K_BYTES = 64 * KROW * 2;
-    static constexpr int V_BYTES = D * VROW * 2;
+    static constexpr int V_BYTES = 64 * VROW * 2;
     static constexpr int LDS = K_BYTES + V_BYTES;
 };
 
@@ -89,7 +96,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     }
 
     // K/V tile kt+1 is fetched into registers while tile kt is multiplied
-    u32x4 kreg[C::NK], vreg[C::NV][2];
+    u32x4 kreg[C::NK], vreg[C::NK];
     auto fetch = [&](int kt) {
 #pragma unroll
         for (int it = 0; it < C::NK; ++it) {
@@ -98,17 +105,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             const int key = kt * 64 + row;
             const bool ok = (idx < 64 * C::CPR) && (key < Lk);
             kreg[it] = ok ? *reinterpret_cast<const u32x4*>(p.k + (long)(k_beg + key) * p.ldk + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
-        }
-#pragma unroll
-        for (int it = 0; it < C::NV; ++it) {
-            const int idx = it * 256 + tid;
-            const int kp = idx / C::CPR, c = idx % C::CPR;
-#pragma unroll
-            for (int e = 0; e < 2; ++e) {
-                const int key = kt * 64 + kp * 2 + e;
-                const bool ok = (idx < 32 * C::CPR) && (key < Lk);
-                vreg[it][e] = ok ? *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
-            }
+            vreg[it] = ok ? *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
         }
     };
     if (nkt > 0) fetch(0);
@@ -118,20 +115,9 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 #pragma unroll
         for (int it = 0; it < C::NK; ++it) {
             const int idx = it * 256 + tid;
-            if (idx < 64 * C::CPR) *reinterpret_cast<u32x4*>(Ks + (idx / C::CPR) * C::KROW + (idx % C::CPR) * 8) = kreg[it];
-        }
-#pragma unroll
-        for (int it = 0; it < C::NV; ++it) {
-            const int idx = it * 256 + tid;
-            if (idx < 32 * C::CPR) {
-                const int kp = idx / C::CPR, c = idx % C::CPR;
-                unsigned* dst = reinterpret_cast<unsigned*>(Vt + (c * 8) * C::VROW + kp * 2);
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {                     // V^T[d][key pair]: two keys of one d per 4-byte write
-                    const unsigned a = vreg[it][0][j], b = vreg[it][1][j];
-                    dst[(2 * j) * (C::VROW / 2)] = (a & 0xffffu) | (b << 16);
-                    dst[(2 * j + 1) * (C::VROW / 2)] = (a >> 16) | (b & 0xffff0000u);
-                }
+            if (idx < 64 * C::CPR) {
+                *reinterpret_cast<u32x4*>(Ks + (idx / C::CPR) * C::KROW + (idx % C::CPR) * 8) = kreg[it];
+                *reinterpret_cast<u32x4*>(Vt + (idx / C::CPR) * C::VROW + (idx % C::CPR) * 8) = vreg[it];
             }
         }
         __syncthreads();
@@ -208,9 +194,10 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
             for (int i = 0; i < C::NB; ++i) {
-                const bf16_t* vp = Vt + (i * 16 + frow) * C::VROW + ks * 32 + fq * 4;
-                const u32x2 lo = *reinterpret_cast<const u32x2*>(vp);
-                const u32x2 hi = *reinterpret_cast<const u32x2*>(vp + 16);
+                // chunk handed in by this lane: key 32ks + 4fq + (frow >> 2) (second read: + 16), d = 16i + 4(frow & 3)
+                const bf16_t* vp = Vt + (ks * 32 + fq * 4 + (frow >> 2)) * C::VROW + i * 16 + (frow & 3) * 4;
+                const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_lds*)(vp)));
+                const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_lds*)(vp + 16 * C::VROW)));
                 const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
                 const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
 #pragma unroll

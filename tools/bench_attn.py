@@ -12,20 +12,20 @@ BF = torch.bfloat16
 
 def main():
     dev = "cuda"
-    # ViT: 8 images x 1352 patches, 16 heads x 80
-    P, H, hd = 8 * 1352, 16, 80
+    # ViT: 8 images x 2116 patches (grid 46x46), 16 heads x 80
+    P, H, hd = 8 * 2116, 16, 80
     qkv = (torch.randn(P, 3 * H * hd, device=dev) * 0.5).to(BF)
     out = torch.empty(P, H * hd, device=dev, dtype=BF)
-    cu_full = torch.arange(0, P + 1, 1352, dtype=torch.int32, device=dev)
+    cu_full = torch.arange(0, P + 1, 2116, dtype=torch.int32, device=dev)
     cu_win = torch.arange(0, P + 1, 64, dtype=torch.int32, device=dev)
     vh = H * hd
-    for name, cu, mx in (("vit_full", cu_full, 1352), ("vit_win", cu_win, 64)):
+    for name, cu, mx in (("vit_full", cu_full, 2116), ("vit_win", cu_win, 64)):
         t = timeit(lambda: ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], out, cu, cu, mx, H, H, hd), 50)
         nseg = cu.numel() - 1
         fl = 4.0 * nseg * mx * mx * H * hd
         print(f"{name:10s}: {t:8.1f} us  {fl / t * 1e-6:7.1f} TFLOP/s")
-    # LLM prefill: 8 x 390 tokens, 16 q heads / 2 kv heads x 128, causal
-    L, B, Hq, Hk, D = 390, 8, 16, 2, 128
+    # LLM prefill: 8 x 577 tokens, 16 q heads / 2 kv heads x 128, causal
+    L, B, Hq, Hk, D = 577, 8, 16, 2, 128
     T = B * L
     q = (torch.randn(T, Hq * D, device=dev) * 0.5).to(BF)
     k = (torch.randn(T, Hk * D, device=dev) * 0.5).to(BF)
