@@ -183,10 +183,14 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
                 pf[rb][ks] = __builtin_bit_cast(bf16x8, pack8(pv + ks * 8));
+            // the running max rarely moves after the first tiles: skip the O rescale for the whole wave when alpha == 1
+            // in every lane (multiplying by exactly 1.0f is the identity, so results do not depend on the shortcut)
+            if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-            for (int i = 0; i < C::NB; ++i)
+                for (int i = 0; i < C::NB; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[rb][i][r] *= alpha;
+                    for (int r = 0; r < 4; ++r) o[rb][i][r] *= alpha;
+            }
         }
 
         // ---- O^T += V^T P^T   (A = V^T rows d, B = P; contraction slots j<4: key 32ks+4fq+j, j>=4: key 32ks+16+4fq+j-4)
