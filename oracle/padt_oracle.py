@@ -678,6 +678,23 @@ def rle_counts_to_string(counts: Sequence[int]) -> str:
     return "".join(out)
 
 
+def box_iou_xywh(b1: Sequence[float], b2: Sequence[float]) -> float:
+    """eval/evaluation_scripts/eval_refcoco.py:15-41 (calculate_iou on (x, y, w, h) boxes) — the "box IoU vs ref" of the metric."""
+    x1, y1, w1, h1 = b1
+    x2, y2, w2, h2 = b2
+    iw = max(0, min(x1 + w1, x2 + w2) - max(x1, x2))
+    ih = max(0, min(y1 + h1, y2 + h2) - max(y1, y2))
+    inter = iw * ih
+    union = w1 * h1 + w2 * h2 - inter
+    return 0.0 if union == 0 else inter / union
+
+
+def mask_ciou_parts(pred, gt) -> Tuple[int, int]:
+    """eval_refcoco.py:44-47 (calculate_ciou): intersection and union pixel counts of two binary masks."""
+    import numpy as np
+    return int(np.logical_and(pred, gt).sum()), int(np.logical_or(pred, gt).sum())
+
+
 def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]]) -> List[Dict]:
     """utils.py:252-266: per object → score = sigmoid(logit); bbox = cxcywh → clamped xywh, scaled by the image's (w, h) and
     rounded with Python's round(); mask = bilinear up-sample of the valid 4H x 4W logits to (h, w), sigmoid > 0.5, uint8."""

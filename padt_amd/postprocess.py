@@ -48,6 +48,17 @@ def box_to_pixels(box: Sequence[float], w: int, h: int) -> Tuple[int, int, int, 
     return (round(e[0] * w), round(e[1] * h), round(e[2] * w), round(e[3] * h))
 
 
+def box_iou_xywh(b1: Sequence[float], b2: Sequence[float]) -> float:
+    """calculate_iou of eval/evaluation_scripts/eval_refcoco.py:15-41 on (x, y, w, h) boxes."""
+    x1, y1, w1, h1 = b1
+    x2, y2, w2, h2 = b2
+    iw = max(0, min(x1 + w1, x2 + w2) - max(x1, x2))
+    ih = max(0, min(y1 + h1, y2 + h2) - max(y1, y2))
+    inter = iw * ih
+    union = w1 * h1 + w2 * h2 - inter
+    return 0.0 if union == 0 else inter / union
+
+
 def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]], rle: bool = True) -> List[Dict]:
     """decoded: vl_decode's dict; labels: parseVRTintoCompletion's per-sample label lists; image_sizes: (w, h) per sample
     (PIL order, as `images[sample_idx].size`).  → one dict per object: sample_idx, score, category, bbox, mask (uint8 numpy

@@ -285,6 +285,17 @@ def test_postprocess_results_end_to_end(setup):
            "pred_mask_valid_hw": tuple(t.cpu() for t in decoded["pred_mask_valid_hw"]), "sample_idx": decoded["sample_idx"]}
     ref = U.O.postprocess_results(cpu, labels, sizes)
     assert len(got) == len(ref) == 2
+    # the metric's "box IoU vs ref": HIP boxes vs the fp32 oracle's own end-to-end boxes (its own tokens, features, decoder)
+    ores = U.O.generate(w, oc, ids, am, pix, grid, T, schedule=sched)
+    st = ores["state"]
+    ofeats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in range(3, 7)], 0)] for b in range(2)]
+    odec = U.O.vl_decode(w, oc, ofeats, st.proto, st.high_res, grid, st.visual_pe)
+    oref = U.O.postprocess_results(odec, labels, sizes)
+    for g, r in zip(got, oref):
+        iou = postprocess.box_iou_xywh(g["bbox"], r["bbox"])
+        inter, union = U.O.mask_ciou_parts(g["mask"], r["mask"])
+        assert iou >= 0.97, f"box IoU vs oracle {iou:.4f}"
+        assert inter / max(union, 1) >= 0.97, f"mask IoU vs oracle {inter / max(union, 1):.4f}"
     for g, r in zip(got, ref):
         assert g["bbox"] == r["bbox"] and g["category"] == r["category"] and g["sample_idx"] == r["sample_idx"]
         assert abs(g["score"] - r["score"]) < 1e-6

@@ -76,3 +76,13 @@ def test_host_box_and_rle_logic_matches_golden():
     assert P.rle_counts(np.ones((2, 2), np.uint8)) == [0, 4] and P.rle_counts(np.zeros((0, 0), np.uint8)) == []
     assert P.rle_counts(np.array([[0, 1], [1, 1]], np.uint8)) == [1, 3]            # column-major: 0,1 | 1,1
     assert P.postprocess_results({"pred_boxes": torch.zeros(0, 4)}, [[]], []) == []
+
+
+def test_box_iou_matches_reference_definition():
+    import padt_oracle as O
+    from padt_amd import postprocess as P
+    cases = [((0, 0, 10, 10), (5, 5, 10, 10), 25 / 175), ((1, 2, 3, 4), (1, 2, 3, 4), 1.0), ((0, 0, 2, 2), (3, 3, 1, 1), 0.0),
+             ((0, 0, 0, 0), (0, 0, 0, 0), 0.0), ((36, 19, 24, 38), (30, 20, 24, 30), None)]
+    for b1, b2, exp in cases:
+        a, b = O.box_iou_xywh(b1, b2), P.box_iou_xywh(b1, b2)
+        assert a == b and (exp is None or abs(a - exp) < 1e-12)
