@@ -70,10 +70,13 @@ int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long l
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
  * q: token t head h at q + t*ldq + h*head_dim (k, v likewise with kv head h / (n_heads/n_kv_heads)).
- * Replaces flash_attn_varlen_func at padt_decoder.py:55 and in HF's ViT (HF:225-291) / LLM prefill (HF:641-689). */
+ * Replaces flash_attn_varlen_func at padt_decoder.py:55 and in HF's ViT (HF:225-291) / LLM prefill (HF:641-689).
+ * rope_cos / rope_sin (nullable, fp32 [token][ld_cs], first head_dim/2 columns): fuse the rotate-half RoPE of q and k
+ * (HF:160-171) into the kernel — self-attention only (cu_q == cu_k), non-causal, max_seqlen_q < 256 (ViT window layers). */
 int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* o,
                      long ldo, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int n_heads,
-                     int n_kv_heads, int head_dim, float scale, int causal);
+                     int n_kv_heads, int head_dim, float scale, int causal, const void* rope_cos, const void* rope_sin,
+                     long ld_cs);
 /* Single-token decode attention over the KV cache (K row-major [B][Hkv][S_max][D], V transposed [B][Hkv][D][S_max]),
  * split over 64-key chunks + combine.  lens[b] = valid keys incl. the token just appended; max_len bounds them.
  * Replaces the Lq==1 case of HF:641-689 with DynamicCache.  Workspace: padt_decode_attn_workspace() bytes, private to

@@ -13,6 +13,7 @@
 //   staging: nothing is shared between waves); partial (m, l, O) per split are merged by decode_combine_kernel.
 #include "common.h"
 #include <cstdlib>
+#include <cstdint>
 
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef v4s_t __attribute__((address_space(3))) v4s_lds;
@@ -25,6 +26,8 @@ struct AttnArgs {
     const int* cu_q; const int* cu_k;
     int group;                      // q heads per kv head
     float scale_log2;               // softmax scale * log2(e)
+    const float* rcos; const float* rsin; long ld_cs;   // optional fused rotate-half RoPE of q and k (self-attention:
+                                                        // one fp32 table [token][>= D/2], same token index space)
 };
 
 template <int D> struct AttnCfg {
@@ -49,9 +52,13 @@ template <int D> struct AttnCfg {
 // shuffles for the max; the sum is reduced once at the end), and the 8 probabilities a lane holds per 32 keys ARE a
 // B-operand fragment of O^T = V^T P^T under the key permutation {32ks+4fq+j, 32ks+16+4fq+j} — P never touches LDS; the
 // same permutation is applied to the V^T fragment (two 8-byte LDS reads).  O^T's rescale factor is in-lane as well.
-template <int D, bool CAUSAL, int QR>
+// ROPE (window layers of the ViT, HF apply_rotary_pos_emb_vision :160-171): q fragments are rotated in registers when
+// they are loaded, the staged K tile is rotated in place in LDS — same fp32 expressions and single bf16 rounding as the
+// stand-alone rope_half kernel, without its extra pass over q and k in HBM.
+template <int D, bool CAUSAL, int QR, bool ROPE>
 __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     using C = AttnCfg<D>;
+    constexpr int HALF = D / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
     bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + C::K_BYTES);
@@ -76,6 +83,21 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             const int qrow = wq0 + rb * 16 + frow;
             const int d = kk * 32 + fq * 8;
             qf[rb][kk] = (qrow < Lq && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + h * D + d) : zero_frag();
+            if (ROPE && qrow < Lq && d < D) {
+                const bool lo = d < HALF;
+                const bf16_t* qp = p.q + (long)(q_beg + qrow) * p.ldq + h * D + (lo ? d + HALF : d - HALF);
+                const long ci = (long)(q_beg + qrow) * p.ld_cs + (lo ? d : d - HALF);
+                float x[8], y[8], c[8], sn[8];
+                unpack8(__builtin_bit_cast(u32x4, qf[rb][kk]), x);
+                unpack8(*reinterpret_cast<const u32x4*>(qp), y);
+                *reinterpret_cast<f32x4*>(c) = *reinterpret_cast<const f32x4*>(p.rcos + ci);
+                *reinterpret_cast<f32x4*>(c + 4) = *reinterpret_cast<const f32x4*>(p.rcos + ci + 4);
+                *reinterpret_cast<f32x4*>(sn) = *reinterpret_cast<const f32x4*>(p.rsin + ci);
+                *reinterpret_cast<f32x4*>(sn + 4) = *reinterpret_cast<const f32x4*>(p.rsin + ci + 4);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) x[e] = lo ? (x[e] * c[e] - y[e] * sn[e]) : (x[e] * c[e] + y[e] * sn[e]);
+                qf[rb][kk] = __builtin_bit_cast(bf16x8, pack8(x));
+            }
         }
 
     f32x4 o[QR][C::NB];
@@ -97,7 +119,24 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 
     // K/V tile kt+1 is fetched into registers while tile kt is multiplied
     u32x4 kreg[C::NK], vreg[C::NK];
+    constexpr int NR = ROPE ? (64 * (C::CPR / 2) + 255) / 256 : 1;  // (row, half-chunk) rotation items per thread per tile
+    f32x4 rc[NR][2], rs[NR][2];
     auto fetch = [&](int kt) {
+        if (ROPE) {
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int idx = it * 256 + tid;
+                const int row = idx / (C::CPR / 2), c = idx % (C::CPR / 2);
+                const int key = kt * 64 + row;
+                const bool ok = (idx < 64 * (C::CPR / 2)) && (key < Lk);
+                const long ci = (long)(k_beg + (ok ? key : 0)) * p.ld_cs + c * 8;
+#pragma unroll
+                for (int e = 0; e < 2; ++e) {
+                    rc[it][e] = ok ? *reinterpret_cast<const f32x4*>(p.rcos + ci + e * 4) : f32x4{1.f, 1.f, 1.f, 1.f};
+                    rs[it][e] = ok ? *reinterpret_cast<const f32x4*>(p.rsin + ci + e * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
+        }
 #pragma unroll
         for (int it = 0; it < C::NK; ++it) {
             const int idx = it * 256 + tid;
@@ -121,6 +160,28 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+        if (ROPE) {                                               // rotate the staged K tile in place (pairs d, d + D/2)
+#pragma unroll
+            for (int it = 0; it < NR; ++it) {
+                const int idx = it * 256 + tid;
+                if (idx < 64 * (C::CPR / 2)) {
+                    const int row = idx / (C::CPR / 2), c = idx % (C::CPR / 2);
+                    bf16_t* k1 = Ks + row * C::KROW + c * 8;
+                    float x1[8], x2[8], o1[8], o2[8];
+                    unpack8(*reinterpret_cast<const u32x4*>(k1), x1);
+                    unpack8(*reinterpret_cast<const u32x4*>(k1 + HALF), x2);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        const float cc = rc[it][e >> 2][e & 3], ss = rs[it][e >> 2][e & 3];
+                        o1[e] = x1[e] * cc - x2[e] * ss;
+                        o2[e] = x2[e] * cc + x1[e] * ss;
+                    }
+                    *reinterpret_cast<u32x4*>(k1) = pack8(o1);
+                    *reinterpret_cast<u32x4*>(k1 + HALF) = pack8(o2);
+                }
+            }
+            __syncthreads();
+        }
         if (kt + 1 < nkt) fetch(kt + 1);
         if (CAUSAL && kt * 64 > wq0 + 16 * QR - 1 + shift) continue;   // tile entirely above this wave's diagonal
 
@@ -587,7 +648,13 @@ extern "C" void padt_set_error(const char* msg);
 template <int D, bool CAUSAL, int QR>
 static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
     const int tiles = (max_seqlen_q + 64 * QR - 1) / (64 * QR);
-    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+    if constexpr (!CAUSAL && QR == 1 && D % 16 == 0) {
+        if (a.rcos) {
+            hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, true>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+            return;
+        }
+    }
+    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, false>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
 }
 
 // long segments, d <= 80: 32 query rows per wave (each K / V^T fragment read from LDS feeds two MFMAs); at d = 128 the
@@ -601,14 +668,20 @@ static void launch_attn(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hi
 
 extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                 void* o, long ldo, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q,
-                                int n_heads, int n_kv_heads, int head_dim, float scale, int causal) {
+                                int n_heads, int n_kv_heads, int head_dim, float scale, int causal, const void* rope_cos,
+                                const void* rope_sin, long ld_cs) {
     if (nseg <= 0 || max_seqlen_q <= 0) return 0;
+    if (rope_cos != nullptr && (rope_sin == nullptr || causal || max_seqlen_q >= 256 || (ld_cs & 3) || ((uintptr_t)rope_cos & 15) ||
+                                ((uintptr_t)rope_sin & 15) || cu_q != cu_k)) {
+        padt_set_error("padt_attn_varlen: fused RoPE needs self-attention (cu_q == cu_k), non-causal, max_seqlen_q < 256, 16-byte aligned fp32 tables");
+        return -1;
+    }
     if ((ldq & 7) || (ldk & 7) || (ldv & 7) || n_heads % n_kv_heads) {
         padt_set_error("padt_attn_varlen: strides must be multiples of 8 elements; heads % kv_heads == 0");
         return -1;
     }
     AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, cu_q, cu_k,
-               n_heads / n_kv_heads, scale * 1.4426950408889634f};
+               n_heads / n_kv_heads, scale * 1.4426950408889634f, (const float*)rope_cos, (const float*)rope_sin, ld_cs};
     hipStream_t s = (hipStream_t)stream;
 #define PADT_ATTN_CASE(DD)                                                         \
     case DD:                                                                       \

@@ -113,8 +113,9 @@ def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None,
     return out
 
 
-def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None):
-    """q/k/v/out: 2-D (tokens, row) bf16 views whose row holds the heads contiguously; cu_*: int32 device tensors."""
+def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None, rope=None):
+    """q/k/v/out: 2-D (tokens, row) bf16 views whose row holds the heads contiguously; cu_*: int32 device tensors.
+    rope=(cos, sin) fp32 [tokens][>= head_dim/2]: rotate q and k inside the kernel (self-attention, max_seqlen_q < 256)."""
     lib = _lib.load()
     _chk_bf16(q, k, v, out)
     assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
@@ -122,7 +123,8 @@ def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, hea
     scale = head_dim ** -0.5 if scale is None else scale
     _lib.check(lib.padt_attn_varlen(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
                                     out.stride(0), _p(cu_q), _p(cu_k), nseg, int(max_seqlen_q), n_heads, n_kv_heads,
-                                    head_dim, float(scale), 1 if causal else 0), "padt_attn_varlen")
+                                    head_dim, float(scale), 1 if causal else 0, _p(rope[0]) if rope else 0,
+                                    _p(rope[1]) if rope else 0, rope[0].stride(0) if rope else 0), "padt_attn_varlen")
     return out
 
 

@@ -115,8 +115,11 @@ class VisionEncoder:
             cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
             ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
             ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
-            ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)                 # q and k heads are adjacent
-            ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
+            fuse = (not full) and mx < 256 and hd % 16 == 0                    # window layers: RoPE inside the attention kernel
+            if not fuse:
+                ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)             # q and k heads are adjacent
+            ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd,
+                            rope=(plan.cos, plan.sin) if fuse else None)
             ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
             ops.row_rstd(x, out=rstd)
             ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)

@@ -43,7 +43,7 @@ def test_argument_validation_without_device(lib):
     # K not a multiple of 8 → -1 with a message, before any launch
     st = lib.padt_gemm_bf16(None, 16, 100, 16, 100, None, 16, 8, None, 0, 4, 8, 100, 0, 0, None)
     assert st == -1 and b"multiples of 8" in lib.padt_last_error()
-    st = lib.padt_attn_varlen(None, 16, 7, 16, 8, 16, 8, 16, 8, None, None, 1, 4, 2, 2, 80, 0.1, 0)
+    st = lib.padt_attn_varlen(None, 16, 7, 16, 8, 16, 8, 16, 8, None, None, 1, 4, 2, 2, 80, 0.1, 0, None, None, 0)
     assert st == -1
     st = lib.padt_decode_attn(None, 16, 16, 16, None, 16, 16, 1, 16, 2, 128, 100, 50, 0.1)   # s_max % 64 != 0
     assert st == -1

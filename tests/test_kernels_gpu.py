@@ -567,6 +567,28 @@ def test_vrt_head_tie_breaks_to_lowest_index(ops):
     assert int(st[2]) == 5
 
 
+@pytest.mark.parametrize("D,H", [(80, 4), (128, 2), (32, 3)])
+def test_attn_varlen_fused_rope_equals_rope_then_attention(ops, D, H):
+    """RoPE fused into the (window) attention kernel == rope_half on q,k followed by the plain kernel; ragged windows."""
+    lens = [64, 48, 36, 64, 7, 130]
+    T = sum(lens)
+    cu = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device="cuda")
+    qkv = rnd(T, 3 * H * D, seed=91)
+    ang = torch.rand(T, D // 2, device="cuda") * 40
+    emb = torch.cat([ang, ang], -1)
+    cos, sin = emb.cos().contiguous(), emb.sin().contiguous()
+    vh = H * D
+    ref_in = qkv.clone()
+    ops.rope_half_(ref_in, cos, sin, 2 * H, D)
+    ref = torch.zeros(T, vh, device="cuda", dtype=BF)
+    ops.attn_varlen(ref_in[:, :vh], ref_in[:, vh:2 * vh], ref_in[:, 2 * vh:], ref, cu, cu, max(lens), H, H, D)
+    got = torch.zeros_like(ref)
+    ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], got, cu, cu, max(lens), H, H, D, rope=(cos, sin))
+    assert torch.equal(got, ref), f"fused rope differs: max |d| {(got.float() - ref.float()).abs().max().item():.3e}"
+    with pytest.raises(Exception, match="fused RoPE"):
+        ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], got, cu, cu, 300, H, H, D, rope=(cos, sin))
+
+
 def test_mask_upsample_binarize_against_reference_expression(ops):
     """padt_mask_upsample_binarize vs F.interpolate(bilinear).sigmoid() > 0.5 on the golden inputs + a ragged extra case:
     up-sampled logits to fp32 rounding, binary masks identical wherever the logit is not within rounding of the threshold."""
