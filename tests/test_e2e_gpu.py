@@ -303,3 +303,36 @@ def test_postprocess_results_end_to_end(setup):
         assert (r["mask_logits_up"].abs().numpy()[diff] < 1e-5).all() and diff.sum() <= 1
         if not diff.any():
             assert g["rle"] == r["rle"]
+
+
+def test_early_eos_stop_rule_and_chunked_sync(setup):
+    """EOS before max_new_tokens: the output is trimmed right after the step in which the last sequence finished
+    (padt.py:756-757), identically for one-shot decode, chunked host syncs (sync_every) and a merged decode group."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=7, seed=7, ragged=True)
+    T = 12
+    sched = ["t", "t", "v", "v", "t", "e"] + ["t"] * (T - 6)          # EOS forced at step 5 → 6 tokens
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T,
+              schedule=sched)
+    a = model.generate(sync_every=T, **kw)
+    b = model.generate(sync_every=2, **kw)                           # host checks `unfinished` every 2 steps
+    c = model.generate(sync_every=2, use_graph=False, **kw)
+    L = ids.shape[1]
+    assert a.sequences.shape[1] == L + 6 and (a.sequences[:, -1] == cfg.eos_token_id).all()
+    assert torch.equal(a.sequences, b.sequences) and torch.equal(a.sequences, c.sequences)
+    assert len(a.hidden_states) == 6 and torch.equal(a.hidden_states.last_layer_rows(), b.hidden_states.last_layer_rows())
+    ores = U.O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, force_tokens=a.sequences.cpu()[:, L:])
+    assert ores["sequences"].shape == a.sequences.shape
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    ref = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=2)
+    got = []
+    for _ in range(3):
+        got += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched, sync_every=3)
+    got += runner.flush()
+    assert len(got) == 3
+    for d, c1, l1, v1 in got:
+        assert c1 == ref[1] and v1 == ref[3] and torch.equal(d["pred_boxes"], ref[0]["pred_boxes"])
