@@ -42,7 +42,8 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="sequential mode only: launch decode steps eagerly (profiling aid)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
     ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
-    ap.add_argument("--timeline", action="store_true", help="print a stream timeline of 4 pipelined steps to stderr")
+    ap.add_argument("--timeline", action="store_true", help="print a stream timeline of pipelined steps to stderr")
+    ap.add_argument("--timeline-steps", type=int, default=4)
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight on separate HIP streams (1 = no overlap)")
     return ap.parse_args()
@@ -348,13 +349,13 @@ def main():
         runner.trace = []
         torch.cuda.synchronize()
         w0 = time.perf_counter()
-        run_steps(4)
+        run_steps(args.timeline_steps)
         torch.cuda.synchronize()
         wall = (time.perf_counter() - w0) * 1e3
         base = runner.trace[0][2]
         marks = sorted(((base.elapsed_time(e), b, tag) for b, tag, e in runner.trace))
         b0 = runner.trace[0][0]
-        print(f"[timeline] 4 steps, wall {wall:.1f} ms", file=sys.stderr)
+        print(f"[timeline] {args.timeline_steps} steps, wall {wall:.1f} ms", file=sys.stderr)
         for t, b, tag in marks:
             print(f"[timeline] {t:8.2f} ms  batch {b - b0}  {tag}", file=sys.stderr)
         runner.trace = None
