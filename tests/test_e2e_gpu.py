@@ -336,3 +336,27 @@ def test_early_eos_stop_rule_and_chunked_sync(setup):
     assert len(got) == 3
     for d, c1, l1, v1 in got:
         assert c1 == ref[1] and v1 == ref[3] and torch.equal(d["pred_boxes"], ref[0]["pred_boxes"])
+
+
+def test_from_pretrained_directory_round_trip(setup, tmp_path):
+    """from_pretrained(config.json + *.safetensors with the checkpoint's key names) builds the same model as the in-memory
+    constructor: identical sequences and boxes (the drop-in construction surface, test_demo.py:20-25)."""
+    cfg, w, model, U, oc = setup
+    import json
+    from safetensors.torch import save_file
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    save_file({k: v.to(torch.bfloat16).contiguous() for k, v in w.items()}, str(tmp_path / "model.safetensors"))
+    json.dump(cfg.to_dict(), open(tmp_path / "config.json", "w"))
+    m2 = PaDTForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16,
+                                                      attn_implementation="flash_attention_2", device_map={"": 0})
+    assert m2.config.vision_config.spatial_merge_size == 2 and m2.model.embed_tokens.weight.shape[0] == cfg.vocab_size
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=7, seed=3, ragged=True)
+    T = 8
+    sched = U.rec_schedule(T, vrt_at=range(2, 5))
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T,
+              schedule=sched)
+    a, b = model.generate(**kw), m2.generate(**kw)
+    assert torch.equal(a.sequences, b.sequences)
+    assert torch.equal(a.hidden_states.last_layer_rows(), b.hidden_states.last_layer_rows())
+    with pytest.raises(FileNotFoundError):
+        PaDTForConditionalGeneration.from_pretrained(str(tmp_path / "missing"))
