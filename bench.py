@@ -30,14 +30,14 @@ HBM_PEAK_GBS = 8000.0
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--steps", type=int, default=64)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tnew", type=int, default=28)
     ap.add_argument("--model", default="3b", choices=["3b", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--merge", type=int, default=4, help="consecutive batches of 8 whose decode steps share one session "
+    ap.add_argument("--merge", type=int, default=8, help="consecutive batches of 8 whose decode steps share one session "
                     "(in-flight batching; 1 = every batch decodes alone)")
     ap.add_argument("--no-graph", action="store_true", help="sequential mode only: launch decode steps eagerly (profiling aid)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
