@@ -279,7 +279,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 template <int MT, int NT, int NW, int EPI, bool OUT_F32, bool NORM, bool PACKED>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float norm_eps) {
     __shared__ __attribute__((aligned(16))) float red[NW - 1][NT * MT][64][4];
+    __shared__ __attribute__((aligned(16))) float red0[NT * (MT > 1 ? MT - 1 : 1)][64][4];
     __shared__ float ssq[NW][MT][16];
+    __shared__ int flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
@@ -359,56 +361,80 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             if (fq == 0) ssq[wave][j][frow] = t;
         }
     }
+    // Cross-wave reduction + epilogue, spread over the waves: wave j (< MT) sums the NW partials of batch row block j and
+    // runs its epilogue — with 64 decode rows the tail is as long as the K loop, one wave doing all of it left the other
+    // waves of the block idle.  Partials are summed in wave order (the order the single-wave version used).
+    constexpr int NWK = NW - 1;
+    const bool worker = wave < MT;
     if (wave > 0) {
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 1][i * MT + j][lane][0]) = acc[i][j];
     }
-    __syncthreads();
-    if (wave == 0) {
+    if (MT > 1 && wave == 0) {                                    // wave 0's partials of the row blocks other waves finish
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < MT; ++j)
+            for (int j = 1; j < MT; ++j) *reinterpret_cast<f32x4*>(&red0[i * (MT - 1) + (j - 1)][lane][0]) = acc[i][j];
+    }
+    __syncthreads();
+    f32x4 sum[NT];
+    const int jw = worker ? wave : 0;                             // row block this wave finishes
+    if (worker) {
 #pragma unroll
-                for (int w = 0; w < NW - 1; ++w) acc[i][j] += *reinterpret_cast<f32x4*>(&red[w][i * MT + j][lane][0]);
-        if (!NORM && gridDim.y > 1) {
-            // the last of the n-block's split blocks to arrive sums the partials and runs the epilogue
-            const int S = gridDim.y;
+        for (int i = 0; i < NT; ++i) {
+            sum[i] = (wave == 0) ? acc[i][0] : *reinterpret_cast<f32x4*>(&red0[i * (MT - 1) + (jw - 1)][lane][0]);
+#pragma unroll
+            for (int w = 0; w < NWK; ++w) sum[i] += *reinterpret_cast<f32x4*>(&red[w][i * MT + jw][lane][0]);
+        }
+    }
+    if (!NORM && gridDim.y > 1) {
+        // split-K: the last of the n-block's split blocks to arrive sums the partials and runs the epilogue
+        const int S = gridDim.y;
+        if (worker) {
             float* mine = p.ws + (((long)(blockIdx.x * S + blockIdx.y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-            for (int i = 0; i < NT * MT; ++i)
+            for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st_agent(mine + i * 256 + r, acc[i / MT][i % MT][r]);
-            if (!handoff_arrive(&p.ticket[blockIdx.x], S, lane)) return;
+                for (int r = 0; r < 4; ++r) st_agent(mine + (i * MT + jw) * 256 + r, sum[i][r]);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores are acknowledged
+        }
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(&p.ticket[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            const int last = (old == S - 1);
+            if (last) __hip_atomic_store(&p.ticket[blockIdx.x], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            flag = last;
+        }
+        __syncthreads();
+        if (!flag) return;
+        if (worker) {
             for (int y = 0; y < S; ++y) {
                 if (y == (int)blockIdx.y) continue;
                 const float* other = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                for (int i = 0; i < NT * MT; ++i)
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) acc[i / MT][i % MT][r] += ld_agent(other + i * 256 + r);
+                    for (int r = 0; r < 4; ++r) sum[i][r] += ld_agent(other + (i * MT + jw) * 256 + r);
             }
         }
+    }
+    if (!worker) return;
+    const int m = jw * 16 + frow;
+    if (NORM) {
+        float t = 0.f;
 #pragma unroll
-        for (int j = 0; j < MT; ++j) {
-            const int m = j * 16 + frow;
-            if (NORM) {
-                float t = 0.f;
+        for (int w = 0; w < NW; ++w) t += ssq[w][jw][frow];
+        const float rstd = rsqrtf(t / (float)p.K + norm_eps);
 #pragma unroll
-                for (int w = 0; w < NW; ++w) t += ssq[w][j][frow];
-                const float rstd = rsqrtf(t / (float)p.K + norm_eps);
+        for (int i = 0; i < NT; ++i) sum[i] *= rstd;
+    }
+    if (EPI == EPI_SWIGLU) {
+        store_swiglu(p, m, n0 + fq * 4, sum[0], sum[NT - 1]);
+    } else {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] *= rstd;
-            }
-            if (EPI == EPI_SWIGLU) {
-                store_swiglu(p, m, n0 + fq * 4, acc[0][j], acc[NT - 1][j]);
-            } else {
-#pragma unroll
-                for (int i = 0; i < NT; ++i) store_frag<EPI, OUT_F32>(p, m, n0 + i * 16 + fq * 4, acc[i][j]);
-            }
-        }
+        for (int i = 0; i < NT; ++i) store_frag<EPI, OUT_F32>(p, m, n0 + i * 16 + fq * 4, sum[i]);
     }
 }
 

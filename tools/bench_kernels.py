@@ -51,6 +51,10 @@ def main():
         ws = [torch.randn(N, K, device="cuda").to(BF) * 0.02 for _ in range(int(os.environ.get('ROT', 6)))]   # rotate weights: defeat L2/MALL reuse
         out = torch.zeros(B, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
         i = [0]
+        B16 = (B + 15) // 16 * 16
+        a_pk = torch.zeros(B16, K, device="cuda", dtype=BF)
+        ops.pack_rows(a, a_pk, B, to_packed=True)
+        out_pk = torch.zeros(B16, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
         split = int(os.environ.get("SPLIT_" + name.upper(), 1))
         ws_split = ops.new_splitk_workspace(N, max(split, 2), "cuda")
 
@@ -62,6 +66,13 @@ def main():
                     ops.gemm(a, w, out=out, epilogue=2, residual=out)
                 else:
                     ops.gemm_rmsnorm(a, w, out=out, epilogue=epi)
+            elif os.environ.get("PACK"):                          # fragment-packed activations, as the decode step runs them
+                if epi == 2:
+                    ops.gemm_packed(a_pk, w, N, out=out_pk, epilogue=2, residual=out_pk, split_k=split, workspace=ws_split,
+                                    a_packed=True, c_packed=True, rows=B)
+                else:
+                    ops.gemm_packed(a_pk, w, N, out=out_pk if epi == 3 else out, epilogue=epi, norm_eps=1e-6, a_packed=True,
+                                    c_packed=(epi == 3), rows=B)
             elif epi == 2:
                 ops.gemm_packed(a, w, N, out=out, epilogue=2, residual=out, split_k=split, workspace=ws_split)
             else:
