@@ -137,11 +137,15 @@ int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask
 /* ---- VRT head + greedy bookkeeping ------------------------------------------------------------------------------------
  * logits = hidden · [embed_table ‖ proto]^T through two base pointers, -inf outside text ∪ own patch rows, per-block
  * (max, argmax) partials; optional dense fp32 logits.  padt.py:292-301.  mode_table/step: scripted logits-processor
- * slot for synthetic weights (0 free, 1 text rows, 2 own VRT rows, 3 force EOS), padt.py:717. */
+ * slot for synthetic weights (0 free, 1 text rows, 2 own VRT rows, 3 force EOS), padt.py:717.
+ * embed_table_packed (nullable): fragment-packed copy of embed_table ([vocab/16][D/32][64][8], as padt_gemm_packed_bf16's
+ * weights); when given, `hidden` must be in the 16-row fragment-packed activation layout (ldh = D) and text rows are
+ * streamed as 1 KiB contiguous wave loads (0.62 GB per step is the decode step's largest single read). */
 long padt_vrt_head_nblk(long vocab, long n_proto);
 int  padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab, const void* proto,
                    long n_proto, const int* vrt_off, const int* mode_table, const int* step, void* logits_f32,
-                   long ld_logits, void* part_val, void* part_idx, long batch, long D, int eos);
+                   long ld_logits, void* part_val, void* part_idx, long batch, long D, int eos,
+                   const void* embed_table_packed);
 /* argmax reduction (ties → lowest id), pad/EOS bookkeeping, token append, hidden-row stash, slot/len/position/step
  * advance — all on device.  padt.py:745-757, 732-737. */
 int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D, int eos,

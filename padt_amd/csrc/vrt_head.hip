@@ -12,6 +12,7 @@
 // (padt_processor.py:125), advance cache slots / rope positions / step counter — all on device, so a decode step is one
 // replayable hipGraph.
 #include "common.h"
+#include <cstdint>
 
 extern "C" void padt_set_error(const char* msg);
 
@@ -25,86 +26,91 @@ struct HeadArgs {
     float* logits; long ldl;           // optional [B][V+NP]
     float* part_val; int* part_idx;    // [nblk][16*MT]
     int B, D, eos;
+    const bf16_t* Ep;                  // optional fragment-packed copy of E (PACKED kernels; h is then packed too)
 };
 
-template <int MT>
+// PACKED: text rows come from a fragment-packed copy of the table ([V/16][D/32][64 lanes][8], ops.pack_weight — every wave
+// load is 1 KiB contiguous) and the hidden rows from the 16-row fragment-packed activation layout; prototype rows (rebuilt
+// per batch) stay row-major.  Waves take groups of U consecutive K-steps; wave j (< MT) finishes sample block j.
+template <int MT, bool PACKED>
 __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[3][MT][64][4];
+    __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * 16;
     const int NT = p.V + p.NP;
     int n = n0 + frow;
     n = n < NT ? n : NT - 1;
+    const bool in_text = PACKED && (n0 + 16 <= p.V);              // whole block inside the packed text table
     const bf16_t* wrow = (n < p.V) ? p.E + (long)n * p.D : p.proto + (long)(n - p.V) * p.D;
+    const bf16_t* wpk = PACKED ? p.Ep + (long)(n0 >> 4) * (p.D >> 5) * 512 + lane * 8 : nullptr;
     const bf16_t* xrow[MT];
     bool xok[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = j * 16 + frow;
-        xok[j] = m < p.B;
-        xrow[j] = p.h + (long)(xok[j] ? m : 0) * p.ldh;
+        xok[j] = PACKED ? true : (m < p.B);
+        xrow[j] = PACKED ? p.h + (long)j * 16 * p.ldh + lane * 8 : p.h + (long)(m < p.B ? m : 0) * p.ldh + fq * 8;
     }
+    const int xstep = PACKED ? 512 : 32;
     f32x4 acc[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nks = (p.D + 31) / 32;
     constexpr int U = 4;
-    for (int ks0 = wave; ks0 < nks; ks0 += 4 * U) {
+    for (int g0 = wave; g0 * U < nks; g0 += 4) {
         bf16x8 wf[U], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ks = ks0 + u * 4;
+            const int ks = g0 * U + u;
             const int k = ks * 32 + fq * 8;
             const bool kok = (ks < nks) && (k < p.D);
-            wf[u] = kok ? ld_frag(wrow + k) : zero_frag();
+            if (PACKED && in_text) wf[u] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wpk + (long)ks * 512)) : zero_frag();
+            else wf[u] = kok ? ld_frag(wrow + k) : zero_frag();
 #pragma unroll
-            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + k) : zero_frag();
+            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
         }
 #pragma unroll
         for (int u = 0; u < U; ++u)
 #pragma unroll
             for (int j = 0; j < MT; ++j) acc[j] = mfma16(wf[u], xf[u][j], acc[j]);
     }
-    if (wave > 0) {
 #pragma unroll
-        for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 1][j][lane][0]) = acc[j];
-    }
+    for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
     __syncthreads();
-    if (wave != 0) return;
+    if (wave >= MT) return;
+    const int j = wave;                                       // sample block this wave finishes
+    f32x4 sum = *reinterpret_cast<f32x4*>(&red[0][j][lane][0]);
+#pragma unroll
+    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
     const int mode = (p.mode_table && p.step) ? p.mode_table[*p.step] : 0;
+    const int m = j * 16 + frow;                              // sample
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    int lo = 0, hi = 0;
+    if (m < p.B) { lo = p.vrt_off[m]; hi = p.vrt_off[m + 1]; }
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-#pragma unroll
-        for (int w = 0; w < 3; ++w) acc[j] += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
-        const int m = j * 16 + frow;                      // sample
-        float best = -INFINITY;
-        int bidx = 0x7fffffff;
-        int lo = 0, hi = 0;
-        if (m < p.B) { lo = p.vrt_off[m]; hi = p.vrt_off[m + 1]; }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            const int row = n0 + fq * 4 + r;
-            bool ok = (m < p.B) && (row < NT);
-            if (ok) {
-                if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
-                else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
-            }
-            const float v = ok ? acc[j][r] : -INFINITY;
-            if (p.logits && m < p.B && row < NT) p.logits[(long)m * p.ldl + row] = v;
-            if (v > best) { best = v; bidx = row; }      // rows ascend with r → first max wins
+    for (int r = 0; r < 4; ++r) {
+        const int row = n0 + fq * 4 + r;
+        bool ok = (m < p.B) && (row < NT);
+        if (ok) {
+            if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
+            else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
         }
-        // combine the 4 lanes (fq = 0..3) that hold the same sample
+        const float v = ok ? sum[r] : -INFINITY;
+        if (p.logits && m < p.B && row < NT) p.logits[(long)m * p.ldl + row] = v;
+        if (v > best) { best = v; bidx = row; }               // rows ascend with r → first max wins
+    }
+    // combine the 4 lanes (fq = 0..3) that hold the same sample
 #pragma unroll
-        for (int off = 16; off <= 32; off <<= 1) {
-            const float ov = __shfl_xor(best, off, 64);
-            const int oi = __shfl_xor(bidx, off, 64);
-            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-        }
-        if (fq == 0 && m < p.B) {
-            p.part_val[(long)blockIdx.x * p.B + m] = best;
-            p.part_idx[(long)blockIdx.x * p.B + m] = bidx;
-        }
+    for (int off = 16; off <= 32; off <<= 1) {
+        const float ov = __shfl_xor(best, off, 64);
+        const int oi = __shfl_xor(bidx, off, 64);
+        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+    }
+    if (fq == 0 && m < p.B) {
+        p.part_val[(long)blockIdx.x * p.B + m] = best;
+        p.part_idx[(long)blockIdx.x * p.B + m] = bidx;
     }
 }
 
@@ -170,17 +176,25 @@ extern "C" long padt_vrt_head_nblk(long vocab, long n_proto) { return (vocab + n
 extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
                              const void* proto, long n_proto, const int* vrt_off, const int* mode_table,
                              const int* step, void* logits_f32, long ld_logits, void* part_val, void* part_idx,
-                             long batch, long D, int eos) {
+                             long batch, long D, int eos, const void* embed_table_packed) {
     if (batch <= 0) return 0;
     if (batch > 64 || (D & 7) || (ldh & 7)) { padt_set_error("padt_vrt_head: batch <= 64, D % 8 == 0 required"); return -1; }
+    if (embed_table_packed && ((D & 31) || (vocab & 15) || ((uintptr_t)embed_table_packed & 15) || ((uintptr_t)hidden & 15))) {
+        padt_set_error("padt_vrt_head: the packed path needs D % 32 == 0, vocab % 16 == 0 and 16-byte aligned pointers");
+        return -1;
+    }
     HeadArgs a{(const bf16_t*)hidden, ldh, (const bf16_t*)embed_table, (int)vocab, (const bf16_t*)proto, (int)n_proto,
                vrt_off, mode_table, step, (float*)logits_f32, ld_logits, (float*)part_val, (int*)part_idx, (int)batch,
-               (int)D, eos};
+               (int)D, eos, (const bf16_t*)embed_table_packed};
     const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
     hipStream_t s = (hipStream_t)stream;
-    if (batch <= 16) hipLaunchKernelGGL(vrt_head_kernel<1>, dim3(nblk), dim3(256), 0, s, a);
-    else if (batch <= 32) hipLaunchKernelGGL(vrt_head_kernel<2>, dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(vrt_head_kernel<4>, dim3(nblk), dim3(256), 0, s, a);
+    if (embed_table_packed) {
+        if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, true>), dim3(nblk), dim3(256), 0, s, a);
+        else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, true>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vrt_head_kernel<4, true>), dim3(nblk), dim3(256), 0, s, a);
+    } else if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, false>), dim3(nblk), dim3(256), 0, s, a);
+    else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, false>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrt_head_kernel<4, false>), dim3(nblk), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

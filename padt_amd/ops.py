@@ -283,13 +283,16 @@ def vrt_head_nblk(vocab, n_proto):
     return _lib.load().padt_vrt_head_nblk(vocab, n_proto)
 
 
-def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=None, step=None, logits=None):
+def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=None, step=None, logits=None,
+             table_packed=None, rows=None):
+    """table_packed: pack_weight(table) — then `hidden` is a fragment-packed activation buffer holding `rows` valid rows."""
     lib = _lib.load()
-    _chk_bf16(hidden, table, proto)
+    _chk_bf16(hidden, table, proto, table_packed)
+    B = hidden.shape[0] if rows is None else rows
     _lib.check(lib.padt_vrt_head(_stream(), _p(hidden), hidden.stride(0), _p(table), table.shape[0], _p(proto),
                                  proto.shape[0], _p(vrt_off), _p(mode_table), _p(step), _p(logits),
                                  logits.stride(0) if logits is not None else 0, _p(part_val), _p(part_idx),
-                                 hidden.shape[0], hidden.shape[1], eos), "padt_vrt_head")
+                                 B, hidden.shape[1], eos, _p(table_packed)), "padt_vrt_head")
 
 
 def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens_out, cur_tok, step, slot, lens, pos3,

@@ -258,6 +258,10 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         d = f"llm.{i}."
         for nm in ("qkv", "o", "gu", "down"):
             W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
+    # fragment-packed copy of the head table for the decode-step logit head (+0.62 GB at 3B; the row-major table stays: it is
+    # the embedding table too, and the prefill-side gathers read rows)
+    if cfg.vocab_size % 16 == 0 and cfg.hidden_size % 32 == 0 and os.environ.get("PADT_HEAD_PACKED", "1") != "0":
+        W["llm.head.wp"] = pack_weight(W["llm.head"])
     put("llm.norm", get("model.norm.weight"))
     W["llm.ones"] = torch.ones(cfg.hidden_size, device=dev, dtype=BF16)
     if cfg.use_visual_prototype_projection:

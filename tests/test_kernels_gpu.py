@@ -547,6 +547,35 @@ def test_vrt_head_and_greedy(ops, B):
     assert not exp_unf.any()                                        # step 3 forced EOS everywhere
 
 
+@pytest.mark.parametrize("B", [5, 20, 40])
+def test_vrt_head_packed_table_is_bit_identical(ops, B):
+    """Fragment-packed text table + packed hidden rows == the row-major call: same partial (max, argmax) and logits."""
+    V, D, per = 3008, 256, 23                                      # V % 16 == 0 (the packed path's requirement)
+    NP = B * per
+    E, P, h = rnd(V, D, seed=95), rnd(NP, D, seed=96), rnd(B, D, seed=97)
+    off = torch.arange(0, NP + 1, per, dtype=torch.int32, device="cuda")
+    nblk = ops.vrt_head_nblk(V, NP)
+    res = []
+    B16 = (B + 15) // 16 * 16
+    hp = torch.zeros(B16, D, device="cuda", dtype=BF)
+    ops.pack_rows(h, hp, B, to_packed=True)
+    Ep = ops.pack_weight(E)
+    for packed in (False, True):
+        pv = torch.zeros(nblk * B, device="cuda")
+        pi = torch.zeros(nblk * B, dtype=torch.int32, device="cuda")
+        lg = torch.zeros(B, V + NP, device="cuda")
+        if packed:
+            ops.vrt_head(hp, E, P, off, pv, pi, 7, logits=lg, table_packed=Ep, rows=B)
+        else:
+            ops.vrt_head(h, E, P, off, pv, pi, 7, logits=lg)
+        res.append((pv, pi, lg))
+    for a, b in zip(res[0], res[1]):
+        assert torch.equal(a, b)
+    full = h.float() @ torch.cat([E, P]).float().T
+    fin = torch.isfinite(res[1][2])
+    close_f32(res[1][2][fin], full[fin], "packed head logits", rel=2e-5)
+
+
 def test_vrt_head_tie_breaks_to_lowest_index(ops):
     V, D = 64, 64
     E = torch.zeros(V, D, device="cuda", dtype=BF)

@@ -104,6 +104,11 @@ def main():
     pi = torch.zeros(nblk * B, dtype=torch.int32, device="cuda")
     t = timeit(lambda: ops.vrt_head(hid, table, proto, voff, pv, pi, 151645), 50)
     print(f"vrt_head B={B}: {t:7.2f} us  {(table.numel() + proto.numel()) * 2 / t * 1e-3:7.1f} GB/s")
+    tp = ops.pack_weight(table)
+    hp = torch.zeros((B + 15) // 16 * 16, 2048, device="cuda", dtype=BF)
+    ops.pack_rows(hid, hp, B, to_packed=True)
+    t = timeit(lambda: ops.vrt_head(hp, table, proto, voff, pv, pi, 151645, table_packed=tp, rows=B), 50)
+    print(f"vrt_head packed B={B}: {t:7.2f} us  {(table.numel() + proto.numel()) * 2 / t * 1e-3:7.1f} GB/s")
     # pure streaming read reference: torch sum over a 45 MB bf16 tensor
     big = [torch.randn(2048, 11008, device="cuda").to(BF) for _ in range(6)]
     i = [0]
