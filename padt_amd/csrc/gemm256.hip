@@ -292,6 +292,40 @@ static void launch256_mf(const Gemm256Args& a, hipStream_t s) {
 // shorter tiles (fewer MFMAs per staged B half-tile).  A ragged last tile row of <= 64 rows can be PEELED off (returned to
 // the caller, who streams it through the skinny kernel) when that saves a whole round: the ViT gate/up GEMM is
 // 16928 = 66 x 256 + 32 rows x 27 tile columns → 1809 tiles = 8 rounds, 1782 tiles = 7 rounds without the 32-row tail.
+struct Plan256 { double cost; int mf; long rows; };
+
+static Plan256 plan256(long M, long N, long K, int force_mf, bool allow_peel, bool force_peel) {
+    const long ntn = (N + TN - 1) / TN;
+    Plan256 best{1e30, 4, M};
+    const double penalty[5] = {0, 0, 1.35, 1.12, 1.0};           // measured at 8192^3: 980 / 1163 / 1349 TFLOP/s
+    for (int mf = 4; mf >= 2; --mf) {
+        if (force_mf >= 2 && force_mf <= 4 && mf != force_mf) continue;
+        const long th = 64 * mf;
+        const long tiles = ((M + th - 1) / th) * ntn;
+        double cost = (double)((tiles + 255) / 256) * mf * penalty[mf];
+        long rows = M;
+        const long tail = M % th;
+        if (allow_peel && tail > 0 && tail <= 64 && M > th) {
+            // skinny pass over `tail` rows ≈ 6 us + N*K*2 B at 4 TB/s; one cost unit = a 64-row tile slab ≈ K * 0.0082 us
+            const double skinny_units = (6.0 + (double)N * K * 2.0 / 4.0e6) / (K * 0.0082);
+            const double c2 = (double)(((M / th) * ntn + 255) / 256) * mf * penalty[mf] + skinny_units;
+            if (c2 < cost || force_peel) { cost = c2; rows = M - tail; }
+        }
+        if (cost < best.cost - 1e-9) best = Plan256{cost, mf, rows};
+    }
+    return best;
+}
+
+template <int EPI, bool F32>
+static void run256(Gemm256Args a, int mf, hipStream_t s) {
+    if (mf == 4) launch256_mf<EPI, F32, 4>(a, s);
+    else if (mf == 3) launch256_mf<EPI, F32, 3>(a, s);
+    else launch256_mf<EPI, F32, 2>(a, s);
+}
+
+// A second way out of a mostly empty last round: split the COLUMNS.  The prefill gate/up GEMM is 19 x 86 tiles = 6.4 rounds
+// of 256-row tiles; its first 80 tile columns are 5.94 rounds and the remaining 6 columns run as one round of 128-row
+// tiles (222 of them) — two launches, 6 + 0.68 round-equivalents instead of 7.
 template <int EPI, bool F32>
 static long launch256(Gemm256Args a, hipStream_t s) {
     const char* fe = getenv("PADT_GEMM_MF");                      // tuning / test knobs, read per call
@@ -299,31 +333,39 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     const char* pe = getenv("PADT_GEMM_PEEL");
     const bool allow_peel = pe ? atoi(pe) != 0 : true;            // 0 never, 1 cost model (default), 2 always when a tail exists (tests)
     const bool force_peel = pe && atoi(pe) == 2;
+    const char* ce = getenv("PADT_GEMM_COLSPLIT");                // 0 never, 1 cost model (default), >= 2: always peel that many tile columns (tests)
+    const int colsplit = ce ? atoi(ce) : 1;
     const long ntn = (a.N + TN - 1) / TN;
-    int best = 4;
-    long best_rows = a.M;
-    double best_cost = 1e30;
-    const double penalty[5] = {0, 0, 1.35, 1.12, 1.0};           // measured at 8192^3: 980 / 1163 / 1349 TFLOP/s
-    for (int mf = 4; mf >= 2; --mf) {
-        if (force >= 2 && force <= 4 && mf != force) continue;
-        const long th = 64 * mf;
-        const long tiles = ((a.M + th - 1) / th) * ntn;
-        double cost = (double)((tiles + 255) / 256) * mf * penalty[mf];
-        long rows = a.M;
-        const long tail = a.M % th;
-        if (allow_peel && tail > 0 && tail <= 64 && a.M > th) {
-            // skinny pass over `tail` rows ≈ 6 us + N*K*2 B at 4 TB/s; one cost unit = a 64-row tile slab ≈ K * 0.0082 us
-            const double skinny_units = (6.0 + (double)a.N * a.K * 2.0 / 4.0e6) / (a.K * 0.0082);
-            const double c2 = (double)(((a.M / th) * ntn + 255) / 256) * mf * penalty[mf] + skinny_units;
-            if (c2 < cost || force_peel) { cost = c2; rows = a.M - tail; }
+    const Plan256 whole = plan256(a.M, a.N, a.K, force, allow_peel, force_peel);
+    long split_cols = 0;
+    Plan256 pm = whole, pr = whole;
+    if (colsplit != 0 && ntn >= 4 && a.N % TN == 0 && whole.rows == a.M) {
+        double best_total = whole.cost;
+        for (long c = 1; c <= 16 && c < ntn - 1; ++c) {
+            if (colsplit >= 2 && c != colsplit) continue;
+            const Plan256 m1 = plan256(a.M, (ntn - c) * TN, a.K, force, false, false);
+            const Plan256 r1 = plan256(a.M, c * TN, a.K, force, false, false);
+            const double total = m1.cost + r1.cost + 0.15;        // + a launch
+            if (total < best_total - 1e-9 || colsplit >= 2) { best_total = total; split_cols = c; pm = m1; pr = r1; }
         }
-        if (cost < best_cost - 1e-9) { best_cost = cost; best = mf; best_rows = rows; }
     }
-    a.M = (int)best_rows;
-    if (best == 4) launch256_mf<EPI, F32, 4>(a, s);
-    else if (best == 3) launch256_mf<EPI, F32, 3>(a, s);
-    else launch256_mf<EPI, F32, 2>(a, s);
-    return best_rows;
+    if (split_cols == 0) {
+        a.M = (int)whole.rows;
+        run256<EPI, F32>(a, whole.mf, s);
+        return whole.rows;
+    }
+    const long n1 = (ntn - split_cols) * TN;                      // weight rows (= pre-epilogue columns) of the first launch
+    const long c1 = (EPI == EPI_SWIGLU) ? n1 / 2 : n1;            // output columns it writes
+    Gemm256Args a1 = a, a2 = a;
+    a1.N = (int)n1;
+    a2.N = a.N - (int)n1;
+    a2.W = a.W + n1 * a.ldw;
+    if (a.bias) a2.bias = a.bias + n1;
+    a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((bf16_t*)a.C + c1);
+    if (a.R) a2.R = a.R + c1;
+    run256<EPI, F32>(a1, pm.mf, s);
+    run256<EPI, F32>(a2, pr.mf, s);
+    return a.M;
 }
 
 // Called by padt_gemm_bf16's dispatcher (gemm.hip) for shapes where the 256^2 tiling pays; arguments already validated.

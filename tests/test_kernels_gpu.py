@@ -138,6 +138,26 @@ def test_gemm_row_scale_is_folded_rmsnorm(ops, M, N, K):
         close_bf16(ops.gemm(x, wi, bi, epilogue=ops.EPI_SWIGLU, row_scale=rstd), ref, f"row_scale swiglu {M}x{N}x{K}")
 
 
+def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
+    """Column-split dispatch (last tile columns as a second launch with its own tile height) == the single launch."""
+    M, N, K = 1100, 1536, 640
+    a, w, b, r = rnd(M, K, seed=55), rnd(N, K, scale=0.05, seed=56), rnd(N, seed=57), rnd(M, N, seed=58)
+    wi = interleave_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous())
+    rstd = ops.row_rstd(a)
+    outs = {}
+    for cs in ("0", "2", "3"):
+        monkeypatch.setenv("PADT_GEMM_COLSPLIT", cs)
+        o1 = r.clone()
+        ops.gemm(a, w, b, out=o1, epilogue=ops.EPI_RESID, residual=o1)
+        o32 = torch.zeros((M, N), device="cuda", dtype=torch.float32)
+        ops.gemm(a, w, b, out=o32, out_f32=True, row_scale=rstd)
+        outs[cs] = (o1, ops.gemm(a, wi, b, epilogue=ops.EPI_SWIGLU, row_scale=rstd), o32)
+    for cs in ("2", "3"):
+        for x0, x1 in zip(outs["0"], outs[cs]):
+            assert torch.equal(x0, x1)
+    close_bf16(outs["2"][0], a.float() @ w.float().T + b.float() + r.float(), "column split resid")
+
+
 @pytest.mark.parametrize("M", [7, 40, 700])
 def test_gemm_epilogues(ops, M):
     K, N = 256, 384
