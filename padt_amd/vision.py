@@ -115,7 +115,9 @@ class VisionEncoder:
             cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
             ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
             ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
-            fuse = (not full) and mx < 256 and hd % 16 == 0                    # window layers: RoPE inside the attention kernel
+            # attn_varlen can rotate q / k itself (rope=), but for the single-tile window segments that lengthens the one
+            # latency chain the kernel consists of: measured 81 us fused vs 31 (rope_half) + 38 (attention) → not used here
+            fuse = False
             if not fuse:
                 ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)             # q and k heads are adjacent
             ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd,
