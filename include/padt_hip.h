@@ -161,6 +161,13 @@ int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj
                                 long out_ld_row, void* up_f32, long up_ld_obj, long up_ld_row, int n_obj, int max_dst_h,
                                 int max_dst_w);
 
+/* ---- image front-end tail ------------------------------------------------------------------ */
+/* uint8 (H, W, 3) image (already resized; H, W multiples of patch*merge) → (H/patch * W/patch) rows of 3*temporal*patch*patch
+ * values in (h/merge, w/merge, merge, merge) block-major patch order, each = lut[c][byte] (fp32 3 x 256 table holding the
+ * processor's rescale + normalize), fp32 or bf16.  HF Qwen2-VL image processor: _preprocess / patchify. */
+int padt_patchify_normalize(void* stream, const void* img_u8, int H, int W, const void* lut_f32, void* out, long ld_out,
+                            int out_bf16, int patch, int merge, int temporal);
+
 #ifdef __cplusplus
 }
 #endif

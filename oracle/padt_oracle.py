@@ -717,6 +717,50 @@ def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Seq
     return res
 
 
+# ---------------------------------------------------------------------------------------------------------------------
+# Image front-end: the HF Qwen2-VL image processor the reference calls through AutoProcessor
+# (transformers/models/qwen2_vl/image_processing_pil_qwen2_vl.py: smart_resize, _preprocess, patchify; arithmetic of
+# image_transforms.rescale / normalize).  Pinned against the INSTALLED transformers 5.15 PIL processor
+# (tests/golden/make_golden_pre.py); the reference pins 4.50.0, whose processor is not in the container (parity with 4.50
+# unpinned).  The bicubic resize itself is PIL's and is not restated.
+def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
+    if max(height, width) / min(height, width) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
+    h_bar = round(height / factor) * factor
+    w_bar = round(width / factor) * factor
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((height * width) / max_pixels)
+        h_bar = max(factor, math.floor(height / beta / factor) * factor)
+        w_bar = max(factor, math.floor(width / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (height * width))
+        h_bar = math.ceil(height * beta / factor) * factor
+        w_bar = math.ceil(width * beta / factor) * factor
+    return h_bar, w_bar
+
+
+IMAGE_MEAN = (0.48145466, 0.4578275, 0.40821073)
+IMAGE_STD = (0.26862954, 0.26130258, 0.27577711)
+RESCALE = 0.00392156862745098
+
+
+def patchify_normalize(image_u8, patch: int = 14, merge: int = 2, temporal: int = 2):
+    """(H, W, 3) uint8, already resized to multiples of patch*merge → ((H/14)*(W/14), 3*2*14*14) float32 rows in
+    (h/2, w/2, 2, 2) block-major patch order, + (grid_h, grid_w).  rescale: float32(float64(u8) * 1/255); normalize:
+    (x - float32(mean)) / float32(std) in float32; frame duplicated along the temporal axis."""
+    import numpy as np
+    x = np.asarray(image_u8).transpose(2, 0, 1)
+    r = (x.astype(np.float64) * RESCALE).astype(np.float32)
+    mean = np.array(IMAGE_MEAN, dtype=np.float32)[:, None, None]
+    std = np.array(IMAGE_STD, dtype=np.float32)[:, None, None]
+    v = (r - mean) / std
+    C, H, W = v.shape
+    gh, gw = H // patch, W // patch
+    pt = v.reshape(C, gh // merge, merge, patch, gw // merge, merge, patch).transpose(1, 4, 2, 5, 0, 3, 6)
+    pt = np.broadcast_to(pt[:, :, :, :, :, None, :, :], (*pt.shape[:5], temporal, *pt.shape[5:]))
+    return pt.reshape(gh * gw, C * temporal * patch * patch), gh, gw
+
+
 def weight_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:
     """Checkpoint key -> shape for the whole path (HF-4.50 layout + PaDT extras)."""
     s: Dict[str, Tuple[int, ...]] = {}

@@ -573,3 +573,41 @@ extern "C" int padt_mask_upsample_binarize(void* stream, const void* masks_f32, 
     PADT_CHECK_LAUNCH("mask_upsample_binarize");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Image front-end tail (HF Qwen2-VL image processor: rescale → normalize → patchify,
+// image_processing_pil_qwen2_vl.py _preprocess / patchify): uint8 (H, W, 3) → pixel_values rows [C=3][T=2][14][14] in
+// (h/2, w/2, 2, 2) block-major patch order.  A byte has 256 values per channel, so rescale+normalize is a 3 x 256 fp32
+// table built on the host with the processor's exact arithmetic — the kernel is a gather + layout change (bit-exact fp32,
+// or its round-to-nearest-even bf16).
+__global__ __launch_bounds__(256) void patchify_normalize_kernel(const unsigned char* __restrict__ img, int H, int W,
+                                                                 const float* __restrict__ lut, void* __restrict__ out,
+                                                                 long ld_out, int out_bf16, int patch, int merge, int temporal) {
+    const int gw = W / patch;
+    const int row_len = 3 * temporal * patch * patch;
+    const int p = blockIdx.x;                                     // output row = patch in block-major order
+    const int bw_n = gw / merge;
+    const int mw = p % merge, mh = (p / merge) % merge, bw = (p / (merge * merge)) % bw_n, bh = p / (merge * merge * bw_n);
+    const int y0 = (bh * merge + mh) * patch, x0 = (bw * merge + mw) * patch;
+    for (int e = threadIdx.x; e < row_len; e += blockDim.x) {
+        const int px = e % patch, py = (e / patch) % patch, c = e / (patch * patch * temporal);
+        const unsigned char u = img[((long)(y0 + py) * W + (x0 + px)) * 3 + c];
+        const float v = lut[c * 256 + u];
+        if (out_bf16) reinterpret_cast<bf16_t*>(out)[(long)p * ld_out + e] = f2bf(v);
+        else reinterpret_cast<float*>(out)[(long)p * ld_out + e] = v;
+    }
+}
+
+extern "C" int padt_patchify_normalize(void* stream, const void* img_u8, int H, int W, const void* lut_f32, void* out,
+                                       long ld_out, int out_bf16, int patch, int merge, int temporal) {
+    if (H <= 0 || W <= 0) return 0;
+    if (patch <= 0 || merge <= 0 || temporal <= 0 || H % (patch * merge) || W % (patch * merge)) {
+        padt_set_error("padt_patchify_normalize: H and W must be multiples of patch*merge");
+        return -1;
+    }
+    const int n_patch = (H / patch) * (W / patch);
+    hipLaunchKernelGGL(patchify_normalize_kernel, dim3(n_patch), dim3(256), 0, (hipStream_t)stream, (const unsigned char*)img_u8,
+                       H, W, (const float*)lut_f32, out, ld_out, out_bf16, patch, merge, temporal);
+    PADT_CHECK_LAUNCH("patchify_normalize");
+    return 0;
+}

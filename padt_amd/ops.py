@@ -321,6 +321,16 @@ def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want
     return (out, up) if want_logits else out
 
 
+def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):
+    """img_u8 (H, W, 3) uint8 device tensor → rows of `out` ((H/patch)*(W/patch), 3*temporal*patch*patch), fp32 or bf16."""
+    assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.shape[2] == 3
+    assert lut.dtype == torch.float32 and lut.shape == (3, 256) and out.stride(1) == 1
+    H, W = img_u8.shape[:2]
+    _lib.check(_lib.load().padt_patchify_normalize(_stream(), _p(img_u8), H, W, _p(lut), _p(out), out.stride(0),
+                                                   1 if out.dtype == BF16 else 0, patch, merge, temporal), "padt_patchify_normalize")
+    return out
+
+
 def memset(t, value=0):
     lib = _lib.load()
     _lib.check(lib.padt_memset(_stream(), _p(t), value, t.numel() * t.element_size()), "padt_memset")

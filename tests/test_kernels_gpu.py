@@ -674,3 +674,29 @@ def test_mask_upsample_binarize_against_reference_expression(ops):
     assert (u2[0].cpu() - r2).abs().max().item() < 1e-5
     d2 = o2[0].cpu().bool() != (r2.sigmoid() > 0.5)
     assert (r2.abs()[d2] < 1e-5).all()
+
+
+def test_patchify_normalize_matches_hf_processor_bit_exact(ops):
+    """padt_patchify_normalize vs the HF Qwen2-VL PIL processor's pixel_values (fixture): fp32 bit-exact, bf16 = its rounding;
+    ImageFrontEnd end to end (host resize skipped: inputs are already at their smart_resize size)."""
+    import numpy as np
+    from padt_amd import preprocess as P
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess.npz"))
+    lut = torch.from_numpy(P.normalize_lut()).cuda()
+    exp = torch.from_numpy(z["pix"])
+    o = 0
+    for k in ("img0", "img1"):
+        img = torch.from_numpy(z[k]).cuda()
+        n = (img.shape[0] // 14) * (img.shape[1] // 14)
+        out32 = torch.zeros(n, 1176, device="cuda")
+        ops.patchify_normalize(img, lut, out32)
+        assert torch.equal(out32.cpu(), exp[o:o + n])
+        out16 = torch.zeros(n, 1176, device="cuda", dtype=BF)
+        ops.patchify_normalize(img, lut, out16)
+        assert torch.equal(out16.cpu(), exp[o:o + n].to(BF))
+        o += n
+    fe = P.ImageFrontEnd("cuda", dtype=torch.float32)
+    pix, grid = fe([z["img0"], z["img1"]])
+    assert torch.equal(pix.cpu(), exp) and grid.tolist() == z["grid"].tolist()
+    with pytest.raises(Exception, match="multiples of patch"):
+        ops.patchify_normalize(torch.zeros(30, 28, 3, dtype=torch.uint8, device="cuda"), lut, torch.zeros(4, 1176, device="cuda"))
