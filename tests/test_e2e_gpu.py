@@ -7,6 +7,8 @@ oracle is teacher-forced on the HIP tokens and every HIP token must be the oracl
 top-2 margin is below the bf16 noise floor (then it must still be within that floor of the max).
 Tolerances are stated where they are asserted.
 """
+import os
+
 import pytest
 import torch
 
@@ -360,3 +362,49 @@ def test_from_pretrained_directory_round_trip(setup, tmp_path):
     assert torch.equal(a.hidden_states.last_layer_rows(), b.hidden_states.last_layer_rows())
     with pytest.raises(FileNotFoundError):
         PaDTForConditionalGeneration.from_pretrained(str(tmp_path / "missing"))
+
+
+def test_infer_dataset_harness_writes_reference_jsonl(setup, tmp_path):
+    """eval/evaluation_scripts/utils.py:176-266 on the throughput runner: rank striding, ragged last batch, both JSONL files
+    with the reference's record schema; records equal to the sequential rec_batch + postprocess path."""
+    cfg, w, model, U, oc = setup
+    import json
+    import padt_amd
+    from padt_amd import harness, pipeline, postprocess
+    T = 9
+    sched = U.rec_schedule(T, vrt_at=range(3, 6))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    shapes = [[1, 8, 8], [1, 10, 12], [1, 6, 10], [1, 8, 8], [1, 10, 12]]
+    dataset = [{"id": 100 + i, "grid": g, "size": (50 + 7 * i, 40 + 5 * i)} for i, g in enumerate(shapes)]
+
+    def prepare(samples):
+        grid, pix, ids, am = U.synthetic_batch(cfg, [s["grid"] for s in samples], n_pre=5, n_post=7, seed=samples[0]["id"], ragged=True)
+        return {"input_ids": ids.cuda(), "attention_mask": am.cuda(), "pixel_values": pix.cuda(), "image_grid_thw": grid,
+                "image_sizes": [s["size"] for s in samples], "ids": [s["id"] for s in samples]}
+
+    seen = []
+    for rank in range(2):
+        info = harness.infer_dataset(model, proc, dataset, prepare, str(tmp_path), batch_size=2, datasetname="syn", suffix="t",
+                                     rank=rank, world=2, max_new_tokens=T, depth=2, merge=2, schedule=sched)
+        comp = [json.loads(l) for l in open(info["completions_file"])]
+        res = [json.loads(l) for l in open(info["results_file"])]
+        assert os.path.basename(info["results_file"]) == f"syn_{rank}_pred_results_t.json"
+        assert len(comp) == info["samples"] and all(set(c) == {"image_id", "completion"} for c in comp)
+        assert all(set(r) == {"image_id", "score", "category", "bbox", "mask"} for r in res) and len(res) == info["samples"]
+        seen += [c["image_id"] for c in comp]
+        # the same records through the sequential path
+        k = 0
+        for idx in pipeline.rank_batches(len(dataset), 2, rank, 2):
+            if idx >= len(dataset):
+                continue
+            b = prepare(dataset[idx: idx + 2])
+            decoded, completions, labels, vrts = pipeline.rec_batch(model, proc, b["input_ids"], b["attention_mask"], b["pixel_values"],
+                                                                    b["image_grid_thw"], max_new_tokens=T, schedule=sched)
+            for r in postprocess.postprocess_results(decoded, labels, b["image_sizes"]):
+                got = res[k]
+                k += 1
+                assert got["image_id"] == b["ids"][r["sample_idx"]] and got["bbox"] == list(r["bbox"]) and got["mask"] == r["rle"]
+                assert abs(got["score"] - r["score"]) < 1e-6 and got["mask"]["size"] == [b["image_sizes"][r["sample_idx"]][1], b["image_sizes"][r["sample_idx"]][0]]
+        assert k == len(res)
+    assert sorted(seen) == [100, 101, 102, 103, 104]
