@@ -140,17 +140,25 @@ int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask
  * slot for synthetic weights (0 free, 1 text rows, 2 own VRT rows, 3 force EOS), padt.py:717.
  * embed_table_packed (nullable): fragment-packed copy of embed_table ([vocab/16][D/32][64][8], as padt_gemm_packed_bf16's
  * weights); when given, `hidden` must be in the 16-row fragment-packed activation layout (ldh = D) and text rows are
- * streamed as 1 KiB contiguous wave loads (0.62 GB per step is the decode step's largest single read). */
+ * streamed as 1 KiB contiguous wave loads (0.62 GB per step is the decode step's largest single read).
+ * gen_cfg (nullable, DEVICE memory: {float repetition_penalty; int eos[4]; int pad[3]}) + seen (nullable, device bitmap
+ * [batch][seen_words] of 32-bit words, bit r = table row r already occurs in that sample's input_ids): HF's
+ * RepetitionPenaltyLogitsProcessor (score < 0 ? score*p : score/p) fused in front of the mask/arg-max, padt.py:570-580,717.
+ * Kept in device memory so a captured decode graph does not bake the values in. */
 long padt_vrt_head_nblk(long vocab, long n_proto);
 int  padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab, const void* proto,
                    long n_proto, const int* vrt_off, const int* mode_table, const int* step, void* logits_f32,
                    long ld_logits, void* part_val, void* part_idx, long batch, long D, int eos,
-                   const void* embed_table_packed);
+                   const void* embed_table_packed, const void* gen_cfg, const void* seen, long seen_words);
 /* argmax reduction (ties → lowest id), pad/EOS bookkeeping, token append, hidden-row stash, slot/len/position/step
- * advance — all on device.  padt.py:745-757, 732-737. */
+ * advance — all on device.  padt.py:745-757, 732-737.  gen_cfg / seen as in padt_vrt_head: extra EOS ids stop a row too
+ * (generation_config's eos_token_id list), and the chosen token's bit is set in the row's seen bitmap. */
 int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D, int eos,
                       int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok, int* step, int* slot,
-                      int* lens, int* pos3, const void* hidden, void* hidden_buf, int advance);
+                      int* lens, int* pos3, const void* hidden, void* hidden_buf, int advance, const void* gen_cfg,
+                      void* seen, long seen_words);
+/* seen[rows[i]] |= bit(ids[i]) for the prompt tokens of a generate call (ids global in the session's table). */
+int  padt_seen_init(void* stream, const long* ids, const int* rows, long n, void* seen, long seen_words);
 
 /* ---- caller-side post-processing --------------------------------------------------------------- */
 /* out[o][y][x] = sigmoid(bilinear(masks[o][:src_h[o]][:src_w[o]] → dst_h[o] x dst_w[o], align_corners=False))[y][x] > 0.5,

@@ -457,7 +457,8 @@ def decode_step(w, cfg: OracleConfig, st: PrefillState, input_ids: Tensor, all_h
 
 def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pixel_values: Tensor,
              grid_thw: Tensor, max_new_tokens: int, schedule: Optional[Sequence[str]] = None,
-             collect_logits: bool = False, force_tokens: Optional[Tensor] = None):
+             collect_logits: bool = False, force_tokens: Optional[Tensor] = None, repetition_penalty: float = 1.0,
+             eos_token_ids: Optional[Sequence[int]] = None):
     """Greedy loop, padt.py:670-762 (essentials).
 
     ``schedule`` (synthetic-weights only): per step one of 't' (argmax restricted to text rows),
@@ -477,6 +478,12 @@ def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pi
         else:
             logits, hidden = decode_step(w, cfg, st, seq[:, -1:])
         nl = logits[:, -1, :].clone().float()
+        if repetition_penalty != 1.0:
+            # HF RepetitionPenaltyLogitsProcessor (generation/logits_process.py), first in the processor list (padt.py:570-580,
+            # applied at :717): every id already in the row — prompt, padding and generated tokens — is penalised
+            score = torch.gather(nl, 1, seq)
+            score = torch.where(score < 0, score * repetition_penalty, score / repetition_penalty)
+            nl = nl.scatter(1, seq, score)
         mode = schedule[t] if schedule is not None and t < len(schedule) else None
         if mode == 't':
             nl[:, cfg.vocab_size:] = float("-inf")
@@ -493,7 +500,8 @@ def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pi
             nxt = force_tokens[:, t].clone()                 # teacher forcing (tests: margin rule of SURVEY.md §7)
         nxt = nxt * unfinished + cfg.pad_token_id * (1 - unfinished)
         seq = torch.cat([seq, nxt[:, None]], dim=-1)
-        unfinished = unfinished & (nxt != cfg.eos_token_id).long()
+        eos_set = [cfg.eos_token_id] if eos_token_ids is None else list(eos_token_ids)
+        unfinished = unfinished & (~torch.isin(nxt, torch.tensor(eos_set))).long()    # padt.py:756 (EosTokenCriteria over the id list)
         if int(unfinished.max()) == 0:
             break
     return {"sequences": seq, "hidden": hiddens, "state": st, "logits": all_logits}

@@ -16,6 +16,14 @@
 
 extern "C" void padt_set_error(const char* msg);
 
+// Generation-config slots kept in DEVICE memory so a captured decode graph does not bake them in
+// (HF generation_config.json: repetition_penalty, eos_token_id list; padt.py:570-580,717,756).
+struct GenCfg {
+    float penalty;                     // RepetitionPenaltyLogitsProcessor: score<0 ? score*p : score/p on every id already in the row
+    int eos[4];                        // up to 4 EOS ids, -1 = unused
+    int pad[3];
+};
+
 struct HeadArgs {
     const bf16_t* h; long ldh;         // [B][D]
     const bf16_t* E; int V;            // text rows
@@ -27,6 +35,8 @@ struct HeadArgs {
     float* part_val; int* part_idx;    // [nblk][16*MT]
     int B, D, eos;
     const bf16_t* Ep;                  // optional fragment-packed copy of E (PACKED kernels; h is then packed too)
+    const GenCfg* gen;                 // optional generation config (repetition penalty) + per-sample seen-token bitmap
+    const unsigned* seen; long seen_words;
 };
 
 // PACKED: text rows come from a fragment-packed copy of the table ([V/16][D/32][64 lanes][8], ops.pack_weight — every wave
@@ -84,6 +94,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
 #pragma unroll
     for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
     const int mode = (p.mode_table && p.step) ? p.mode_table[*p.step] : 0;
+    const float pen = (p.gen && p.seen) ? p.gen->penalty : 1.0f;
     const int m = j * 16 + frow;                              // sample
     float best = -INFINITY;
     int bidx = 0x7fffffff;
@@ -97,7 +108,9 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
             if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
             else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
         }
-        const float v = ok ? sum[r] : -INFINITY;
+        float sc = sum[r];
+        if (pen != 1.0f && ok && ((p.seen[(long)m * p.seen_words + (row >> 5)] >> (row & 31)) & 1u)) sc = sc < 0.f ? sc * pen : sc / pen;
+        const float v = ok ? sc : -INFINITY;
         if (p.logits && m < p.B && row < NT) p.logits[(long)m * p.ldl + row] = v;
         if (v > best) { best = v; bidx = row; }               // rows ascend with r → first max wins
     }
@@ -126,6 +139,8 @@ struct GreedyArgs {
     const bf16_t* hidden;     // [B][D] last-layer hidden of this step (post final norm)
     bf16_t* hidden_buf;       // [T_max][B][D]
     int advance;              // 1: bump slot/lens/pos (decode steps and after prefill)
+    const GenCfg* gen;        // optional: extra EOS ids
+    unsigned* seen; long seen_words;   // optional: bitmap of ids present in each row (repetition penalty), updated here
 };
 
 __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
@@ -160,7 +175,13 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
         long next = unf ? (long)si[0] : (long)p.pad;                 // padt.py:749
         if (step < p.T_max) p.tokens_out[(long)b * p.T_max + step] = next;
         p.cur_tok[b] = next;
-        p.unfinished[b] = unf & (next != p.eos);                     // padt.py:756
+        bool is_eos = next == p.eos;
+        if (p.gen) {
+#pragma unroll
+            for (int k = 0; k < 4; ++k) is_eos = is_eos || (p.gen->eos[k] >= 0 && next == (long)p.gen->eos[k]);
+        }
+        p.unfinished[b] = unf & (is_eos ? 0 : 1);                    // padt.py:756
+        if (p.seen) p.seen[(long)b * p.seen_words + (next >> 5)] |= 1u << (next & 31);   // the row now contains `next`
         if (p.advance) {
             p.slot[b] += 1; p.lens[b] += 1;
             p.pos3[b] += 1; p.pos3[p.B + b] += 1; p.pos3[2 * p.B + b] += 1;
@@ -176,7 +197,8 @@ extern "C" long padt_vrt_head_nblk(long vocab, long n_proto) { return (vocab + n
 extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
                              const void* proto, long n_proto, const int* vrt_off, const int* mode_table,
                              const int* step, void* logits_f32, long ld_logits, void* part_val, void* part_idx,
-                             long batch, long D, int eos, const void* embed_table_packed) {
+                             long batch, long D, int eos, const void* embed_table_packed, const void* gen_cfg,
+                             const void* seen, long seen_words) {
     if (batch <= 0) return 0;
     if (batch > 64 || (D & 7) || (ldh & 7)) { padt_set_error("padt_vrt_head: batch <= 64, D % 8 == 0 required"); return -1; }
     if (embed_table_packed && ((D & 31) || (vocab & 15) || ((uintptr_t)embed_table_packed & 15) || ((uintptr_t)hidden & 15))) {
@@ -185,7 +207,8 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
     }
     HeadArgs a{(const bf16_t*)hidden, ldh, (const bf16_t*)embed_table, (int)vocab, (const bf16_t*)proto, (int)n_proto,
                vrt_off, mode_table, step, (float*)logits_f32, ld_logits, (float*)part_val, (int*)part_idx, (int)batch,
-               (int)D, eos, (const bf16_t*)embed_table_packed};
+               (int)D, eos, (const bf16_t*)embed_table_packed, (const GenCfg*)gen_cfg, (const unsigned*)seen, seen_words};
+    if (seen && seen_words * 32 < vocab + n_proto) { padt_set_error("padt_vrt_head: seen bitmap narrower than the table"); return -1; }
     const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
     hipStream_t s = (hipStream_t)stream;
     if (embed_table_packed) {
@@ -203,15 +226,34 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
 extern "C" int padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D,
                                 int eos, int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok,
                                 int* step, int* slot, int* lens, int* pos3, const void* hidden, void* hidden_buf,
-                                int advance) {
+                                int advance, const void* gen_cfg, void* seen, long seen_words) {
     if (batch <= 0) return 0;
     if (D & 7) { padt_set_error("padt_greedy_step: D % 8 == 0 required"); return -1; }
     GreedyArgs a{(const float*)part_val, (const int*)part_idx, (int)nblk, (int)batch, (int)D, eos, pad, (int)t_max,
                  unfinished, tokens_out, cur_tok, step, slot, lens, pos3, (const bf16_t*)hidden, (bf16_t*)hidden_buf,
-                 advance};
+                 advance, (const GenCfg*)gen_cfg, (unsigned*)seen, seen_words};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(greedy_step_kernel, dim3((unsigned)batch), dim3(256), 0, s, a);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// seen[row[i]] |= bit(ids[i]) for every prompt token (ids already global in the session's table); ids outside the table are
+// ignored (the range assert of padt.py:203 is reported by the embedding kernel).
+__global__ void seen_init_kernel(const long* __restrict__ ids, const int* __restrict__ rows, long n, unsigned* seen, long words) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long id = ids[i];
+        if (id >= 0 && id < words * 32) atomicOr(&seen[(long)rows[i] * words + (id >> 5)], 1u << (id & 31));
+    }
+}
+
+extern "C" int padt_seen_init(void* stream, const long* ids, const int* rows, long n, void* seen, long seen_words) {
+    if (n <= 0) return 0;
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(seen_init_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ids, rows, n, (unsigned*)seen, seen_words);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

@@ -168,6 +168,9 @@ class DecodeSession:
         self.hn = z(B, D)
         self.hn_first = z(B, D)          # last prompt token's post-norm hidden state per row (first-token selection)
         self.hn_pk = z(B16, D)           # packed copy of the head's input rows
+        # generation-config slots (device memory, so the captured graph does not bake them in) + per-row seen-token bitmap
+        self.gen_cfg = ops.gen_cfg_tensor(1.0, (), device)
+        self.seen = z(B, (cfg.vocab_size + np_max + 31) // 32, dt=I32)
         self.err = z(1, dt=I32)
         self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
         self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
@@ -205,13 +208,14 @@ class DecodeSession:
         if hp is not None:                                   # packed table + packed hidden rows: 1 KiB contiguous wave loads
             ops.pack_rows(hn, self.hn_pk, self.B, to_packed=True)
             ops.vrt_head(self.hn_pk, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
-                         mode_table=self.mode_table, step=self.step, table_packed=hp, rows=self.B)
+                         mode_table=self.mode_table, step=self.step, table_packed=hp, rows=self.B, gen_cfg=self.gen_cfg,
+                         seen=self.seen)
         else:
             ops.vrt_head(hn, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
-                         mode_table=self.mode_table, step=self.step)
+                         mode_table=self.mode_table, step=self.step, gen_cfg=self.gen_cfg, seen=self.seen)
         ops.greedy_step(self.part_val, self.part_idx, self.nblk, hn, self.hidden_buf, self.unfinished, self.tokens,
                         self.cur_tok, self.step, self.slot, self.lens, self.pos3, cfg.eos_token_id, cfg.pad_token_id,
-                        advance=advance)
+                        advance=advance, gen_cfg=self.gen_cfg, seen=self.seen)
 
     def run_steps(self, n: int, use_graph: bool = True):
         if n <= 0:

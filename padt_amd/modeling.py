@@ -137,21 +137,25 @@ class PaDTForConditionalGeneration:
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
                  max_new_tokens=1024, do_sample=False, output_hidden_states=True, return_dict_in_generate=True,
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
-                 use_graph: bool = True, lane: int = 0, **unused):
+                 use_graph: bool = True, lane: int = 0, repetition_penalty: float = 1.0, eos_token_id=None, **unused):
         """Greedy generation over the unified text‖VRT vocabulary.
 
         ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
         VRT rows only, 'e' force EOS, None free — applied where HF's ``logits_processor`` sits (padt.py:717).
         ``lane`` selects an independent decode session (KV caches, token ring, graph) so several batches can be in
         flight on different HIP streams (pipeline.PipelinedRunner).
+        ``repetition_penalty`` / ``eos_token_id`` (int or list, must contain config.eos_token_id): the two
+        generation_config.json entries HF's generate turns into a logits processor / stopping criterion (padt.py:570-580).
         """
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
-                                   schedule, sync_every, use_graph, lane)
+                                   schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
+                                   eos_token_id=eos_token_id)
         return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate)
 
     @torch.no_grad()
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=False,
-                        schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1):
+                        schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
+                        repetition_penalty=1.0, eos_token_id=None):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -169,6 +173,10 @@ class PaDTForConditionalGeneration:
             raise ValueError("pixel_values and image_grid_thw are required (text-only input crashes in the reference too, "
                              "padt.py:292 with image_prototypes unbound)")
         cfg, dev = self.config, self.device
+        eos_list = [cfg.eos_token_id] if eos_token_id is None else ([int(eos_token_id)] if isinstance(eos_token_id, int) else [int(e) for e in eos_token_id])
+        if cfg.eos_token_id not in eos_list or len(eos_list) > 4:
+            raise NotImplementedError("eos_token_id must contain config.eos_token_id and hold at most 4 ids")
+        gen_key = (float(repetition_penalty), tuple(eos_list))
         grid = image_grid_thw.detach().cpu().long()
         B = input_ids.shape[0]
         T_max = int(max_new_tokens)
@@ -181,7 +189,11 @@ class PaDTForConditionalGeneration:
         if group is None:
             sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
-                         use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule)
+                         use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule,
+                         gen_key=gen_key)
+            sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu").to(dev, non_blocking=True))
+            if gen_key[0] != 1.0:
+                sess.seen.zero_()
             # neutral state for every row; the batches overwrite their own rows (unused rows stay finished / empty)
             st = torch.zeros(T_max + 1, dtype=torch.int32)
             if schedule is not None:
@@ -199,7 +211,8 @@ class PaDTForConditionalGeneration:
         else:
             sess = group["sess"]
             if (group["launched"] or k >= group["n_slots"] or B != group["B"] or T_max != group["T_max"]
-                    or schedule != group["schedule"] or sess.s_max < need_s or sess.np_max < proto_row0 + n_proto):
+                    or schedule != group["schedule"] or gen_key != group["gen_key"] or sess.s_max < need_s
+                    or sess.np_max < proto_row0 + n_proto):
                 return None
         rows = slice(row0, row0 + B)
 
@@ -217,6 +230,13 @@ class PaDTForConditionalGeneration:
         sess.lens[rows].copy_((lens_t + 1).to(dev, non_blocking=True))  # keys visible to the next token
         sess.pos3[:, rows].copy_(torch.tensor([plan.next_pos] * 3, dtype=torch.int32).to(dev, non_blocking=True))
         self.rope_deltas = plan.rope_deltas
+        if gen_key[0] != 1.0:
+            # RepetitionPenaltyLogitsProcessor sees the caller's full (B, L) input_ids, padding included
+            ids_full = input_ids.detach().to(dev).long()
+            if proto_row0:
+                ids_full = torch.where(ids_full >= cfg.vocab_size, ids_full + proto_row0, ids_full)
+            rws = (torch.arange(B, device=dev, dtype=torch.int32) + row0)[:, None].expand(B, ids_full.shape[1]).contiguous()
+            ops.seen_init(ids_full.reshape(-1).contiguous(), rws.reshape(-1), sess.seen)
 
         # ---- prefill; the first token is selected together with the other batches of the group (launch_decode)
         hn_all = self.lm.prefill(plan, low, sess)

@@ -284,7 +284,7 @@ def vrt_head_nblk(vocab, n_proto):
 
 
 def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=None, step=None, logits=None,
-             table_packed=None, rows=None):
+             table_packed=None, rows=None, gen_cfg=None, seen=None):
     """table_packed: pack_weight(table) — then `hidden` is a fragment-packed activation buffer holding `rows` valid rows."""
     lib = _lib.load()
     _chk_bf16(hidden, table, proto, table_packed)
@@ -292,16 +292,32 @@ def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=
     _lib.check(lib.padt_vrt_head(_stream(), _p(hidden), hidden.stride(0), _p(table), table.shape[0], _p(proto),
                                  proto.shape[0], _p(vrt_off), _p(mode_table), _p(step), _p(logits),
                                  logits.stride(0) if logits is not None else 0, _p(part_val), _p(part_idx),
-                                 B, hidden.shape[1], eos, _p(table_packed)), "padt_vrt_head")
+                                 B, hidden.shape[1], eos, _p(table_packed), _p(gen_cfg), _p(seen),
+                                 seen.shape[1] if seen is not None else 0), "padt_vrt_head")
+
+
+def seen_init(ids, rows, seen):
+    """ids int64 (n,), rows int32 (n,) device tensors: set bit ids[i] in seen[rows[i]] (prompt tokens of a generate call)."""
+    assert ids.dtype == torch.int64 and rows.dtype == torch.int32 and ids.numel() == rows.numel() and seen.dtype == torch.int32
+    _lib.check(_lib.load().padt_seen_init(_stream(), _p(ids), _p(rows), ids.numel(), _p(seen), seen.shape[1]), "padt_seen_init")
+
+
+def gen_cfg_tensor(repetition_penalty=1.0, eos_ids=(), device="cuda"):
+    """Device copy of the generation-config slots the head / greedy kernels read: {float penalty; int eos[4]; int pad[3]}."""
+    import struct
+    eos = list(eos_ids)[:4] + [-1] * (4 - min(4, len(eos_ids)))
+    raw = struct.pack("<f7i", float(repetition_penalty), *eos, 0, 0, 0)
+    return torch.frombuffer(bytearray(raw), dtype=torch.int32).clone().to(device)
 
 
 def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens_out, cur_tok, step, slot, lens, pos3,
-                eos, pad, advance=True):
+                eos, pad, advance=True, gen_cfg=None, seen=None):
     lib = _lib.load()
     B, D = hidden.shape
     _lib.check(lib.padt_greedy_step(_stream(), _p(part_val), _p(part_idx), nblk, B, D, eos, pad, tokens_out.shape[1],
                                     _p(unfinished), _p(tokens_out), _p(cur_tok), _p(step), _p(slot), _p(lens), _p(pos3),
-                                    _p(hidden), _p(hidden_buf), 1 if advance else 0), "padt_greedy_step")
+                                    _p(hidden), _p(hidden_buf), 1 if advance else 0, _p(gen_cfg), _p(seen),
+                                    seen.shape[1] if seen is not None else 0), "padt_greedy_step")
 
 
 def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want_logits=False):

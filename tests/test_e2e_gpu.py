@@ -408,3 +408,51 @@ def test_infer_dataset_harness_writes_reference_jsonl(setup, tmp_path):
                 assert abs(got["score"] - r["score"]) < 1e-6 and got["mask"]["size"] == [b["image_sizes"][r["sample_idx"]][1], b["image_sizes"][r["sample_idx"]][0]]
         assert k == len(res)
     assert sorted(seen) == [100, 101, 102, 103, 104]
+
+
+def test_repetition_penalty_and_eos_list(setup):
+    """generation_config fidelity: HF's RepetitionPenaltyLogitsProcessor fused into the logit head (seen-id
+    bitmap incl. prompt + padding ids) and an EOS id list — against the oracle with the same processor (margin rule)."""
+    cfg, w, model, U, oc = setup
+    O = U.O
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 10, 12], [1, 8, 8], [1, 6, 10]], n_pre=6, n_post=9, ragged=True)
+    T = 12
+    sched = U.rec_schedule(T, vrt_at=range(4, 8))
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T,
+              schedule=sched)
+    L = ids.shape[1]
+    base = model.generate(**kw).sequences.cpu()[:, L:]
+    pen = 1.6
+    out = model.generate(repetition_penalty=pen, **kw)
+    toks = out.sequences.cpu()[:, L:]
+    assert not torch.equal(toks, base), "penalty changed nothing: the test has no power"
+    ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks, repetition_penalty=pen)
+    n_tie = 0
+    for t in range(toks.shape[1]):
+        lg = ores["logits"][t]
+        top2 = lg.topk(2, dim=-1).values
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        floor = 2e-2 * lg[torch.isfinite(lg)].abs().max().item()
+        for b in range(3):
+            second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
+            if (top2[b, 0] - second).item() > floor:
+                assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the penalised argmax"
+            else:
+                n_tie += 1
+                assert (top2[b, 0] - chosen[b]).item() <= floor
+    assert n_tie <= T * 3 // 2
+    # graph replay with a different penalty value afterwards: the value lives in device memory, not in the captured graph
+    again = model.generate(**kw).sequences.cpu()[:, L:]
+    assert torch.equal(again, base)
+    # EOS list: the token sample 0 produced at step 1 becomes a second EOS id → that row stops there and is padded
+    extra = int(base[0, 1])
+    stop = model.generate(eos_token_id=[cfg.eos_token_id, extra], **kw).sequences.cpu()[:, L:]
+    assert torch.equal(stop[0, :2], base[0, :2]) and (stop[0, 2:] == cfg.pad_token_id).all()
+    for b in (1, 2):
+        first = (base[b] == extra).nonzero()
+        upto = int(first[0]) + 1 if len(first) else T
+        assert torch.equal(stop[b, :upto], base[b, :upto])
+    oref = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, force_tokens=stop, eos_token_ids=[cfg.eos_token_id, extra])
+    assert torch.equal(oref["sequences"][:, L:], stop[:, : oref["sequences"].shape[1] - L])
+    with pytest.raises(NotImplementedError):
+        model.generate(eos_token_id=[extra], **kw)
