@@ -433,30 +433,72 @@ struct QkvPostArgs {
 };
 
 __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
+    __shared__ float cs[2][128];                                  // cos / sin of this token's D/2 angles (D <= 256)
     const int t = blockIdx.x;
     const int half = p.D >> 1;
     const int b = p.sample ? p.sample[t] : t;
     const int slot = p.slot ? p.slot[t] : p.lens[b];
     const bf16_t* row = p.qkv + (long)t * p.ld;
-    const int nqk = (p.Hq + p.Hkv) * half;
-    for (int i = threadIdx.x; i < nqk; i += blockDim.x) {
-        const int h = i / half, d = i % half;
+    // the angle depends on (token, d) only: computed once per token, not once per head
+    for (int d = threadIdx.x; d < half; d += blockDim.x) {
         const int axis = d < p.sec0 ? 0 : (d < p.sec0 + p.sec1 ? 1 : 2);
         const float ang = (float)p.pos[(long)axis * p.T + t] * p.inv_freq[d];
-        const float c = cosf(ang), s = sinf(ang);
-        const bf16_t* x = row + (long)h * p.D;
-        const float x1 = bf2f(x[d]), x2 = bf2f(x[d + half]);
-        const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
-        if (h < p.Hq) {
-            bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
-            q[d] = o1; q[d + half] = o2;
-        } else {
-            const int g = h - p.Hq;
-            bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
-            kc[d] = o1; kc[d + half] = o2;
-            if (p.k_pack) {
-                bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
-                kp[d] = o1; kp[d + half] = o2;
+        cs[0][d] = cosf(ang);
+        cs[1][d] = sinf(ang);
+    }
+    __syncthreads();
+    if ((half & 7) == 0 && (p.ld & 7) == 0 && (p.ld_q & 7) == 0 && (p.ld_kp & 7) == 0) {
+        // 16-byte path: item = (head, 8-wide chunk of the first half); its partner chunk sits D/2 further
+        const int cph = half >> 3;
+        const int items = (p.Hq + p.Hkv) * cph;
+        for (int i = threadIdx.x; i < items; i += blockDim.x) {
+            const int h = i / cph, d = (i % cph) * 8;
+            const bf16_t* x = row + (long)h * p.D + d;
+            float x1[8], x2[8], o1[8], o2[8];
+            unpack8(*reinterpret_cast<const u32x4*>(x), x1);
+            unpack8(*reinterpret_cast<const u32x4*>(x + half), x2);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float c = cs[0][d + e], sn = cs[1][d + e];
+                o1[e] = x1[e] * c - x2[e] * sn;
+                o2[e] = x2[e] * c + x1[e] * sn;
+            }
+            const u32x4 r1 = pack8(o1), r2 = pack8(o2);
+            if (h < p.Hq) {
+                bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D + d;
+                *reinterpret_cast<u32x4*>(q) = r1;
+                *reinterpret_cast<u32x4*>(q + half) = r2;
+            } else {
+                const int g = h - p.Hq;
+                bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D + d;
+                *reinterpret_cast<u32x4*>(kc) = r1;
+                *reinterpret_cast<u32x4*>(kc + half) = r2;
+                if (p.k_pack) {
+                    bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D + d;
+                    *reinterpret_cast<u32x4*>(kp) = r1;
+                    *reinterpret_cast<u32x4*>(kp + half) = r2;
+                }
+            }
+        }
+    } else {
+        const int nqk = (p.Hq + p.Hkv) * half;
+        for (int i = threadIdx.x; i < nqk; i += blockDim.x) {
+            const int h = i / half, d = i % half;
+            const float c = cs[0][d], s = cs[1][d];
+            const bf16_t* x = row + (long)h * p.D;
+            const float x1 = bf2f(x[d]), x2 = bf2f(x[d + half]);
+            const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
+            if (h < p.Hq) {
+                bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
+                q[d] = o1; q[d + half] = o2;
+            } else {
+                const int g = h - p.Hq;
+                bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
+                kc[d] = o1; kc[d + half] = o2;
+                if (p.k_pack) {
+                    bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
+                    kp[d] = o1; kp[d + half] = o2;
+                }
             }
         }
     }
@@ -473,6 +515,7 @@ extern "C" int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, con
                                  int n_kv_heads, int head_dim, int s_max, int sec0, int sec1) {
     if (T <= 0) return 0;
     if (!slot && !lens) { padt_set_error("padt_llm_qkv_post: need slot[] or lens[]"); return -1; }
+    if (head_dim > 256 || (head_dim & 1)) { padt_set_error("padt_llm_qkv_post: head_dim must be even and <= 256"); return -1; }
     QkvPostArgs a{(const bf16_t*)qkv, ld_qkv, pos3, sample, slot, lens, (const float*)inv_freq, (bf16_t*)q_out, ld_q,
                   (bf16_t*)k_pack, ld_kp, (bf16_t*)k_cache, (bf16_t*)vt_cache, (int)T, n_heads, n_kv_heads, head_dim,
                   s_max, sec0, sec1};
