@@ -38,6 +38,14 @@ int         padt_event_destroy(void* ev);
  * 142-184 (decoder projections, MLPs, heads). */
 int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
                    const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32, const void* row_scale);
+/* C = rope(row_scale[m] * (A · W^T) + bias), bf16: rotate-half RoPE (HF:160-171) of output columns [0, rope_cols) fused into the
+ * epilogue.  Those columns must be PAIR-INTERLEAVED per head — column 2i / 2i+1 of a head = its d = i / i + head_dim/2 —
+ * which the caller gets by permuting W's rows (and bias) once at load; q·k scores are invariant under the common
+ * permutation.  rope_cos / rope_sin: fp32 [M][ld_cs], column i < head_dim/2 = angle of pair i.  Replaces
+ * {qkv Linear → apply_rotary_pos_emb_vision} of the ViT block (HF:219-220,160-171) without the extra pass over q and k. */
+int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
+                        long M, long N, long K, const void* row_scale, const void* rope_cos, const void* rope_sin, long ld_cs,
+                        long rope_cols, int head_dim);
 /* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above). */
 int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 

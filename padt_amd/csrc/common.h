@@ -48,6 +48,27 @@ PADT_DEV bool handoff_arrive(int* ticket, int total, int lane) {
     return true;
 }
 
+// Rotate-half RoPE fused into a GEMM epilogue.  The projection's output columns are stored PAIR-INTERLEAVED per head
+// ((d, d + D/2) adjacent: weights.py permutes the q / k weight rows at load; q·k dot products do not care about a common
+// permutation of d), so the 4 consecutive columns a lane holds are two complete rotation pairs.
+struct RopeEpi {
+    const float* cos; const float* sin; long ld;   // fp32 [row][>= D/2] tables; cos == nullptr → off
+    int cols;                                      // columns [0, cols) are rotated (q and k), the rest (v) pass through
+    int D;                                         // head width (D % 4 == 0)
+};
+
+PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
+    if (r.cos == nullptr || n >= r.cols) return;
+    const int i = (n % r.D) >> 1;                  // pair index of columns (n, n+1); (n+2, n+3) is pair i + 1
+    const float c0 = r.cos[(long)m * r.ld + i], c1 = r.cos[(long)m * r.ld + i + 1];
+    const float s0 = r.sin[(long)m * r.ld + i], s1 = r.sin[(long)m * r.ld + i + 1];
+    const float a0 = o[0], b0 = o[1], a1 = o[2], b1 = o[3];
+    o[0] = a0 * c0 - b0 * s0;
+    o[1] = b0 * c0 + a0 * s0;
+    o[2] = a1 * c1 - b1 * s1;
+    o[3] = b1 * c1 + a1 * s1;
+}
+
 PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
 PADT_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
 

@@ -32,6 +32,7 @@ struct GemmArgs {
     int* ticket = nullptr;       //          and one completion ticket per n-block (zero between launches)
     int split = 1;
     const float* rs = nullptr;   // optional per-row scale applied to the accumulator before bias (fused RMSNorm: rstd[m])
+    RopeEpi rope = {nullptr, nullptr, 0, 0, 0};   // optional fused RoPE of the leading output columns (EPI_NONE only)
     int a_pack = 0;              // skinny kernel: A / (C and R) stored in the 16-row fragment-packed activation layout
     int c_pack = 0;              //   element (m, k) at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8   (see padt_hip.h)
 };
@@ -72,6 +73,7 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] += bv[r];
         }
+        if (EPI == EPI_NONE) rope_pairs(o, m, n, p.rope);
         if (EPI == EPI_GELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
@@ -234,6 +236,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
                 unpack4(braw[ni], bv);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc[mi] + bv[r];
+                if (EPI == EPI_NONE) rope_pairs(o, mb + mi * 16, nb + ni * 16, p.rope);
                 if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
@@ -444,7 +447,7 @@ extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, long* rows_done);
+                                const float* row_scale, const RopeEpi* rope, long* rows_done);
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -502,9 +505,9 @@ static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
     else launch_skinny<4, EPI, false, true>(a, eps, s);
 }
 
-extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
-                              long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                              const void* row_scale) {
+static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                          const void* row_scale, const RopeEpi& rope) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         padt_set_error("padt_gemm_bf16: K, lda, ldw must be multiples of 8 and A, W 16-byte aligned");
@@ -519,7 +522,8 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
     if (epilogue < 0 || epilogue > 3) { padt_set_error("padt_gemm_bf16: unknown epilogue"); return -1; }
     long done = 0;
     const float* rs = (const float*)row_scale;
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &done) == 0) {
+    RopeEpi rp = rope;
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -530,11 +534,13 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
         C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
         if (R) R = (const bf16_t*)R + done * ldr;
         if (rs) rs += done;
+        if (rp.cos) { rp.cos += done * rp.ld; rp.sin += done * rp.ld; }
         M -= done;
     }
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
                (int)M, (int)N, (int)K};
     a.rs = rs;
+    a.rope = rp;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: dispatch_m<EPI_NONE, false>(a, s); break;
@@ -549,6 +555,27 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;
+}
+
+extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+                              long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                              const void* row_scale) {
+    return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
+                          RopeEpi{nullptr, nullptr, 0, 0, 0});
+}
+
+// C = rope(row_scale[m] * (A · W^T) + bias): the rotate-half RoPE of the leading `rope_cols` output columns fused into the
+// epilogue (ViT qkv projection: q and k columns, pair-interleaved per head by a load-time permutation of W's rows).
+extern "C" int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+                                   long ldc, long M, long N, long K, const void* row_scale, const void* rope_cos,
+                                   const void* rope_sin, long ld_cs, long rope_cols, int head_dim) {
+    if (rope_cos == nullptr || rope_sin == nullptr || head_dim <= 0 || (head_dim & 3) || (rope_cols & 3) || rope_cols > N ||
+        rope_cols % head_dim || (N & 3)) {
+        padt_set_error("padt_gemm_rope_bf16: need cos/sin tables, head_dim % 4 == 0, rope_cols a multiple of head_dim and <= N, N % 4 == 0");
+        return -1;
+    }
+    return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, nullptr, 0, M, N, K, EPI_NONE, 0, row_scale,
+                          RopeEpi{(const float*)rope_cos, (const float*)rope_sin, ld_cs, (int)rope_cols, head_dim});
 }
 
 // Fused RMSNorm + projection for decode-sized batches (M <= 64):  C = epi(rstd(A)[m] * (A · W^T)[m] + bias), where

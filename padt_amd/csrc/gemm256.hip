@@ -30,6 +30,7 @@ struct Gemm256Args {
     const bf16_t* R; long ldr;
     int M, N, K;
     const float* rs;                // optional per-row scale of the accumulator (fused RMSNorm rstd), applied before bias
+    RopeEpi rope;                   // optional fused RoPE of the leading output columns (EPI_NONE)
     int group_m;                    // tile rasterisation: ids walk down group_m tile rows, then to the next tile column
 };
 
@@ -259,6 +260,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc + bv[r];
+                if (EPI == EPI_NONE) rope_pairs(o, m, n, p.rope);
                 if (EPI == EPI_GELU) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
@@ -339,7 +341,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     const Plan256 whole = plan256(a.M, a.N, a.K, force, allow_peel, force_peel);
     long split_cols = 0;
     Plan256 pm = whole, pr = whole;
-    if (colsplit != 0 && ntn >= 4 && a.N % TN == 0 && whole.rows == a.M) {
+    if (colsplit != 0 && a.rope.cos == nullptr && ntn >= 4 && a.N % TN == 0 && whole.rows == a.M) {
         double best_total = whole.cost;
         for (long c = 1; c <= 16 && c < ntn - 1; ++c) {
             if (colsplit >= 2 && c != colsplit) continue;
@@ -373,7 +375,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 // *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, long* rows_done) {
+                                const float* row_scale, const RopeEpi* rope, long* rows_done) {
     static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -385,7 +387,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     static const int group_m = getenv("PADT_GEMM_GROUP_M") ? atoi(getenv("PADT_GEMM_GROUP_M")) : 8;   // tuning knob
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, group_m < 1 ? 1 : group_m};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;

@@ -56,6 +56,22 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     return out
 
 
+def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
+    """out = rope(row_scale[m] * (a @ w^T) + bias) with the leading rope_cols columns pair-interleaved per head (see
+    weights.interleave_rope_rows): the ViT qkv projection with RoPE fused into the epilogue."""
+    lib = _lib.load()
+    _chk_bf16(a, w, bias, out)
+    M, K = a.shape
+    N = w.shape[0]
+    assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(0) == sin.stride(0)
+    if GEMM_LOG is not None:
+        GEMM_LOG.append((a, w, bias, out, EPI_NONE, None, False, None, row_scale))
+    _lib.check(lib.padt_gemm_rope_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+                                       _p(row_scale), _p(cos), _p(sin), cos.stride(0), int(rope_cols), int(head_dim)),
+               "padt_gemm_rope_bf16")
+    return out
+
+
 def gemm_rmsnorm(a, w, bias=None, out=None, epilogue=EPI_NONE, eps=1e-6):
     """out = epi(rstd(a) * (a @ w^T) + bias) for decode-sized batches (rows <= 64); w carries the folded norm weight."""
     lib = _lib.load()

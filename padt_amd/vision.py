@@ -114,14 +114,14 @@ class VisionEncoder:
             full = i in v.fullatt_block_indexes
             cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
             ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
-            ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
-            # attn_varlen can rotate q / k itself (rope=), but for the single-tile window segments that lengthens the one
-            # latency chain the kernel consists of: measured 81 us fused vs 31 (rope_half) + 38 (attention) → not used here
-            fuse = False
-            if not fuse:
-                ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)             # q and k heads are adjacent
-            ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd,
-                            rope=(plan.cos, plan.sin) if fuse else None)
+            # qkv projection with the rotary embedding applied in its epilogue (q / k columns are pair-interleaved per head by
+            # prepare_weights): no separate pass over q and k
+            if W.vit_rope_fused:
+                ops.gemm_rope(x, W[p + "qkv.w"], W[p + "qkv.b"], qkv, plan.cos, plan.sin, 2 * vh, hd, row_scale=rstd)
+            else:                                                              # head widths the pair epilogue cannot take
+                ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
+                ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)
+            ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
             ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
             ops.row_rstd(x, out=rstd)
             ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)

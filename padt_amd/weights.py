@@ -164,6 +164,16 @@ def load_checkpoint_state_dict(path: str) -> Dict[str, torch.Tensor]:
 
 
 # ------------------------------------------------------------------------------------------------- prepared layout
+def interleave_rope_rows(w, n_heads, head_dim):
+    """Row permutation of a projection's leading n_heads*head_dim rows (weight (N, K) or bias (N,)): within each head, row
+    2i <- d = i and row 2i + 1 <- d = i + head_dim/2, i.e. rotation pairs become adjacent output columns."""
+    half = head_dim // 2
+    idx = torch.arange(n_heads * head_dim, device=w.device).view(n_heads, 2, half).transpose(1, 2).reshape(-1)
+    out = w.clone()
+    out[: n_heads * head_dim] = w[: n_heads * head_dim][idx]
+    return out
+
+
 def interleave16(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """[gate16 | up16 | gate16 | up16 ...] along dim 0 (rows already padded to a multiple of 16)."""
     n = a.shape[0]
@@ -216,8 +226,13 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         # accumulator with rstd[row] (ops.row_rstd + gemm(row_scale=)) — the normalised activations are never materialised
         n1 = get(s + "norm1.weight").float().to(dev)[None, :]
         n2 = get(s + "norm2.weight").float().to(dev)[None, :]
-        put(d + "qkv.w", get(s + "attn.qkv.weight").to(dev).float() * n1)
-        put(d + "qkv.b", get(s + "attn.qkv.bias"))
+        # q and k rows pair-interleaved per head ((d, d + hd/2) adjacent) so the qkv GEMM's epilogue can apply the rotary
+        # embedding lane-locally (ops.gemm_rope); q·k scores are invariant under the common permutation, v is untouched
+        hd_v = v.hidden_size // v.num_heads
+        W.vit_rope_fused = hd_v % 4 == 0 and os.environ.get("PADT_VIT_ROPE_FUSED", "1") != "0"
+        il = (lambda t: interleave_rope_rows(t, 2 * v.num_heads, hd_v)) if W.vit_rope_fused else (lambda t: t)
+        put(d + "qkv.w", il(get(s + "attn.qkv.weight").to(dev).float() * n1))
+        put(d + "qkv.b", il(get(s + "attn.qkv.bias").to(dev)))
         put(d + "proj.w", get(s + "attn.proj.weight"))
         put(d + "proj.b", get(s + "attn.proj.bias"))
         put(d + "gu.w", interleave16(_pad_rows(get(s + "mlp.gate_proj.weight").to(dev).float() * n2, vi_pad),

@@ -158,6 +158,38 @@ def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
     close_bf16(outs["2"][0], a.float() @ w.float().T + b.float() + r.float(), "column split resid")
 
 
+@pytest.mark.parametrize("M,K", [(1000, 640), (40, 256), (2 * 256 + 24, 512), (300, 136)])
+def test_gemm_rope_epilogue(ops, M, K, monkeypatch):
+    """qkv projection with RoPE fused into the epilogue (pair-interleaved q/k rows) vs Linear → rotate-half RoPE in fp32 on the
+    ORIGINAL layout, compared after undoing the permutation; every kernel family (phase kernel, 128^2, skinny, peeled tail)."""
+    from padt_amd.weights import interleave_rope_rows
+    H, D = 4, 80
+    N = 3 * H * D
+    x, w, b = rnd(M, K, seed=65), rnd(N, K, scale=0.05, seed=66), rnd(N, seed=67)
+    ang = torch.rand(M, D // 2, device="cuda") * 30
+    cos = torch.cat([ang, ang], -1).cos().contiguous()
+    sin = torch.cat([ang, ang], -1).sin().contiguous()
+    rstd = ops.row_rstd(x)
+    lin = (x.float() @ w.float().T) * torch.rsqrt(x.float().pow(2).mean(-1, keepdim=True) + 1e-6) + b.float()
+    qk = lin[:, : 2 * H * D].view(M, 2 * H, D)
+    rot = torch.cat([-qk[..., D // 2:], qk[..., : D // 2]], -1)
+    ref = lin.clone()
+    ref[:, : 2 * H * D] = (qk * cos[:, None] + rot * sin[:, None]).reshape(M, -1)
+    wi, bi = interleave_rope_rows(w, 2 * H, D), interleave_rope_rows(b, 2 * H, D)
+    if M == 2 * 256 + 24:
+        monkeypatch.setenv("PADT_GEMM_PEEL", "2")
+        monkeypatch.setenv("PADT_GEMM_MF", "4")
+    out = torch.zeros(M, N, device="cuda", dtype=BF)
+    ops.gemm_rope(x, wi, bi, out, cos, sin, 2 * H * D, D, row_scale=rstd)
+    # undo the pair interleave of the q / k columns: column 2i <- d = i, column 2i + 1 <- d = i + D/2
+    un = out.float().clone()
+    v = out.float()[:, : 2 * H * D].view(M, 2 * H, D // 2, 2)
+    un[:, : 2 * H * D] = torch.cat([v[..., 0], v[..., 1]], -1).reshape(M, -1)
+    close_bf16(un, ref, f"gemm_rope {M}x{N}x{K}")
+    with pytest.raises(Exception, match="padt_gemm_rope_bf16"):
+        ops.gemm_rope(x, wi, bi, out, cos, sin, 2 * H * D + 4, D)
+
+
 @pytest.mark.parametrize("M", [7, 40, 700])
 def test_gemm_epilogues(ops, M):
     K, N = 256, 384
