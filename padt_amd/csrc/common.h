@@ -60,8 +60,10 @@ struct RopeEpi {
 PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
     if (r.cos == nullptr || n >= r.cols) return;
     const int i = (n % r.D) >> 1;                  // pair index of columns (n, n+1); (n+2, n+3) is pair i + 1
-    const float c0 = r.cos[(long)m * r.ld + i], c1 = r.cos[(long)m * r.ld + i + 1];
-    const float s0 = r.sin[(long)m * r.ld + i], s1 = r.sin[(long)m * r.ld + i + 1];
+    // i is even (n % 4 == 0, D % 4 == 0) and ld is even → one 8-byte load per table
+    const float2 cc = *reinterpret_cast<const float2*>(r.cos + (long)m * r.ld + i);
+    const float2 ss = *reinterpret_cast<const float2*>(r.sin + (long)m * r.ld + i);
+    const float c0 = cc.x, c1 = cc.y, s0 = ss.x, s1 = ss.y;
     const float a0 = o[0], b0 = o[1], a1 = o[2], b1 = o[3];
     o[0] = a0 * c0 - b0 * s0;
     o[1] = b0 * c0 + a0 * s0;

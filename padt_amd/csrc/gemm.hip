@@ -570,7 +570,7 @@ extern "C" int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const 
                                    long ldc, long M, long N, long K, const void* row_scale, const void* rope_cos,
                                    const void* rope_sin, long ld_cs, long rope_cols, int head_dim) {
     if (rope_cos == nullptr || rope_sin == nullptr || head_dim <= 0 || (head_dim & 3) || (rope_cols & 3) || rope_cols > N ||
-        rope_cols % head_dim || (N & 3)) {
+        rope_cols % head_dim || (N & 3) || (ld_cs & 1) || ((uintptr_t)rope_cos & 7) || ((uintptr_t)rope_sin & 7)) {
         padt_set_error("padt_gemm_rope_bf16: need cos/sin tables, head_dim % 4 == 0, rope_cols a multiple of head_dim and <= N, N % 4 == 0");
         return -1;
     }
