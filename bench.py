@@ -271,8 +271,15 @@ def main():
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # PADT_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (ranks share device 0); the
+        # driver's runs use the default: nccl = RCCL over xGMI, one GPU per rank
+        backend = os.environ.get("PADT_DIST_BACKEND", "nccl")
+        local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     else:
         torch.cuda.set_device(0)
     device = f"cuda:{local}" if world > 1 else "cuda:0"
