@@ -92,6 +92,30 @@ class VisionEncoder:
             torch.cuda.current_stream().synchronize()        # tables are shared by every stream that runs this grid later
         return self._plans[key]
 
+    def block(self, i: int, x, plan: VisionPlan, rstd, qkv, att, hbuf, force_full=None):
+        """One ViT block in place on x (P, vh): x += proj(attn(rope(qkv(RMSNorm(x))))); x += down(SwiGLU(RMSNorm(x)))
+        (HF:297-321).  Window segments except for the full-attention layers (padt.py:89-93)."""
+        cfg, W = self.cfg, self.W
+        v = cfg.vision_config
+        vh, H = v.hidden_size, v.num_heads
+        hd = vh // H
+        p = f"vit.{i}."
+        full = (i in v.fullatt_block_indexes) if force_full is None else force_full
+        cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
+        ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
+        # qkv projection with the rotary embedding applied in its epilogue (q / k columns are pair-interleaved per head by
+        # prepare_weights): no separate pass over q and k
+        if W.vit_rope_fused:
+            ops.gemm_rope(x, W[p + "qkv.w"], W[p + "qkv.b"], qkv, plan.cos, plan.sin, 2 * vh, hd, row_scale=rstd)
+        else:                                                              # head widths the pair epilogue cannot take
+            ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
+            ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)
+        ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
+        ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
+        ops.row_rstd(x, out=rstd)
+        ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
+        ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
+
     def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):
         """pixel_values (P, C*T*p*p) fp32 or bf16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
         cfg, W = self.cfg, self.W
@@ -110,22 +134,7 @@ class VisionEncoder:
         att = torch.empty_like(x)
         hbuf = torch.empty((P, W.vit_ipad), device=x.device, dtype=x.dtype)
         for i in range(v.depth):
-            p = f"vit.{i}."
-            full = i in v.fullatt_block_indexes
-            cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
-            ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
-            # qkv projection with the rotary embedding applied in its epilogue (q / k columns are pair-interleaved per head by
-            # prepare_weights): no separate pass over q and k
-            if W.vit_rope_fused:
-                ops.gemm_rope(x, W[p + "qkv.w"], W[p + "qkv.b"], qkv, plan.cos, plan.sin, 2 * vh, hd, row_scale=rstd)
-            else:                                                              # head widths the pair epilogue cannot take
-                ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
-                ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)
-            ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
-            ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
-            ops.row_rstd(x, out=rstd)
-            ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
-            ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
+            self.block(i, x, plan, rstd, qkv, att, hbuf)
         high = x
         ops.rmsnorm(x, W["vit.merger.ln_q"], out=n)
         m = ops.gemm(n.view(plan.N, vh * cfg.merge_unit), W["vit.merger.0.w"], W["vit.merger.0.b"], epilogue=ops.EPI_GELU)

@@ -1,0 +1,119 @@
+"""HIP path at REAL PaDT_Pro_3B shapes against outputs of the reference itself (tests/golden/real_*.npz were produced by running
+the reference's own `custom_visual_forward` block and `vl_decode` / `PaDTDecoder`, tests/golden/make_golden.py): one ViT block at
+2116 x 1280 (window and full attention) and the 98 M-parameter PaDT decoder with 3 objects over 2 images.
+
+The reference ran in fp32; the HIP path stores weights and activations in bf16 → tolerances are bf16-storage sized and written
+at each assert."""
+import dataclasses
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _t(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+def _seeded(shape, name, scale, jitter_one=False):
+    import zlib
+    g = torch.Generator().manual_seed(zlib.crc32(name.encode()) & 0x7FFFFFFF)
+    t = scale * torch.randn(shape, generator=g)
+    return 1 + t if jitter_one else t
+
+
+def rel(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item(), ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
+
+
+def test_vit_block_real_shape_against_reference_output(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    import padt_oracle as O
+    from padt_amd.config import VisionConfig
+    from padt_amd.vision import VisionEncoder
+    from padt_amd.weights import prepare_weights, synthetic_state_dict
+    z = np.load(f"{golden_dir}/real_vit_block.npz")
+    base = padt_amd.small_test_config()
+    cfg = dataclasses.replace(base, vision_config=VisionConfig(hidden_size=1280, depth=1, num_heads=16, intermediate_size=3420,
+                                                               fullatt_block_indexes=(), out_hidden_size=base.hidden_size))
+    sd = synthetic_state_dict(cfg, seed=0, device="cpu")
+    ocfg = O.OracleConfig()
+    for k, shp in O.weight_shapes(ocfg).items():                    # the seeded block weights the reference ran with
+        if k.startswith("visual.blocks.0."):
+            sd[k] = _seeded(shp, k, 0.1, True) if (k.endswith("norm1.weight") or k.endswith("norm2.weight")) else _seeded(shp, k, 0.02)
+    W = prepare_weights(sd, cfg, device="cuda")
+    enc = VisionEncoder(cfg, W, "cuda")
+    grid = torch.tensor([[1, 46, 46]])
+    plan = enc.plan(grid)
+    g = torch.Generator().manual_seed(int(z["x_seed"]))
+    x0 = torch.randn(2116, 1280, generator=g).to(torch.bfloat16).cuda()
+    rows = _t(z["rows"])
+    for full, key in ((False, "y_win"), (True, "y_full")):
+        x = x0.clone()
+        bufs = (torch.empty(2116, device="cuda", dtype=torch.float32), torch.empty(2116, 3 * 1280, device="cuda", dtype=torch.bfloat16),
+                torch.empty_like(x), torch.empty(2116, W.vit_ipad, device="cuda", dtype=torch.bfloat16))
+        enc.block(0, x, plan, *bufs, force_full=full)
+        mx, rms = rel(x[rows.cuda()], _t(z[key]))
+        print(f"\\n[real ViT block {key}] vs reference: rel max {mx:.3e} rms {rms:.3e}")
+        assert rms < 1.5e-2 and mx < 6e-2, f"{key}: rel err max {mx:.3e} rms {rms:.3e}"   # bf16 weights + activations, 7 kernels deep
+
+
+def test_padt_decoder_real_shape_against_reference_output(golden_dir):
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    import padt_oracle as O
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    z = np.load(f"{golden_dir}/real_decoder.npz")
+    base = padt_amd.small_test_config(layers=1, vit_depth=1)
+    cfg = dataclasses.replace(base, hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, intermediate_size=256,
+                              vision_config=dataclasses.replace(base.vision_config, out_hidden_size=2048),
+                              vl_decoder={"hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "use_mask_loss": True})
+    sd = synthetic_state_dict(cfg, seed=0, device="cpu")
+    ocfg = O.OracleConfig()
+    for k, shp in O.weight_shapes(ocfg).items():
+        if k.startswith("vl_decoder."):
+            sd[k] = _seeded(shp, k, 0.1, True) if O._is_norm_weight(k) else _seeded(shp, k, 0.02 if k.endswith("bias") else 0.03)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    g = torch.Generator().manual_seed(123)
+    _ = torch.randn(2116, 1280, generator=g)                       # same stream position as make_golden.py
+    _ = torch.randint(0, 2116, (48,), generator=g)
+    grids = torch.tensor([[1, 46, 30], [1, 8, 8]])
+    Ps = [46 * 30, 64]
+    low = torch.randn(sum(Ps) // 4, 2048, generator=g)
+    high = torch.randn(sum(Ps), 1280, generator=g)
+    wi, _ = O.window_index(grids, 2, 112, 14)
+    c, s = O.vit_rotary(ocfg, grids, wi)
+    feats = [[torch.randn(5, 2048, generator=g), torch.randn(2, 2048, generator=g)], [torch.randn(4, 2048, generator=g)]]
+    bf = torch.bfloat16
+    out = model.vl_decode([[f.to(bf).cuda() for f in fs] for fs in feats], low.to(bf).cuda(), high.to(bf).cuda(), grids,
+                          (c.cuda(), s.cuda()))
+    assert out["sample_idx"] == z["sample_idx"].tolist() and list(out["pred_mask"].shape) == z["mask_shape"].tolist()
+    assert torch.equal(out["pred_mask_valid_hw"][0].cpu(), _t(z["valid_h"])) and torch.equal(out["pred_mask_valid_hw"][1].cpu(), _t(z["valid_w"]))
+    # (1) against the reference's fp32 run: the difference is dominated by rounding its fp32 weights / inputs to bf16 (what the
+    #     reference's own GPU path does too), measured ~1.4e-2 on box coordinates with these random N(0, 0.03^2) weights
+    db = (out["pred_boxes"].float().cpu() - _t(z["pred_boxes"])).abs().max().item()
+    ds = (out["pred_score"].float().cpu() - _t(z["pred_score"])).abs().max().item()
+    mx, rms = rel(out["pred_mask"].flatten()[_t(z["mask_idx"]).cuda()], _t(z["mask_vals"]))
+    print(f"\n[real PaDT decoder] vs reference fp32: box |d|max {db:.3e} score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}")
+    assert db < 4e-2 and ds < 0.15 * (abs(z["pred_score"]).max() + 1) and rms < 6e-2
+    # (2) against the oracle (which test_oracle_golden pins to that same reference output to 1e-5) fed the SAME bf16-rounded
+    #     weights and inputs: isolates the kernels' own arithmetic
+    r = lambda t_: t_.to(bf).float()
+    dwb = {k: r(v) for k, v in sd.items() if k.startswith("vl_decoder.")}
+    odec = O.vl_decode(dwb, ocfg, [[r(f) for f in fs] for fs in feats], r(low), r(high), grids, (c, s))
+    db2 = (out["pred_boxes"].float().cpu() - odec["pred_boxes"]).abs().max().item()
+    ds2 = (out["pred_score"].float().cpu() - odec["pred_score"]).abs().max().item()
+    mx2, rms2 = rel(out["pred_mask"], odec["pred_mask"])
+    print(f"[real PaDT decoder] vs oracle on bf16 operands: box |d|max {db2:.3e} score |d|max {ds2:.3e} mask rel max {mx2:.3e} rms {rms2:.3e}")
+    # ~35 kernel outputs are rounded to bf16 on the way (2^-9 relative each, random N(0, 0.03^2) weights of gain > 1): measured
+    # 7.6e-3 on box coordinates, 1.0e-2 rms on mask logits — the reference's own bf16 GPU path sits at the same distance
+    assert db2 < 2e-2, f"boxes differ from the oracle by {db2:.3e}"                        # boxes in [0, 1]
+    assert ds2 < 5e-2 * (odec["pred_score"].abs().max().item() + 1)
+    assert rms2 < 2e-2 and mx2 < 1e-1
