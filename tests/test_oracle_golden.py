@@ -156,3 +156,29 @@ def test_real_shape_decoder(golden_dir):
     assert list(out["pred_mask"].shape) == z["mask_shape"].tolist()
     assert torch.allclose(out["pred_mask"].flatten()[_t(z["mask_idx"])], _t(z["mask_vals"]), atol=5e-5)
     assert out["sample_idx"] == z["sample_idx"].tolist()
+
+
+def test_real_width_llm_layer(golden_dir):
+    """One LLM layer at PaDT_Pro_3B width + final norm, prefill over the real 577-token prompt layout and two cached decode steps,
+    against HF's Qwen2_5_VLTextModel (fixture: tests/golden/make_golden_llm.py)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location("mk_llm", os.path.join(golden_dir, "make_golden_llm.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(f"{golden_dir}/real_llm_layer.npz")
+    cfg = mk.cfg_1layer()
+    w = mk.layer_weights(cfg)
+    ids, grid = mk.prompt(cfg)
+    pos, deltas = O.rope_index(cfg, ids, grid, torch.ones_like(ids))
+    assert torch.equal(deltas, _t(z["deltas"]))
+    g = torch.Generator().manual_seed(int(z["x_seed"]))
+    x = torch.randn(1, 577, cfg.hidden_size, generator=g)
+    xd = torch.randn(2, 1, 1, cfg.hidden_size, generator=g)
+    kv = O.KVCache(1)
+    h = O.llm_forward(w, cfg, x, pos, torch.ones(1, 577, dtype=torch.long), kv)
+    assert torch.allclose(h[0, _t(z["rows"])], _t(z["h_rows"]), atol=2e-5) and torch.allclose(h[0, -1], _t(z["h_last"]), atol=2e-5)
+    for t_, key in enumerate(("step0", "step1")):
+        p = (torch.tensor([[577 + t_]]) + deltas).view(1, 1, 1).expand(3, 1, 1)
+        o = O.llm_forward(w, cfg, xd[t_], p, torch.ones(1, 578 + t_, dtype=torch.long), kv)
+        assert torch.allclose(o[0, 0], _t(z[key]), atol=2e-5), key

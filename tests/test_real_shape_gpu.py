@@ -117,3 +117,68 @@ def test_padt_decoder_real_shape_against_reference_output(golden_dir):
     assert db2 < 2e-2, f"boxes differ from the oracle by {db2:.3e}"                        # boxes in [0, 1]
     assert ds2 < 5e-2 * (odec["pred_score"].abs().max().item() + 1)
     assert rms2 < 2e-2 and mx2 < 1e-1
+
+
+def test_llm_layer_real_width_against_hf_text_model(golden_dir):
+    """One LLM layer at PaDT_Pro_3B width (16/2 heads x 128, MLP 11008, mRoPE [16,24,24]) + final norm: packed prefill over the
+    real 577-token prompt layout, then two decode steps through the fused decode kernels — against outputs of HF's
+    Qwen2_5_VLTextModel (fixture from tests/golden/make_golden_llm.py).  The fixture feeds inputs_embeds directly: every prompt
+    position has a unique token id (or is an image token), so the embedding table / image rows carry those vectors."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import importlib.util
+    import os
+    import padt_amd
+    from padt_amd import ops
+    from padt_amd.llm import plan_prompt
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    spec = importlib.util.spec_from_file_location("mk_llm", os.path.join(golden_dir, "make_golden_llm.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(f"{golden_dir}/real_llm_layer.npz")
+    ocfg = mk.cfg_1layer()
+    w = mk.layer_weights(ocfg)
+    ids, grid = mk.prompt(ocfg)
+    g = torch.Generator().manual_seed(int(z["x_seed"]))
+    x = torch.randn(1, 577, ocfg.hidden_size, generator=g)
+    xd = torch.randn(2, 1, 1, ocfg.hidden_size, generator=g)
+    base = padt_amd.small_test_config(layers=1, vit_depth=1)
+    cfg = dataclasses.replace(base, vocab_size=ocfg.vocab_size, hidden_size=2048, num_attention_heads=16, num_key_value_heads=2,
+                              intermediate_size=11008, image_token_id=ocfg.image_token_id,
+                              vision_start_token_id=ocfg.vision_start_token_id, eos_token_id=ocfg.eos_token_id,
+                              pad_token_id=ocfg.pad_token_id,
+                              vision_config=dataclasses.replace(base.vision_config, out_hidden_size=2048))
+    sd = synthetic_state_dict(cfg, seed=0, device="cpu")
+    for k, v in w.items():
+        sd[k] = v
+    emb = torch.zeros(cfg.vocab_size, 2048)
+    is_img = ids[0] == cfg.image_token_id
+    emb[ids[0][~is_img]] = x[0][~is_img]                            # unique text ids → their input vectors
+    emb[900], emb[901] = xd[0, 0, 0], xd[1, 0, 0]                   # the two decode-step inputs
+    sd["model.embed_tokens.weight"] = emb
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    lm = model.lm
+    plan = plan_prompt(cfg, ids, torch.ones_like(ids), grid, "cuda")
+    sess = lm.session(1, 577 + 4, 529, 4)
+    img = x[0][is_img].to(torch.bfloat16).cuda()
+    hn = lm.prefill(plan, img, sess)
+    rows = _t(z["rows"]).cuda()
+    mx, rms = rel(hn[rows], _t(z["h_rows"]))
+    print(f"\\n[real-width LLM layer, prefill] vs HF text model: rel max {mx:.3e} rms {rms:.3e}")
+    assert rms < 1e-2 and mx < 5e-2
+    # decode steps: position = 577 + t + rope_delta on all three axes, append slot = 577 + t
+    delta = int(z["deltas"][0, 0])
+    sess.vrt_off.zero_()
+    for t_, key in enumerate(("step0", "step1")):
+        sess.cur_tok.fill_(900 + t_)
+        sess.slot.fill_(577 + t_)
+        sess.lens.fill_(578 + t_)
+        sess.pos3.fill_(577 + t_ + delta)
+        sess.unfinished.fill_(1)
+        sess.step.zero_()
+        sess.step_kernels()
+        mx, rms = rel(sess.hn[0], _t(z[key]))
+        print(f"[real-width LLM layer, decode step {t_}] vs HF text model: rel max {mx:.3e} rms {rms:.3e}")
+        assert rms < 1e-2 and mx < 5e-2
+    assert int(sess.err) == 0
