@@ -182,3 +182,45 @@ def test_llm_layer_real_width_against_hf_text_model(golden_dir):
         print(f"[real-width LLM layer, decode step {t_}] vs HF text model: rel max {mx:.3e} rms {rms:.3e}")
         assert rms < 1e-2 and mx < 5e-2
     assert int(sess.err) == 0
+
+
+def test_vrt_head_real_vocabulary():
+    """The logit head at the real table size (151936 text rows + 8 x 529 prototype rows, D = 2048, 8 samples), row-major and
+    packed: logits vs a plain fp32 matmul, arg-max identical wherever the top-2 margin exceeds the bf16-input noise floor."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from padt_amd import ops
+    V, NP, D, B = 151936, 8 * 529, 2048, 8
+    g = torch.Generator(device="cuda").manual_seed(11)
+    E = (torch.randn(V, D, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    P = (torch.randn(NP, D, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    h = torch.randn(B, D, device="cuda", generator=g).to(torch.bfloat16)
+    off = torch.arange(0, NP + 1, 529, dtype=torch.int32, device="cuda")
+    nblk = ops.vrt_head_nblk(V, NP)
+    ref = h.float() @ torch.cat([E, P]).float().T
+    allow = torch.zeros(B, V + NP, dtype=torch.bool, device="cuda")
+    allow[:, :V] = True
+    for b in range(B):
+        allow[b, V + b * 529: V + (b + 1) * 529] = True
+    ref = ref.masked_fill(~allow, float("-inf"))
+    Ep = ops.pack_weight(E)
+    hp = torch.zeros(16, D, device="cuda", dtype=torch.bfloat16)
+    ops.pack_rows(h, hp, B, to_packed=True)
+    for packed in (False, True):
+        pv = torch.zeros(nblk * B, device="cuda")
+        pi = torch.zeros(nblk * B, dtype=torch.int32, device="cuda")
+        lg = torch.zeros(B, V + NP, device="cuda")
+        if packed:
+            ops.vrt_head(hp, E, P, off, pv, pi, 151645, logits=lg, table_packed=Ep, rows=B)
+        else:
+            ops.vrt_head(h, E, P, off, pv, pi, 151645, logits=lg)
+        fin = torch.isfinite(ref)
+        assert torch.equal(torch.isfinite(lg), fin)
+        err = (lg[fin] - ref[fin]).abs().max().item()
+        assert err <= 2e-5 * ref[fin].abs().max().item() + 1e-5, f"logits differ by {err:.3e}"   # same bf16 operands, fp32 accumulate
+        best = pv.view(nblk, B).max(0)
+        tok = pi.view(nblk, B).gather(0, best.indices[None])[0].long()
+        top2 = ref.topk(2, dim=-1)
+        for b in range(B):
+            if (top2.values[b, 0] - top2.values[b, 1]).item() > 1e-4:
+                assert int(tok[b]) == int(top2.indices[b, 0])
