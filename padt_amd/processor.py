@@ -1,6 +1,8 @@
 """Processor wrapper and completion parser — drop-in for ``padt_processor.py`` (same names, arguments, return values and
 error behaviour, including the quirks listed in SURVEY.md Appendix C.5/6/10).  Pure host logic: token ids and strings.
 """
+from typing import List, Tuple
+
 import torch
 
 try:  # the real tokenizer path uses HF's AddedToken; fake tokenizers in tests accept plain objects with .content
@@ -13,139 +15,150 @@ except Exception:  # pragma: no cover
             return o
 
 
-class VisonTextProcessingClass(object):
-    """padt_processor.py:4-57."""
+class VisonTextProcessingClass:
+    """Drop-in for the reference's processor wrapper (padt_processor.py:4-57): everything not defined here is forwarded to the
+    wrapped HF processor; on top of it the wrapper owns the VRT vocabulary — ``<|VRT_k|>`` must tokenise to
+    ``embedding_rows + k`` — and the local ↔ global VRT id shift of a batch."""
+
+    EMPTY_TOKEN = "<|empty_token_%d|>"
+    VRT_TOKEN = "<|VRT_%d|>"
 
     def __init__(self, processing_class, spatial_merge_size=2):
         self.processing_class = processing_class
         self.spatial_merge_size = spatial_merge_size
-        self.model_embed_token_size = len(processing_class.tokenizer.get_vocab())
+        self.model_embed_token_size = self._vocab_size()
+
+    def _vocab_size(self) -> int:
+        return len(self.processing_class.tokenizer.get_vocab())
 
     def __getattr__(self, name: str):
-        if hasattr(self.processing_class, name):
-            return getattr(self.processing_class, name)
+        # reached only when normal lookup fails: forward to the wrapped processor (tokenizer, batch_decode, apply_chat_template …)
+        inner = self.__dict__.get("processing_class")
+        if inner is not None and hasattr(inner, name):
+            return getattr(inner, name)
         raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
 
+    # ---- vocabulary management
     def prepare(self, model_embed_token_size):
-        """Pad the tokenizer with <|empty_token_i|> up to the embedding rows so <|VRT_k|> gets id rows+k (:15-21)."""
+        """Fill the gap between the tokenizer's vocabulary and the embedding table with ``<|empty_token_i|>`` specials, so the
+        VRT tokens added later start exactly at row ``model_embed_token_size`` (padt_processor.py:15-21)."""
         self.model_embed_token_size = model_embed_token_size
-        need_pad_size = model_embed_token_size - len(self.tokenizer.get_vocab())
-        assert '<|empty_token_0|>' in self.tokenizer.vocab or need_pad_size > 0
-        if need_pad_size > 0:
-            self.tokenizer.add_tokens([AddedToken("<|empty_token_%d|>" % i, lstrip=False, rstrip=False, special=True,
-                                                  normalized=False) for i in range(need_pad_size)])
+        missing = model_embed_token_size - self._vocab_size()
+        assert missing > 0 or self.EMPTY_TOKEN % 0 in self.tokenizer.vocab
+        if missing > 0:
+            self.tokenizer.add_tokens([AddedToken(self.EMPTY_TOKEN % i, lstrip=False, rstrip=False, special=True, normalized=False)
+                                       for i in range(missing)])
         return True
 
     def set_image_grid_thw(self, image_grid_thw):
-        """Grow the vocabulary to the largest merged-patch count in the batch (:23-28)."""
-        max_visual_patch_num = image_grid_thw.cumprod(-1).max(dim=0)[0][-1] // (self.spatial_merge_size) ** 2
-        have = len(self.processing_class.tokenizer.get_vocab()) - self.model_embed_token_size
-        if have < max_visual_patch_num:
+        """Make sure ``<|VRT_0|> … <|VRT_{n-1}|>`` exist for n = the largest merged-patch count in the batch (:23-28)."""
+        wanted = int(image_grid_thw.prod(dim=-1).max()) // self.spatial_merge_size ** 2
+        present = self._vocab_size() - self.model_embed_token_size
+        if present < wanted:
             self.processing_class.tokenizer.add_tokens(
-                [AddedToken("<|VRT_%d|>" % i, lstrip=False, rstrip=False, special=False, normalized=False)
-                 for i in range(have, int(max_visual_patch_num))])
+                [AddedToken(self.VRT_TOKEN % i, lstrip=False, rstrip=False, special=False, normalized=False)
+                 for i in range(present, wanted)])
         return True
 
     def __call__(self, *args, **kwargs):
-        parent_ret = self.processing_class(*args, **kwargs)
-        if 'image_grid_thw' in parent_ret:
-            self.set_image_grid_thw(parent_ret['image_grid_thw'])
-        return parent_ret
+        batch = self.processing_class(*args, **kwargs)
+        if 'image_grid_thw' in batch:
+            self.set_image_grid_thw(batch['image_grid_thw'])
+        return batch
 
-    def _offsets(self, input_ids, image_grid_thw):
-        per = torch.nn.functional.pad((image_grid_thw.cumprod(-1)[:, -1] // (self.spatial_merge_size) ** 2).cumsum(dim=-1),
-                                      (1, 0), 'constant', 0)
-        return per[:-1, None].expand(-1, input_ids.shape[1]).to(input_ids.device)
+    # ---- VRT ids: local (per image, 0-based) ↔ global (offset by the merged patches of the samples before it)
+    def _shift_vrt_ids(self, input_ids, image_grid_thw, sign: int):
+        is_vrt = input_ids >= self.model_embed_token_size
+        if bool(is_vrt.any()):
+            merged = image_grid_thw.prod(dim=-1) // self.spatial_merge_size ** 2
+            start = (merged.cumsum(0) - merged).to(input_ids.device)           # exclusive prefix sum: first patch of each sample
+            input_ids[is_vrt] += sign * start[:, None].expand_as(input_ids)[is_vrt]
+        return input_ids                                                       # modified in place, like the reference
 
     def assign_to_global_vrt_id(self, input_ids, image_grid_thw):
-        """In place, like the reference (:36-42): ids >= embed rows get the sample's cumulative patch offset added."""
-        visual_patch_mask = input_ids >= self.model_embed_token_size
-        if visual_patch_mask.sum() > 0:
-            input_ids[visual_patch_mask] += self._offsets(input_ids, image_grid_thw)[visual_patch_mask]
-        return input_ids
+        return self._shift_vrt_ids(input_ids, image_grid_thw, +1)
 
     def assign_to_local_vrt_id(self, input_ids, image_grid_thw):
-        visual_patch_mask = input_ids >= self.model_embed_token_size
-        if visual_patch_mask.sum() > 0:
-            input_ids[visual_patch_mask] -= self._offsets(input_ids, image_grid_thw)[visual_patch_mask]
-        return input_ids
+        return self._shift_vrt_ids(input_ids, image_grid_thw, -1)
 
     def pid2vrt(self, patch_ids):
-        if type(patch_ids) == int:
-            patch_ids = [patch_ids]
-        else:
-            patch_ids = [int(i) for i in patch_ids]
-        return ''.join(['<|VRT_%d|>' % i for i in patch_ids])
+        ids = [patch_ids] if type(patch_ids) == int else [int(i) for i in patch_ids]
+        return ''.join(self.VRT_TOKEN % i for i in ids)
+
+
+def _scan_completion(toks: List[str], eos_token: str, free_form: bool) -> List[Tuple[str, List[int], str]]:
+    """String state machine of padt_processor.py:92-144 on one sample's per-token strings → [(label, VRT step indices, VRT text)].
+
+    Two flags: inside an ``<answer>`` span (or ``free_form`` = no thinking section expected, so objects may appear anywhere) and
+    inside a quoted object name.  A run of ``<|VRT_k|>`` tokens closes the object that the last quoted name labelled.  List
+    indexing is deliberately unguarded: the reference looks one and two tokens ahead and lets the IndexError escape when a
+    tag or a VRT run touches the end of the completion — the caller drops that sample (padt_processor.py:146-150)."""
+    objects: List[Tuple[str, List[int], str]] = []
+    answering = quoting = False
+    name = ""
+    i = 0
+    while i < len(toks):
+        tok = toks[i]
+        if eos_token in tok:
+            break
+        opens = (not answering) and '<' in tok and '</' not in tok and 'answer' in toks[i + 1] and '>' in toks[i + 2]
+        if opens:
+            answering = True
+            i += 3
+            continue
+        if answering or free_form:
+            if '</' in tok and 'answer' in toks[i + 1] and '>' in toks[i + 2]:
+                break
+            if '"' in tok:
+                if quoting:                                   # closing quote: text before it still belongs to the name
+                    name = (name + tok.split('"')[0]).strip()
+                else:                                         # opening quote: the name starts after it
+                    name = tok.split('"')[1]
+                quoting = not quoting
+                i += 1
+                continue
+            if '<|VRT_' in tok:
+                quoting = False
+                steps, text = [], ""
+                while '<|VRT_' in toks[i]:                    # IndexError when the run reaches the end of the completion
+                    steps.append(i)
+                    text += toks[i]
+                    i += 1
+                objects.append((name, steps, text))
+                continue
+            if quoting:
+                name += tok
+        i += 1
+    return objects
 
 
 def parseVRTintoCompletion(processor, completion_ids, hidden_states, need_thinking_mask=None, image_prototype=None,
                            image_grid_thw=None):
     """padt_processor.py:60-151.  ``hidden_states[step][-1][batch_idx]`` must be the (Lq, D) last-layer state that
-    PREDICTED completion token ``step`` (our generate() returns a lazy sequence with exactly that indexing)."""
-    ret_list, ret_completions, ret_labels, ret_vrts, ret_vrts_feats = [], [], [], [], []
+    PREDICTED completion token ``step`` (our generate() returns a lazy sequence with exactly that indexing).
+    → (completions, per-sample lists of object features, labels, VRT strings, prototype features)."""
     if image_grid_thw is not None:
-        vision_patch_nums = torch.nn.functional.pad((image_grid_thw.cumprod(-1)[:, -1] // 4).cumsum(-1), (1, 0), 'constant', 0)
+        patch_starts = torch.nn.functional.pad((image_grid_thw.cumprod(-1)[:, -1] // 4).cumsum(-1), (1, 0), 'constant', 0)
     if need_thinking_mask is None:
         need_thinking_mask = torch.ones(len(completion_ids)).to(torch.bool)
-
-    for batch_idx, completion in enumerate(completion_ids):
+    completions, all_feats, all_labels, all_vrts, all_proto = [], [], [], [], []
+    for b, completion in enumerate(completion_ids):
         toks = processor.batch_decode(completion)
-        ret_completions.append(''.join(toks))
-        s_list, s_labels, s_vrts, s_vfeats = [], [], [], []
-        i = 0
-        without_thinking = not need_thinking_mask[batch_idx].item()
-        in_answer = False
-        in_name = False
-        label = ""
+        completions.append(''.join(toks))
+        feats, labels, vrts, protos = [], [], [], []
         try:
-            while i < len(toks):
-                if processor.tokenizer.eos_token in toks[i]:
-                    break
-                if in_answer is False and '<' in toks[i] and '</' not in toks[i] and 'answer' in toks[i + 1] and '>' in toks[i + 2]:
-                    in_answer = True
-                    i += 3
-                    continue
-                if in_answer is True or without_thinking:
-                    if '</' in toks[i] and 'answer' in toks[i + 1] and '>' in toks[i + 2]:
-                        in_answer = False
-                        break
-                    else:
-                        if '"' in toks[i] and in_name is False:
-                            in_name = True
-                            label = toks[i].split('"')[1]
-                            i += 1
-                            continue
-                        if '"' in toks[i] and in_name is True:
-                            in_name = False
-                            label += toks[i].split('"')[0]
-                            label = label.strip()
-                            i += 1
-                            continue
-                        if '<|VRT_' in toks[i]:
-                            in_name = False
-                            run_states, run_str = [], ""
-                            while '<|VRT_' in toks[i]:                 # IndexError at end-of-completion → sample dropped
-                                run_states.append(hidden_states[i][-1][batch_idx])
-                                run_str += toks[i]
-                                i += 1
-                            s_list.append(torch.cat(run_states, dim=0))
-                            s_labels.append(label)
-                            s_vrts.append(run_str)
-                            if image_prototype is not None and image_grid_thw is not None:
-                                ids = processor(text=run_str, return_tensors='pt')['input_ids'].to(image_grid_thw.device)[0, ...] \
-                                    + vision_patch_nums[batch_idx] - processor.model_embed_token_size
-                                s_vfeats.append(image_prototype[ids])
-                            continue
-                        if in_name:
-                            label += toks[i]
-                i += 1
-            ret_list.append(s_list)
-            ret_labels.append(s_labels)
-            ret_vrts.append(s_vrts)
-            ret_vrts_feats.append(s_vfeats)
-        except:  # noqa: E722 — the reference swallows everything per sample (padt_processor.py:146-150)
-            ret_list.append([])
-            ret_labels.append([])
-            ret_vrts.append([])
-            ret_vrts_feats.append([])
-    return ret_completions, ret_list, ret_labels, ret_vrts, ret_vrts_feats
+            for name, steps, text in _scan_completion(toks, processor.tokenizer.eos_token, not need_thinking_mask[b].item()):
+                feats.append(torch.cat([hidden_states[s][-1][b] for s in steps], dim=0))
+                labels.append(name)
+                vrts.append(text)
+                if image_prototype is not None and image_grid_thw is not None:
+                    rows = processor(text=text, return_tensors='pt')['input_ids'].to(image_grid_thw.device)[0, ...] \
+                        + patch_starts[b] - processor.model_embed_token_size
+                    protos.append(image_prototype[rows])
+        except Exception:  # the reference swallows everything per sample and returns empty lists for it (padt_processor.py:146-150)
+            feats, labels, vrts, protos = [], [], [], []
+        all_feats.append(feats)
+        all_labels.append(labels)
+        all_vrts.append(vrts)
+        all_proto.append(protos)
+    return completions, all_feats, all_labels, all_vrts, all_proto
