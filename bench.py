@@ -34,7 +34,7 @@ def parse_args():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tnew", type=int, default=28)
-    ap.add_argument("--model", default="3b", choices=["3b", "small"])
+    ap.add_argument("--model", default="3b", choices=["3b", "7b", "small"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--merge", type=int, default=8, help="consecutive batches of 8 whose decode steps share one session "
@@ -52,8 +52,8 @@ def parse_args():
 def build_model(args, device):
     import padt_amd
     from padt_amd.modeling import PaDTForConditionalGeneration
-    cfg = padt_amd.padt_pro_3b() if args.model == "3b" else padt_amd.small_test_config()
-    grid_hw = (46, 46) if args.model == "3b" else (10, 12)
+    cfg = {"3b": padt_amd.padt_pro_3b, "7b": padt_amd.padt_pro_7b, "small": padt_amd.small_test_config}[args.model]()
+    grid_hw = (10, 12) if args.model == "small" else (46, 46)
     model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device)
     return cfg, model, grid_hw
 
@@ -209,7 +209,7 @@ def cpu_baseline_leg(cfg, args):
         for _ in range(reps):
             fn()
         return (time.perf_counter() - t0) / reps
-    H = W_ = 46 if args.model == "3b" else 10
+    H = W_ = 10 if args.model == "small" else 46
     grid = torch.tensor([[1, H, W_]])
     P, N = H * W_, H * W_ // 4
     L, T = 15 + N + 33, args.tnew
@@ -394,7 +394,7 @@ def main():
                                    "mask head on), bf16, random-init 3.85B weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder "
                                    "per batch, decode steps of %d consecutive batches share one weight pass (in-flight batching, "
                                    "per-sample results bit-identical to batch-at-a-time)" % (args.batch, args.tnew, args.batch, args.merge)
-                       if args.model == "3b" else "small_test_config (plumbing)",
+                       if args.model == "3b" else ("PaDT_Pro_7B (untied head), same REC workload" if args.model == "7b" else "small_test_config (plumbing)"),
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth * args.merge,
                        "decode_groups_in_flight": args.depth, "batches_per_decode_group": args.merge},
             "alg_tflops_e2e": round(value * ALG_TFLOP_PER_IMAGE, 1) if args.model == "3b" else None,

@@ -327,7 +327,7 @@ def test_attn_online_softmax_rescale_branch(ops):
     close_bf16(out, ref_attn(q, k, v, [0, L], [0, L], H, H, D, False), "rescale", ulps=6)
 
 
-@pytest.mark.parametrize("D,Hq,Hkv", [(128, 16, 2), (32, 4, 2)])
+@pytest.mark.parametrize("D,Hq,Hkv", [(128, 16, 2), (32, 4, 2), (128, 28, 4)])
 def test_decode_attn(ops, D, Hq, Hkv):
     B, S_max = 3, 640
     lens = [578, 130, 64]
@@ -388,7 +388,7 @@ def test_gemm_packed_activations(ops, M, N, K):
         assert torch.equal(un, ref_sw), "SwiGLU into a packed buffer"
 
 
-@pytest.mark.parametrize("D,Hq,Hkv,sec", [(128, 16, 2, (16, 24, 24)), (32, 4, 2, (4, 6, 6))])
+@pytest.mark.parametrize("D,Hq,Hkv,sec", [(128, 16, 2, (16, 24, 24)), (32, 4, 2, (4, 6, 6)), (128, 28, 4, (16, 24, 24))])
 def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     """rope table + (rope, append, split attention) + merge == llm_qkv_post → decode_attn, and the fp32 reference."""
     B, S_max = 3, 1344
