@@ -91,7 +91,9 @@ def roofline_leg(model, inp, args, cfg):
     run_step(model, inp, args, 1)
     torch.cuda.synchronize()
     log, ops.GEMM_LOG = ops.GEMM_LOG, None
-    tile = [c for c in log if c[0].shape[0] > 64]                       # launches that take gemm_tile_kernel
+    # launches that take a tile kernel (M > 64); "hp" entries are the split-precision decoder GEMMs (ops.gemm_hp: A = [hi | lo],
+    # W = [W | W], K' = 2K): their ALGORITHMIC work is the reference's 2*M*N*K, half of what the MFMA pipe executes
+    tile = [c for c in log if (c[8] if isinstance(c[0], str) else c[0].shape[0]) > 64]
     vip, vi = model.W.vit_ipad, cfg.vision_config.intermediate_size
     lip, li = model.W.llm_ipad, cfg.intermediate_size
     dip, di = model.W.dec_ipad, cfg.vl_decoder["intermediate_size"]
@@ -105,7 +107,14 @@ def roofline_leg(model, inp, args, cfg):
         return n
     flops = 0.0
     alg_bytes = 0.0
-    for (a, w, bias, out, epi, res, f32, K, rs) in tile:
+    for c in tile:
+        if isinstance(c[0], str):
+            _, a, w, bias, out, epi, res, out_mode, M = c
+            n, k = alg(w.shape[0]), alg(w.shape[1] // 2)
+            flops += 2.0 * M * n * k
+            alg_bytes += 4.0 * M * k + 2.0 * n * k + 4.0 * M * n * (2 if res is not None else 1)
+            continue
+        (a, w, bias, out, epi, res, f32, K, rs) = c
         k = K if K is not None else a.shape[1]
         flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(k)
         n_out = alg(w.shape[0]) // (2 if epi == 3 else 1)
@@ -118,8 +127,12 @@ def roofline_leg(model, inp, args, cfg):
     stream = torch.cuda.current_stream().cuda_stream
 
     def replay():
-        for (a, w, bias, out, epi, res, f32, K, rs) in tile:
-            ops.gemm(a, w, bias, out=out, epilogue=epi, residual=res, out_f32=f32, K=K, row_scale=rs)
+        for c in tile:
+            if isinstance(c[0], str):
+                ops.gemm_hp(c[1], c[2], c[3], out=c[4], epilogue=c[5], residual=c[6], out_mode=c[7], M=c[8])
+            else:
+                (a, w, bias, out, epi, res, f32, K, rs) = c
+                ops.gemm(a, w, bias, out=out, epilogue=epi, residual=res, out_f32=f32, K=K, row_scale=rs)
     replay()
     torch.cuda.synchronize()
     reps, best = 3, None
@@ -134,7 +147,9 @@ def roofline_leg(model, inp, args, cfg):
     if args.breakdown:                                             # per-shape efficiency of the tile kernel (stderr)
         shapes = {}
         for c in tile:
-            a, w, bias, out, epi, res, f32, K = c
+            if isinstance(c[0], str):
+                continue
+            a, w, bias, out, epi, res, f32, K = c[:8]
             shapes.setdefault((a.shape[0], w.shape[0], K if K is not None else a.shape[1], epi), []).append(c)
         for key, calls in sorted(shapes.items()):
             for c in calls[:2]:

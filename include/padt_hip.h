@@ -142,6 +142,36 @@ int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, const int* pos
 int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
                       const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm);
 
+/* ---- split-precision ("hp") PaDT decoder (padt_decoder.py:20-276 at fp32-class activation precision) -------------------
+ * The north star's 1e-3 box / mask-logit tolerance is not reachable with bf16 activation storage between the decoder's kernels
+ * (tests/study_decoder_precision.py: each stored tensor of the query path costs 1-2.5e-3 by itself).  The hp decoder keeps
+ * fp32 residual streams and hands every GEMM its A operand as a bf16 (hi, lo) pair, hi = bf16(x), lo = bf16(x - hi), stored
+ * [hi(K) | lo(K)] per row against a weight image [W | W]: padt_gemm_bf16_ex below IS padt_gemm_bf16 at K' = 2K (fp32
+ * accumulation of hi*W + lo*W), with two extra epilogue options:
+ *   resid_f32: epilogue 2 adds an fp32 residual R[M][ldr] (out_f32 must be 1) — the fp32 residual stream, in place allowed;
+ *   lo_off:    bf16 output stored as a pair, hi at C[m][n], lo at C[m][lo_off + n] (lo_off >= N, ldc >= lo_off + N). */
+int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
+                      const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32, const void* row_scale,
+                      int resid_f32, long lo_off);
+/* Row kernel: y0 = f(x), y1 = f(x) + pos[r % pos_rows], f(x) = act(RMSNorm_w(x[idx[r]] + add[r / add_div])), every stage
+ * optional (null pointer); x bf16 or fp32 (x_f32); each output off (mode 0), fp32 rows (1) or bf16 split rows (2) laid out
+ * [hi(chunk) lo(chunk)] x D/chunk.  padt_decoder.py:71-74 (RMSNorm), :30-31 (+ positional query), :220 (repeat4(low) + high),
+ * :168-172 (Linear → RMSNorm → GELU of mask_output_upscaling1), padt.py:365-373 (per-object row gather). */
+int padt_norm_split(void* stream, const void* x, long ldx, int x_f32, const int* idx, const void* add_f32, long ld_add, int add_div,
+                    const void* w, float eps, int act, const void* pos_f32, long ld_pos, long pos_rows, void* y0, long ld_y0,
+                    int y0_mode, void* y1, long ld_y1, int y1_mode, long rows, long D, long chunk);
+/* In-place rotate-half rotary on fp32 rows (padt_decoder.py:38-51, flash-attn apply_rotary_emb, non-interleaved). */
+int padt_rope_half_f32(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T, int n_heads,
+                       int head_dim);
+/* fp32 varlen non-causal attention (padt_decoder.py:52-58): q/k/v fp32 rows with the heads contiguous, exact expf softmax,
+ * output as split rows (chunk as above) for the out-projection.  head_dim 32 / 64 / 80 / 128. */
+int padt_attn_f32(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split, long ldo,
+                  long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k, int n_heads,
+                  int head_dim, float scale);
+/* padt_mask_scatter on fp32 e2 / mask tokens. */
+int padt_mask_scatter_f32(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
+                          const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm);
+
 /* ---- VRT head + greedy bookkeeping ------------------------------------------------------------------------------------
  * logits = hidden · [embed_table ‖ proto]^T through two base pointers, -inf outside text ∪ own patch rows, per-block
  * (max, argmax) partials; optional dense fp32 logits.  padt.py:292-301.  mode_table/step: scripted logits-processor

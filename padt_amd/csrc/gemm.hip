@@ -35,7 +35,20 @@ struct GemmArgs {
     RopeEpi rope = {nullptr, nullptr, 0, 0, 0};   // optional fused RoPE of the leading output columns (EPI_NONE only)
     int a_pack = 0;              // skinny kernel: A / (C and R) stored in the 16-row fragment-packed activation layout
     int c_pack = 0;              //   element (m, k) at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8   (see padt_hip.h)
+    int r_f32 = 0;               // EPI_RESID: R is fp32 [M][ldr] (fp32 residual stream; with OUT_F32)
+    long lo_off = 0;             // bf16 output: also store lo = bf16(x - hi) at C + lo_off (split-precision pair, padt_gemm_bf16_ex)
 };
+
+// bf16 split pair of 4 fp32 values: hi = bf16(x), lo = bf16(x - hi)  (hi + lo carries 16 mantissa bits)
+PADT_DEV void split4(const float* o, u32x2& hi, u32x2& lo) {
+    hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    float h[4];
+    h[0] = __builtin_bit_cast(float, hi[0] << 16);
+    h[1] = __builtin_bit_cast(float, hi[0] & 0xffff0000u);
+    h[2] = __builtin_bit_cast(float, hi[1] << 16);
+    h[3] = __builtin_bit_cast(float, hi[1] & 0xffff0000u);
+    lo = u32x2{pack2bf(o[0] - h[0], o[1] - h[1]), pack2bf(o[2] - h[2], o[3] - h[3])};
+}
 
 // offset of element (m, n) of a row-major or fragment-packed [rows][ld] activation matrix (n % 4 == 0 keeps 4 elements together)
 PADT_DEV long act_index(int m, int n, long ld, int packed) {
@@ -66,7 +79,11 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
         const u32x2 braw = *reinterpret_cast<const u32x2*>(bp);     // both loads are issued before either is consumed
         u32x2 rraw = u32x2{0u, 0u};
-        if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + act_index(m, n, p.ldr, p.c_pack));
+        f32x4 rf = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (EPI == EPI_RESID) {
+            if (p.r_f32) rf = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (long)m * p.ldr + n);
+            else rraw = *reinterpret_cast<const u32x2*>(p.R + act_index(m, n, p.ldr, p.c_pack));
+        }
         {
             float bv[4];
             unpack4(braw, bv);
@@ -82,9 +99,16 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
             float rv[4];
             unpack4(rraw, rv);
 #pragma unroll
-            for (int r = 0; r < 4; ++r) o[r] += rv[r];
+            for (int r = 0; r < 4; ++r) o[r] += p.r_f32 ? rf[r] : rv[r];
         }
         if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+        else if (p.lo_off) {
+            u32x2 hi, lo;
+            split4(o, hi, lo);
+            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+            *reinterpret_cast<u32x2*>(c) = hi;
+            *reinterpret_cast<u32x2*>(c + p.lo_off) = lo;
+        }
         else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + act_index(m, n, p.ldc, p.c_pack)) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
         return;
     }
@@ -92,9 +116,13 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         float x = o[r];
         if (p.bias) x += bf2f(p.bias[n + r]);
         if (EPI == EPI_GELU) x = gelu_erf(x);
-        if (EPI == EPI_RESID) x += bf2f(p.R[(long)m * p.ldr + n + r]);
+        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
         if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-        else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
+        else {
+            const bf16_t h = f2bf(x);
+            reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = h;
+            if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(h));
+        }
     }
 }
 
@@ -210,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 
     // epilogue: acc[mi][ni][r] = C[m0 + wm*64 + mi*16 + (lane&15)][n0 + wn*64 + ni*16 + (lane>>4)*4 + r]
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (interior && EPI != EPI_SWIGLU) {
+    if (interior && EPI != EPI_SWIGLU && !p.r_f32 && !p.lo_off) {
         // block-uniform fast path: no per-fragment bounds checks; every bias / residual load is issued up front
         const int mb = m0 + wm * 64 + frow, nb = n0 + wn * 64 + fq * 4;
         u32x2 braw[4], rraw[4][4];
@@ -447,7 +475,7 @@ extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, const RopeEpi* rope, long* rows_done);
+                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off);
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -507,7 +535,7 @@ static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
 
 static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                           long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                          const void* row_scale, const RopeEpi& rope) {
+                          const void* row_scale, const RopeEpi& rope, int resid_f32 = 0, long lo_off = 0) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         padt_set_error("padt_gemm_bf16: K, lda, ldw must be multiples of 8 and A, W 16-byte aligned");
@@ -523,7 +551,15 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
     long done = 0;
     const float* rs = (const float*)row_scale;
     RopeEpi rp = rope;
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done) == 0) {
+    if (resid_f32 && (epilogue != EPI_RESID || !out_f32 || ((uintptr_t)R & 15))) {
+        padt_set_error("padt_gemm_bf16_ex: an fp32 residual needs epilogue 2, fp32 output and a 16-byte aligned R");
+        return -1;
+    }
+    if (lo_off && (out_f32 || epilogue == EPI_SWIGLU || (lo_off & 3) || lo_off < N || ldc < lo_off + N)) {
+        padt_set_error("padt_gemm_bf16_ex: a split (hi|lo) output needs bf16 output, lo_off % 4 == 0, lo_off >= N and ldc >= lo_off + N");
+        return -1;
+    }
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -532,7 +568,7 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         // a peeled ragged tail (<= 64 rows): the rest of this function streams it through the skinny kernel
         A = (const bf16_t*)A + done * lda;
         C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
-        if (R) R = (const bf16_t*)R + done * ldr;
+        if (R) R = resid_f32 ? (const void*)((const float*)R + done * ldr) : (const void*)((const bf16_t*)R + done * ldr);
         if (rs) rs += done;
         if (rp.cos) { rp.cos += done * rp.ld; rp.sin += done * rp.ld; }
         M -= done;
@@ -541,6 +577,8 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
                (int)M, (int)N, (int)K};
     a.rs = rs;
     a.rope = rp;
+    a.r_f32 = resid_f32;
+    a.lo_off = lo_off;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: dispatch_m<EPI_NONE, false>(a, s); break;
@@ -562,6 +600,16 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
                               const void* row_scale) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
                           RopeEpi{nullptr, nullptr, 0, 0, 0});
+}
+
+// Extended epilogues for the split-precision PaDT decoder (decoder_hp.hip): resid_f32 — R (and C: out_f32 must be set) is the
+// fp32 residual stream; lo_off != 0 — bf16 output stored as a (hi, lo) pair, hi at C[m][n], lo = bf16(x - hi) at C[m][lo_off + n],
+// i.e. directly the [hi | lo] A operand (K' = 2N) of the next GEMM whose weight image is [W | W].
+extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
+                                 const void* row_scale, int resid_f32, long lo_off) {
+    return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
+                          RopeEpi{nullptr, nullptr, 0, 0, 0}, resid_f32, lo_off);
 }
 
 // C = rope(row_scale[m] * (A · W^T) + bias): the rotate-half RoPE of the leading `rope_cols` output columns fused into the

@@ -32,6 +32,8 @@ struct Gemm256Args {
     const float* rs;                // optional per-row scale of the accumulator (fused RMSNorm rstd), applied before bias
     RopeEpi rope;                   // optional fused RoPE of the leading output columns (EPI_NONE)
     int group_m;                    // tile rasterisation: ids walk down group_m tile rows, then to the next tile column
+    int r_f32;                      // EPI_RESID: R is fp32 [M][ldr] (with OUT_F32)
+    long lo_off;                    // bf16 output: also store lo = bf16(x - hi) at C + lo_off (padt_gemm_bf16_ex)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
@@ -247,9 +249,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         float x = acc[mi][ni][r] * rsc;
                         if (p.bias) x += bf2f(p.bias[n + r]);
                         if (EPI == EPI_GELU) x = gelu_erf(x);
-                        if (EPI == EPI_RESID) x += bf2f(p.R[(long)m * p.ldr + n + r]);
+                        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
                         if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-                        else reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = f2bf(x);
+                        else {
+                            const bf16_t hb = f2bf(x);
+                            reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = hb;
+                            if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(hb));
+                        }
                     }
                     continue;
                 }
@@ -257,7 +263,11 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 float bv[4], o[4];
                 unpack4b(*reinterpret_cast<const u32x2*>(bp), bv);
                 u32x2 rraw = u32x2{0u, 0u};
-                if (EPI == EPI_RESID) rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
+                f32x4 rf = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (EPI == EPI_RESID) {
+                    if (p.r_f32) rf = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + (long)m * p.ldr + n);
+                    else rraw = *reinterpret_cast<const u32x2*>(p.R + (long)m * p.ldr + n);
+                }
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc + bv[r];
                 if (EPI == EPI_NONE) rope_pairs(o, m, n, p.rope);
@@ -269,10 +279,19 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                     float rv[4];
                     unpack4b(rraw, rv);
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                    for (int r = 0; r < 4; ++r) o[r] += p.r_f32 ? rf[r] : rv[r];
                 }
                 if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
-                else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                else {
+                    const u32x2 hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+                    *reinterpret_cast<u32x2*>(cp) = hi;
+                    if (p.lo_off) {                               // split-precision pair: lo = bf16(x - hi)
+                        float hv[4];
+                        unpack4b(hi, hv);
+                        *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2bf(o[0] - hv[0], o[1] - hv[1]), pack2bf(o[2] - hv[2], o[3] - hv[3])};
+                    }
+                }
             }
         }
     }
@@ -364,7 +383,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     a2.W = a.W + n1 * a.ldw;
     if (a.bias) a2.bias = a.bias + n1;
     a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((bf16_t*)a.C + c1);
-    if (a.R) a2.R = a.R + c1;
+    if (a.R) a2.R = a.r_f32 ? (const bf16_t*)((const float*)a.R + c1) : a.R + c1;
     run256<EPI, F32>(a1, pm.mf, s);
     run256<EPI, F32>(a2, pr.mf, s);
     return a.M;
@@ -375,7 +394,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 // *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, const RopeEpi* rope, long* rows_done) {
+                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off) {
     static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -387,7 +406,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     static const int group_m = getenv("PADT_GEMM_GROUP_M") ? atoi(getenv("PADT_GEMM_GROUP_M")) : 8;   // tuning knob
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;

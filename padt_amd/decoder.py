@@ -114,6 +114,8 @@ class PaDTDecoder:
                         patch_off: List[int], patch_num: List[int], grids: List[List[int]]):
         """feats_cat (ΣVRT, D_llm); low_img/high_img/pe_img = per-image tensors (all samples concatenated);
         obj_sample[o] = sample index of object o; patch_off/patch_num per sample."""
+        if self.W.dec_hp:
+            return self.forward_objects_hp(feats_cat, n_vp, low_img, high_img, pe_img, obj_sample, patch_off, patch_num, grids)
         W, dev, mu = self.W, self.device, self.cfg.merge_unit
         n_obj = len(n_vp)
         dh = self.dh
@@ -158,4 +160,106 @@ class PaDTDecoder:
         Hm, Wm = pl["Hm"], pl["Wm"]
         masks = torch.zeros((n_obj, 4 * Hm, 4 * Wm), device=dev, dtype=torch.float32)
         ops.mask_scatter(e2, mask_tok, cu_p_t, pl["Ws32"], masks, n_obj, N, dm)
+        return bbox, score, masks, (Hs, Ws)
+
+    # ================================================================================================================
+    # Split-precision path (csrc/decoder_hp.hip; default): fp32 residual streams, (hi, lo) bf16 pairs into every GEMM, fp32
+    # attention.  Same graph as above, statement for statement; measured against the fp32 oracle in
+    # tests/test_real_shape_gpu.py at the 1e-3 box / mask tolerance of the north star.
+    def _attention_hp(self, pfx, q_in, k_in, v_in, cu_q, cu_k, max_q, max_k, q_rope, k_rope, residual, fused=None):
+        """q_in / k_in / v_in: split rows.  fused = "qk" (self-attention: q and k share their input) or "kv" (query→image: k
+        and v share theirs) use the stacked weight images; q_rope / k_rope: (cos, sin) fp32 tables for the image side or None."""
+        W, H, hd, dh = self.W, self.heads, self.hd, self.dh
+        if fused == "qk":
+            qk = ops.gemm_hp(q_in, W[pfx + "qk.hp"], W[pfx + "qk.b"])
+            q, k = qk[:, :dh], qk[:, dh:2 * dh]
+            v = ops.gemm_hp(v_in, W[pfx + "v_proj.hp"], W[pfx + "v_proj.b"])
+        elif fused == "kv":
+            q = ops.gemm_hp(q_in, W[pfx + "q_proj.hp"], W[pfx + "q_proj.b"])
+            kv = ops.gemm_hp(k_in, W[pfx + "kv.hp"], W[pfx + "kv.b"])
+            k, v = kv[:, :dh], kv[:, dh:2 * dh]
+        else:
+            q = ops.gemm_hp(q_in, W[pfx + "q_proj.hp"], W[pfx + "q_proj.b"])
+            k = ops.gemm_hp(k_in, W[pfx + "k_proj.hp"], W[pfx + "k_proj.b"])
+            v = ops.gemm_hp(v_in, W[pfx + "v_proj.hp"], W[pfx + "v_proj.b"])
+        if q_rope is not None:
+            ops.rope_half_f32_(q, q_rope[0], q_rope[1], H, hd)
+        if k_rope is not None:
+            ops.rope_half_f32_(k, k_rope[0], k_rope[1], H, hd)
+        a = ops.attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, H, hd)
+        return ops.gemm_hp(a, W[pfx + "proj.hp"], W[pfx + "proj.b"], out=residual, epilogue=ops.EPI_RESID, residual=residual)
+
+    def _block_hp(self, pfx, query, memory, cu_q, cu_m, max_q, max_m, query_pos, memory_pos):
+        """PaDTDecoderBlock.forward (padt_decoder.py:95-128) on fp32 streams `query` / `memory` (updated in place)."""
+        W, S, N_ = self.W, ops.OUT_SPLIT, ops.OUT_NONE
+        qn, qnp = ops.norm_split(query, W[pfx + "norm1"], pos=query_pos, y0_mode=S, y1_mode=S)
+        self._attention_hp(pfx + "self_attn.", qnp, qnp, qn, cu_q, cu_q, max_q, max_q, None, None, query, fused="qk")
+        _, qnp = ops.norm_split(query, W[pfx + "norm2"], pos=query_pos, y0_mode=N_, y1_mode=S)
+        mn, _ = ops.norm_split(memory, W[pfx + "norm3"])
+        self._attention_hp(pfx + "cross_attn_query_to_image.", qnp, mn, mn, cu_q, cu_m, max_q, max_m, None, memory_pos, query, fused="kv")
+        n4, _ = ops.norm_split(query, W[pfx + "norm4"])
+        h = ops.gemm_hp(n4, W[pfx + "mlp.0.hp"], W[pfx + "mlp.0.b"], epilogue=ops.EPI_GELU, out_mode=S)
+        ops.gemm_hp(h, W[pfx + "mlp.2.hp"], W[pfx + "mlp.2.b"], out=query, epilogue=ops.EPI_RESID, residual=query)
+        qn, qnp = ops.norm_split(query, W[pfx + "norm5"], pos=query_pos, y0_mode=S, y1_mode=S)
+        mn, _ = ops.norm_split(memory, W[pfx + "norm6"])
+        self._attention_hp(pfx + "cross_attn_image_to_query.", mn, qnp, qn, cu_m, cu_q, max_m, max_q, memory_pos, None, memory)
+        return query, memory
+
+    def _in_proj_hp(self, x, idx=None):
+        W = self.W
+        n, _ = ops.norm_split(x, W["dec.input_projection.0.weight"], idx=idx)
+        h = ops.gemm_hp(n, W["dec.input_projection.1.weight.hp"], W["dec.input_projection.1.bias"], epilogue=ops.EPI_GELU,
+                        out_mode=ops.OUT_SPLIT)
+        return ops.gemm_hp(h, W["dec.input_projection.3.weight.hp"], W["dec.input_projection.3.bias"])
+
+    def _mlp3_hp(self, name, x_split):
+        W = self.W
+        h = ops.gemm_hp(x_split, W[f"dec.{name}.0.weight.hp"], W[f"dec.{name}.0.bias"], epilogue=ops.EPI_GELU, out_mode=ops.OUT_SPLIT)
+        h = ops.gemm_hp(h, W[f"dec.{name}.2.weight.hp"], W[f"dec.{name}.2.bias"], epilogue=ops.EPI_GELU, out_mode=ops.OUT_SPLIT)
+        n_out = W[f"dec.{name}.4.weight"].shape[0]
+        return ops.gemm_hp(h, W[f"dec.{name}.4.weight.hp"], W[f"dec.{name}.4.bias"])[:, :n_out]
+
+    def forward_objects_hp(self, feats_cat, n_vp, low_img, high_img, pe_img, obj_sample, patch_off, patch_num, grids):
+        W, dev, mu = self.W, self.device, self.cfg.merge_unit
+        n_obj, dh = len(n_vp), self.dh
+        pl = self._plan(n_vp, obj_sample, patch_off, patch_num, grids)
+        cu_q_t, max_q = pl["cu_q_t"], pl["max_q"]
+        low_idx, high_idx, cu_p_t, cu_l_t, max_p = pl["low_idx"], pl["high_idx"], pl["cu_p_t"], pl["cu_l_t"], pl["max_p"]
+        F, S, N_ = ops.OUT_F32, ops.OUT_SPLIT, ops.OUT_NONE
+        # ---- queries (padt_decoder.py:196-207)
+        _, feats = ops.norm_split(self._in_proj_hp(feats_cat), pos=W["dec.vp.f32"], y0_mode=N_, y1_mode=F)
+        table = torch.cat([W["dec.tokens.f32"], feats], dim=0)
+        cu_query = ops.gather_rows(table, pl["q_rows"])
+        low = ops.gather_rows(self._in_proj_hp(low_img), low_idx)            # projection once per image, then replicate
+        cos = ops.gather_rows(pe_img[0], high_idx)
+        sin = ops.gather_rows(pe_img[1], high_idx)
+        low_pe = (cos.view(-1, mu * cos.shape[1])[:, : cos.shape[1]], sin.view(-1, mu * sin.shape[1])[:, : sin.shape[1]])
+
+        query_pos = cu_query
+        out = cu_query.clone()
+        out, low = self._block_hp("dec.low_res_transformer.", out, low, cu_q_t, cu_l_t, max_q, max_p // mu, query_pos, low_pe)
+        # high = RMSNorm(repeat4(low) + high)  (padt_decoder.py:220); the per-object gather of the bf16 ViT rows rides along
+        high, _ = ops.norm_split(high_img, W["dec.high_res_norm.weight"], idx=high_idx, add=low, add_div=mu, y0_mode=F)
+        out, high = self._block_hp("dec.high_res_transformer1.", out, high, cu_q_t, cu_p_t, max_q, max_p, query_pos, (cos, sin))
+        out, high = self._block_hp("dec.high_res_transformer2.", out, high, cu_q_t, cu_p_t, max_q, max_p, query_pos, (cos, sin))
+
+        tok, _ = ops.norm_split(out, idx=pl["tok_idx"])                      # [box ; score ; mask tokens] as split rows
+        bbox = self._mlp3_hp("bbox_prediction", tok[:n_obj]).contiguous()
+        ops.sigmoid_f32_(bbox)
+        score = ops.gemm_hp(tok[n_obj:2 * n_obj], W["dec.score_prediction.weight.hp"], W["dec.score_prediction.bias"])[:, :1]
+        Hs, Ws = pl["Hs"].clone(), pl["Ws"].clone()
+        if not self.use_mask_loss:
+            return bbox, score, None, ()
+        mask_tok = self._mlp3_hp("mask_output_mlp", tok[2 * n_obj:])         # (n_obj, dh/16) fp32, row-strided view
+        dm = dh // 16
+        N = high.shape[0]
+        hs, _ = ops.norm_split(high)
+        up1 = ops.gemm_hp(hs, W["dec.mask_output_upscaling1.0.weight.hp"], W["dec.mask_output_upscaling1.0.bias"])
+        # Linear → RMSNorm → GELU (padt_decoder.py:168-172), split in groups of dh/4 so the (N, dh) → (4N, dh/4) re-view keeps pairs
+        up1n, _ = ops.norm_split(up1, W["dec.mask_output_upscaling1.1.weight"], act=1, chunk=dh // 4)
+        e2 = ops.gemm_hp(up1n.view(4 * N, dh // 2), W["dec.mask_output_upscaling2.0.weight.hp"], W["dec.mask_output_upscaling2.0.bias"],
+                         epilogue=ops.EPI_GELU)
+        Hm, Wm = pl["Hm"], pl["Wm"]
+        masks = torch.zeros((n_obj, 4 * Hm, 4 * Wm), device=dev, dtype=torch.float32)
+        ops.mask_scatter_f32(e2, mask_tok, cu_p_t, pl["Ws32"], masks, n_obj, N, dm)
         return bbox, score, masks, (Hs, Ws)

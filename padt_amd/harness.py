@@ -19,7 +19,9 @@ from .postprocess import postprocess_results
 
 def infer_dataset(model, processor, dataset: Sequence, prepare: Callable, output_dir: str, batch_size: int = 1,
                   datasetname: str = "coco", suffix: str = "", rank: int = 0, world: int = 1, max_new_tokens: int = 1024,
-                  depth: int = 2, merge: int = 4, schedule=None):
+                  depth: int = 2, merge: int = 4, schedule=None, repetition_penalty=None, eos_token_id=None):
+    """repetition_penalty / eos_token_id: None = the checkpoint's generation_config.json (model.generation_config), as HF's
+    generate() inside the reference's loop applies it (utils.py:230-236 → padt.py:436)."""
     os.makedirs(output_dir, exist_ok=True)
     f_res = os.path.join(output_dir, f"{datasetname}_{rank}_pred_results_{suffix}.json")
     f_comp = os.path.join(output_dir, f"{datasetname}_{rank}_pred_comp_{suffix}.json")
@@ -49,7 +51,8 @@ def infer_dataset(model, processor, dataset: Sequence, prepare: Callable, output
         b = prepare(dataset[idx: idx + batch_size])
         meta.append({"ids": list(b["ids"]), "image_sizes": list(b["image_sizes"])})
         drain(runner.submit(b["input_ids"], b["attention_mask"], b["pixel_values"], b["image_grid_thw"],
-                            max_new_tokens=max_new_tokens, schedule=schedule))
+                            max_new_tokens=max_new_tokens, schedule=schedule, repetition_penalty=repetition_penalty,
+                            eos_token_id=eos_token_id))
         n += len(b["ids"])
     drain(runner.flush())
     return {"samples": n, "results_file": f_res, "completions_file": f_comp}

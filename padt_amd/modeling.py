@@ -100,6 +100,11 @@ class PaDTForConditionalGeneration:
         self.model = SimpleNamespace(embed_tokens=SimpleNamespace(weight=self.W["llm.embed"]))
         self.use_visual_prototype_projection = config.use_visual_prototype_projection
         self.rope_deltas = None
+        # defaults HF's generate() takes from the checkpoint's generation_config.json (padt.py:436 _prepare_generation_config,
+        # :570-580 logits processors / stopping criteria); from_pretrained fills it, explicit generate() kwargs override it
+        self.generation_config = SimpleNamespace(repetition_penalty=1.0, eos_token_id=[config.eos_token_id],
+                                                 pad_token_id=config.pad_token_id, do_sample=False, temperature=1.0,
+                                                 top_k=0, top_p=1.0)
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -120,7 +125,27 @@ class PaDTForConditionalGeneration:
             device = f"cuda:{d}" if isinstance(d, int) else str(d)
         elif isinstance(device_map, (str, torch.device)):
             device = str(device_map)
-        return cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype)
+        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype)
+        gpath = os.path.join(path, "generation_config.json")
+        if os.path.exists(gpath):
+            model.load_generation_config(json.load(open(gpath)))
+        return model
+
+    def load_generation_config(self, d: dict):
+        """generation_config.json → defaults of generate(), as HF's GenerationMixin applies them (padt.py:436): repetition_penalty,
+        eos_token_id (int or list), pad_token_id, do_sample / temperature / top_k / top_p."""
+        g = self.generation_config
+        if d.get("repetition_penalty") is not None:
+            g.repetition_penalty = float(d["repetition_penalty"])
+        if d.get("eos_token_id") is not None:
+            e = d["eos_token_id"]
+            g.eos_token_id = [int(e)] if isinstance(e, int) else [int(x) for x in e]
+        if d.get("pad_token_id") is not None:
+            g.pad_token_id = int(d["pad_token_id"])
+        for k, cast in (("do_sample", bool), ("temperature", float), ("top_k", int), ("top_p", float)):
+            if d.get(k) is not None:
+                setattr(g, k, cast(d[k]))
+        return g
 
     @classmethod
     def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
@@ -135,17 +160,18 @@ class PaDTForConditionalGeneration:
     # ------------------------------------------------------------------ generate (padt.py:414-616 → 618-800)
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
-                 max_new_tokens=1024, do_sample=False, output_hidden_states=True, return_dict_in_generate=True,
+                 max_new_tokens=1024, do_sample=None, output_hidden_states=True, return_dict_in_generate=True,
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
-                 use_graph: bool = True, lane: int = 0, repetition_penalty: float = 1.0, eos_token_id=None, **unused):
+                 use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None, **unused):
         """Greedy generation over the unified text‖VRT vocabulary.
 
         ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
         VRT rows only, 'e' force EOS, None free — applied where HF's ``logits_processor`` sits (padt.py:717).
         ``lane`` selects an independent decode session (KV caches, token ring, graph) so several batches can be in
         flight on different HIP streams (pipeline.PipelinedRunner).
-        ``repetition_penalty`` / ``eos_token_id`` (int or list, must contain config.eos_token_id): the two
-        generation_config.json entries HF's generate turns into a logits processor / stopping criterion (padt.py:570-580).
+        ``repetition_penalty`` / ``eos_token_id`` (int or list) / ``do_sample``: default to the checkpoint's
+        generation_config.json (self.generation_config), exactly the entries HF's generate turns into a logits processor /
+        stopping criterion / sampling switch (padt.py:436,570-580,740-743); explicit arguments override.
         """
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
                                    schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
@@ -153,9 +179,9 @@ class PaDTForConditionalGeneration:
         return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate)
 
     @torch.no_grad()
-    def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=False,
+    def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=None,
                         schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
-                        repetition_penalty=1.0, eos_token_id=None):
+                        repetition_penalty=None, eos_token_id=None):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -167,13 +193,16 @@ class PaDTForConditionalGeneration:
         decode kernel); the weights are streamed once per step for all rows.  Returns None instead of adding when the
         batch does not fit the group's session (caller closes the group and starts a new one).
         """
+        gc = self.generation_config
+        do_sample = gc.do_sample if do_sample is None else do_sample
+        repetition_penalty = gc.repetition_penalty if repetition_penalty is None else repetition_penalty
         if do_sample:
             raise NotImplementedError("sampling (padt.py:740-743) is not on the accelerated path; use do_sample=False")
         if pixel_values is None or image_grid_thw is None:
             raise ValueError("pixel_values and image_grid_thw are required (text-only input crashes in the reference too, "
                              "padt.py:292 with image_prototypes unbound)")
         cfg, dev = self.config, self.device
-        eos_list = [cfg.eos_token_id] if eos_token_id is None else ([int(eos_token_id)] if isinstance(eos_token_id, int) else [int(e) for e in eos_token_id])
+        eos_list = list(gc.eos_token_id) if eos_token_id is None else ([int(eos_token_id)] if isinstance(eos_token_id, int) else [int(e) for e in eos_token_id])
         if cfg.eos_token_id not in eos_list or len(eos_list) > 4:
             raise NotImplementedError("eos_token_id must contain config.eos_token_id and hold at most 4 ids")
         gen_key = (float(repetition_penalty), tuple(eos_list))
@@ -190,7 +219,7 @@ class PaDTForConditionalGeneration:
             sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
                          use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule,
-                         gen_key=gen_key)
+                         gen_key=gen_key, eos_list=eos_list)
             sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu").to(dev, non_blocking=True))
             if gen_key[0] != 1.0:
                 sess.seen.zero_()
@@ -293,13 +322,14 @@ class PaDTForConditionalGeneration:
             if sub["proto_row0"]:                                  # back to this batch's own global VRT ids
                 toks = torch.where(toks >= cfg.vocab_size, toks - sub["proto_row0"], toks)
             # reference stops right after the step in which the last sequence finished (padt.py:756-757)
-            eos_hit = (toks == cfg.eos_token_id)
+            eos_hit = torch.isin(toks, torch.tensor(group["eos_list"], device=toks.device, dtype=toks.dtype))   # any id of the EOS list finishes a row
             if bool(eos_hit.any(dim=1).all()):
                 stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
                 toks = toks[:, :stop]
             n_steps = toks.shape[1]
             sequences = torch.cat([sub["input_ids"].to(dev), toks], dim=1)
-            hidden = StepHiddenStates(sess.hidden_buf[:n_steps, row0: row0 + B].contiguous(), n_steps, sub["hn_all"],
+            # clone: the session's hidden_buf is reused by the lane's next generate(); the caller owns what it gets back
+            hidden = StepHiddenStates(sess.hidden_buf[:n_steps, row0: row0 + B].clone(), n_steps, sub["hn_all"],
                                       plan.lens, plan.L_pad)
             table_rows = cfg.vocab_size + sub["n_proto"]
 
@@ -324,9 +354,10 @@ class PaDTForConditionalGeneration:
         cfg, dev = self.config, self.device
         flat = sum(object_vp_feats, [])
         if len(flat) == 0:                                        # padt.py:406-412 (the dummy pass of 383-393 is skipped)
-            return {"pred_boxes": torch.zeros((0, 4), device=dev, dtype=self.dtype),
-                    "pred_score": torch.zeros((0, 1), device=dev, dtype=self.dtype),
-                    "pred_mask": torch.zeros((0, 8, 8), device=dev, dtype=self.dtype),
+            f32 = torch.float32                                   # same dtypes as the non-empty result (boxes / scores / logits are fp32)
+            return {"pred_boxes": torch.zeros((0, 4), device=dev, dtype=f32),
+                    "pred_score": torch.zeros((0, 1), device=dev, dtype=f32),
+                    "pred_mask": torch.zeros((0, 8, 8), device=dev, dtype=f32),
                     "pred_mask_valid_hw": (), "sample_idx": []}
         grids = [[int(x) for x in g] for g in torch.as_tensor(image_grid_thws).tolist()]
         patch_num = [g[0] * g[1] * g[2] for g in grids]

@@ -363,6 +363,96 @@ def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):
     return out
 
 
+# ------------------------------------------------------------------------------------------------ split-precision decoder ops
+F32 = torch.float32
+OUT_NONE, OUT_F32, OUT_SPLIT = 0, 1, 2
+
+
+def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_mode=OUT_F32, M=None):
+    """Split-precision GEMM (include/padt_hip.h "hp decoder"): a_split (M, 2K) bf16 rows [hi | lo], w2 (N, 2K) = [W | W].
+    out_mode OUT_F32 → fp32 (M, N) [+ fp32 residual, in place allowed]; OUT_SPLIT → bf16 (M, 2N) rows [hi | lo]."""
+    lib = _lib.load()
+    _chk_bf16(a_split, w2, bias)
+    M = a_split.shape[0] if M is None else M
+    N, K2 = w2.shape
+    assert a_split.shape[1] == K2, (a_split.shape, w2.shape)
+    if out_mode == OUT_F32:
+        if out is None:
+            out = torch.empty((M, (N + 3) // 4 * 4), device=a_split.device, dtype=F32)
+        assert out.dtype == F32 and out.stride(-1) == 1
+        if residual is not None:
+            assert residual.dtype == F32 and epilogue == EPI_RESID
+        lo_off = 0
+    else:
+        assert residual is None and N % 4 == 0
+        if out is None:
+            out = torch.empty((M, 2 * N), device=a_split.device, dtype=BF16)
+        assert out.dtype == BF16 and out.shape[1] >= 2 * N
+        lo_off = N
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("hp", a_split, w2, bias, out, epilogue, residual, out_mode, M))
+    _lib.check(lib.padt_gemm_bf16_ex(_stream(), _p(a_split), a_split.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out), out.stride(0),
+                                     _p(residual), residual.stride(0) if residual is not None else 0, M, N, K2, epilogue,
+                                     1 if out_mode == OUT_F32 else 0, 0, 1 if residual is not None else 0, lo_off), "padt_gemm_bf16_ex")
+    return out
+
+
+def norm_split(x, w=None, eps=1e-6, act=0, idx=None, add=None, add_div=1, pos=None, y0_mode=OUT_SPLIT, y1_mode=OUT_NONE, chunk=None,
+               rows=None, D=None):
+    """→ (y0, y1) of padt_norm_split; x bf16 or fp32 (rows, >= D); modes OUT_NONE / OUT_F32 / OUT_SPLIT (split rows are 2*D wide)."""
+    lib = _lib.load()
+    assert x.dtype in (BF16, F32) and x.stride(-1) == 1
+    D = x.shape[1] if D is None else D
+    rows = (idx.numel() if idx is not None else x.shape[0]) if rows is None else rows
+    chunk = D if chunk is None else chunk
+
+    def mk(mode):
+        if mode == OUT_NONE:
+            return None
+        return torch.empty((rows, D if mode == OUT_F32 else 2 * D), device=x.device, dtype=F32 if mode == OUT_F32 else BF16)
+    y0, y1 = mk(y0_mode), mk(y1_mode)
+    if add is not None:
+        assert add.dtype == F32 and add.stride(-1) == 1
+    if pos is not None:
+        assert pos.dtype == F32 and pos.stride(-1) == 1
+    if idx is not None:
+        assert idx.dtype == torch.int32
+    _lib.check(lib.padt_norm_split(_stream(), _p(x), x.stride(0), 1 if x.dtype == F32 else 0, _p(idx), _p(add),
+                                   add.stride(0) if add is not None else 0, add_div, _p(w), float(eps), int(act), _p(pos),
+                                   pos.stride(0) if pos is not None else 0, pos.shape[0] if pos is not None else 1,
+                                   _p(y0), y0.stride(0) if y0 is not None else 0, y0_mode, _p(y1), y1.stride(0) if y1 is not None else 0,
+                                   y1_mode, rows, D, chunk), "padt_norm_split")
+    return y0, y1
+
+
+def rope_half_f32_(x, cos, sin, n_heads, head_dim):
+    """in place on the first n_heads*head_dim columns of the fp32 rows x (T, row)."""
+    assert x.dtype == F32 and cos.dtype == F32 and sin.dtype == F32 and cos.stride(-1) == 1 and sin.stride() == cos.stride()
+    _lib.check(_lib.load().padt_rope_half_f32(_stream(), _p(x), x.stride(0), _p(cos), _p(sin), cos.stride(0), x.shape[0], n_heads,
+                                              head_dim), "padt_rope_half_f32")
+    return x
+
+
+def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, out=None):
+    """fp32 varlen attention → split rows (Tq, 2*n_heads*head_dim) bf16."""
+    assert q.dtype == F32 and k.dtype == F32 and v.dtype == F32 and cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
+    Dm = n_heads * head_dim
+    if out is None:
+        out = torch.empty((q.shape[0], 2 * Dm), device=q.device, dtype=BF16)
+    scale = head_dim ** -0.5 if scale is None else scale
+    _lib.check(_lib.load().padt_attn_f32(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), Dm,
+                                         _p(cu_q), _p(cu_k), cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, float(scale)),
+               "padt_attn_f32")
+    return out
+
+
+def mask_scatter_f32(e2, mask_tok, cu_patch, obj_w, masks, n_obj, total_patches, dm):
+    assert e2.dtype == F32 and mask_tok.dtype == F32 and masks.dtype == F32 and masks.is_contiguous()
+    _lib.check(_lib.load().padt_mask_scatter_f32(_stream(), _p(e2), e2.stride(0), _p(mask_tok), mask_tok.stride(0), _p(cu_patch), _p(obj_w),
+                                                 _p(masks), n_obj, total_patches, masks.shape[1], masks.shape[2], dm), "padt_mask_scatter_f32")
+    return masks
+
+
 def memset(t, value=0):
     lib = _lib.load()
     _lib.check(lib.padt_memset(_stream(), _p(t), value, t.numel() * t.element_size()), "padt_memset")

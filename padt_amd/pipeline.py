@@ -78,7 +78,7 @@ class PipelinedRunner:
         self.pending.append(g)
 
     def submit(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, schedule=None,
-               need_thinking_mask=None, sync_every=None, repetition_penalty=1.0, eos_token_id=None):
+               need_thinking_mask=None, sync_every=None, repetition_penalty=None, eos_token_id=None):
         done = []
         bid = self.n_batches
         self.n_batches += 1
@@ -94,6 +94,13 @@ class PipelinedRunner:
             g = self.cur
             pre = g["pre"]
             pre.wait_stream(torch.cuda.current_stream())          # inputs were produced on the caller's stream
+            # ... and are consumed on the prefill / decode streams, possibly long after the caller dropped them: tell the
+            # caching allocator (record_stream) so their blocks are not handed to the caller's next batch while a lagging
+            # side stream still reads them; the group also holds references until its results were collected
+            for t in (ids, attention_mask, pixel_values, image_grid_thw):
+                if isinstance(t, torch.Tensor) and t.is_cuda:
+                    t.record_stream(pre)
+                    t.record_stream(self.decode_streams[g["lane"]])
             self._mark(bid, "prefill_begin", pre)
             with torch.cuda.stream(pre):
                 ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
@@ -108,6 +115,7 @@ class PipelinedRunner:
         self._mark(bid, "prefill_end", pre)
         g["ctx"] = ctx
         g["meta"].append((input_ids.shape, image_grid_thw, need_thinking_mask))
+        g.setdefault("keep", []).append((ids, attention_mask, pixel_values))
         g["bids"].append(bid)
         if len(g["meta"]) == self.merge:
             self._close_cur()

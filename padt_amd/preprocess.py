@@ -54,7 +54,13 @@ class ImageFrontEnd:
 
     def resize_host(self, image):
         """PIL image or (H, W, 3) uint8 array → uint8 array at the smart_resize size (PIL bicubic, as the processor does)."""
+        if hasattr(image, "convert"):                              # PIL: the processor's do_convert_rgb (modes L / P / RGBA / CMYK ...)
+            image = image.convert("RGB")
         arr = np.asarray(image)
+        if arr.ndim == 2:                                          # gray ndarray → 3 equal channels
+            arr = np.repeat(arr[:, :, None], 3, axis=2)
+        if arr.ndim != 3 or arr.shape[2] < 3 or arr.dtype != np.uint8:
+            raise ValueError(f"image must be PIL or a (H, W[, >=3]) uint8 array, got shape {arr.shape} dtype {arr.dtype}")
         h, w = arr.shape[:2]
         rh, rw = smart_resize(h, w, self.patch * self.merge, self.min_pixels, self.max_pixels)
         if (rh, rw) == (h, w):

@@ -140,4 +140,4 @@ class VisionEncoder:
         m = ops.gemm(n.view(plan.N, vh * cfg.merge_unit), W["vit.merger.0.w"], W["vit.merger.0.b"], epilogue=ops.EPI_GELU)
         low_win = ops.gemm(m, W["vit.merger.2.w"], W["vit.merger.2.b"])
         low = ops.gather_rows(low_win, plan.reverse)                           # raster order (padt.py:103-104)
-        return low, high, (plan.cos, plan.sin)
+        return low, high, (plan.cos.clone(), plan.sin.clone())     # the caller owns past_visual_pe (plan tables are cached)

@@ -202,6 +202,7 @@ class PreparedWeights(dict):
     vit_ipad: int
     llm_ipad: int
     dec_ipad: int
+    dec_hp: bool = False
 
 
 def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda") -> PreparedWeights:
@@ -311,4 +312,38 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         put(d + "mlp.0.b", _pad_rows(get(s + "mlp.0.bias"), di_pad))
         put(d + "mlp.2.w", _pad_cols(get(s + "mlp.2.weight"), di_pad))
         put(d + "mlp.2.b", get(s + "mlp.2.bias"))
+    # Split-precision decoder (csrc/decoder_hp.hip, default): every decoder Linear also as the image [W | W] along K, so that the
+    # bf16 MFMA GEMM over an activation stored as [hi | lo] pairs accumulates hi·W + lo·W (16-bit-mantissa activations) with
+    # unchanged kernels at K' = 2K; projections that share their input are stacked along N (self-attn q|k, query→image k|v).
+    # +0.4 GB for the 98 M-parameter decoder.  PADT_DECODER_HP=0 keeps the plain bf16 decoder only.
+    W.dec_hp = os.environ.get("PADT_DECODER_HP", "1") != "0"
+    if W.dec_hp:
+        def dbl(*names):
+            t = torch.cat([W[n] for n in names], dim=0) if len(names) > 1 else W[names[0]]
+            return torch.cat([t, t], dim=1).contiguous()
+        W["dec.tokens.f32"] = W["dec.bbox_score_mask_tokens.weight"].float()
+        W["dec.vp.f32"] = W["dec.vp_embedding.weight"].float()
+        for name in ("input_projection.1.weight", "input_projection.3.weight", "score_prediction.weight",
+                     "mask_output_upscaling1.0.weight", "mask_output_upscaling2.0.weight"):
+            W["dec." + name + ".hp"] = dbl("dec." + name)
+        for head in ("bbox_prediction", "mask_output_mlp"):
+            for k in (0, 2, 4):
+                W[f"dec.{head}.{k}.weight.hp"] = dbl(f"dec.{head}.{k}.weight")
+        for blk in ("low_res_transformer", "high_res_transformer1", "high_res_transformer2"):
+            d = "dec." + blk + "."
+            a = d + "self_attn."
+            W[a + "qk.hp"] = dbl(a + "q_proj.w", a + "k_proj.w")
+            W[a + "qk.b"] = torch.cat([W[a + "q_proj.b"], W[a + "k_proj.b"]]).contiguous()
+            W[a + "v_proj.hp"] = dbl(a + "v_proj.w")
+            W[a + "proj.hp"] = dbl(a + "proj.w")
+            a = d + "cross_attn_query_to_image."
+            W[a + "q_proj.hp"] = dbl(a + "q_proj.w")
+            W[a + "kv.hp"] = dbl(a + "k_proj.w", a + "v_proj.w")
+            W[a + "kv.b"] = torch.cat([W[a + "k_proj.b"], W[a + "v_proj.b"]]).contiguous()
+            W[a + "proj.hp"] = dbl(a + "proj.w")
+            a = d + "cross_attn_image_to_query."
+            for pr in ("q_proj", "k_proj", "v_proj", "proj"):
+                W[a + pr + ".hp"] = dbl(a + pr + ".w")
+            W[d + "mlp.0.hp"] = dbl(d + "mlp.0.w")
+            W[d + "mlp.2.hp"] = dbl(d + "mlp.2.w")
     return W

@@ -1,0 +1,185 @@
+"""Split-precision ("hp") decoder kernels (csrc/decoder_hp.hip + the padt_gemm_bf16_ex epilogues) against plain PyTorch fp32 / fp64
+statements of the same ops.  Tolerances: the (hi, lo) bf16 pair carries 16 mantissa bits → 2^-16 relative per element on the way
+into a GEMM; everything else is fp32 arithmetic.  Written at each assert."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+BF, F32 = torch.bfloat16, torch.float32
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from padt_amd import ops as _ops
+    return _ops
+
+
+def rndf(*shape, scale=1.0, seed=0):
+    g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
+    return (torch.randn(*shape, generator=g) * scale).cuda()
+
+
+def join(split, D, chunk=None):
+    """(rows, 2D) split rows [hi(chunk) lo(chunk)]... → fp32 (rows, D) = hi + lo."""
+    chunk = D if chunk is None else chunk
+    r = split.float().view(split.shape[0], D // chunk, 2, chunk)
+    return (r[:, :, 0] + r[:, :, 1]).reshape(split.shape[0], D)
+
+
+def split_ref(x):
+    hi = x.to(BF)
+    lo = (x - hi.float()).to(BF)
+    return torch.cat([hi, lo], dim=1)
+
+
+def rel_err(out, ref):
+    return ((out.double() - ref.double()).abs().max() / (ref.double().pow(2).mean().sqrt() + 1e-30)).item()
+
+
+def split_close(got, ref, what=""):
+    """a value read back from a (hi, lo) pair: |err| <= 2^-17 |x| (hi: half an ulp of 8 bits, lo: half an ulp of the remainder) —
+    asserted at 2^-16 |x| + fp32 noise."""
+    err = (got.double() - ref.double()).abs()
+    lim = ref.double().abs() * 2.0 ** -16 + 2e-6 * ref.double().pow(2).mean().sqrt()
+    assert bool((err <= lim).all()), f"{what}: max err {err.max().item():.3e}, worst ratio {(err / lim).max().item():.2f}"
+
+
+@pytest.mark.parametrize("x_f32", [True, False])
+def test_norm_split_all_stages(ops, x_f32):
+    rows, D, src_rows = 37, 1280, 50
+    x = rndf(src_rows, D, seed=1)
+    if not x_f32:
+        x = x.to(BF)
+    idx = torch.randint(0, src_rows, (rows,), generator=torch.Generator().manual_seed(3)).to(torch.int32).cuda()
+    add = rndf((rows + 3) // 4, D, seed=2)
+    w = (1 + 0.1 * rndf(D, seed=4)).to(BF)
+    pos = rndf(5, D, seed=5)
+    y0, y1 = ops.norm_split(x, w, eps=1e-6, act=1, idx=idx, add=add, add_div=4, pos=pos, y0_mode=ops.OUT_F32, y1_mode=ops.OUT_SPLIT, chunk=320)
+    xs = x.float()[idx.long()] + add[torch.arange(rows, device="cuda") // 4]
+    ref = xs * torch.rsqrt(xs.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()
+    ref = torch.nn.functional.gelu(ref)
+    assert rel_err(y0, ref) < 2e-6                                # fp32 arithmetic
+    ref1 = ref + pos[torch.arange(rows, device="cuda") % 5]
+    split_close(join(y1, D, 320), ref1, "norm_split y1")
+    # pass-through (no norm): exact split of the input
+    s0, _ = ops.norm_split(x if x_f32 else x.float())
+    assert torch.equal(s0, split_ref(x.float()))
+
+
+@pytest.mark.parametrize("M,N,K,epi", [(64, 1280, 1280, 0), (20, 1280, 2048, 1), (700, 640, 1280, 1), (2116, 2560, 1280, 0), (9, 4, 1280, 0),
+                                        (300, 320, 320, 1), (1000, 1280, 3456, 2), (40, 1280, 1280, 2)])
+def test_gemm_hp_against_fp64(ops, M, N, K, epi):
+    """A = fp32 activations as (hi, lo) pairs, W bf16 doubled along K: result within 16-mantissa-bit input rounding of the exact
+    product — three orders of magnitude tighter than the plain bf16 GEMM's 2^-9."""
+    a = rndf(M, K, seed=10)
+    w = rndf(N, K, scale=0.05, seed=11).to(BF)
+    b = rndf(N, scale=0.1, seed=12).to(BF)
+    w2 = torch.cat([w, w], dim=1).contiguous()
+    a_s, _ = ops.norm_split(a)
+    ref = a.double() @ w.double().T + b.double()
+    if epi == 1:
+        ref = torch.nn.functional.gelu(ref)
+    if epi == 2:
+        r = rndf(M, N, seed=13)
+        out = r.clone()
+        ops.gemm_hp(a_s, w2, b, out=out, epilogue=ops.EPI_RESID, residual=out)      # in place, fp32 residual stream
+        assert rel_err(out, ref + r.double()) < 5e-5
+        return
+    out = ops.gemm_hp(a_s, w2, b, epilogue=epi)
+    assert out.dtype == F32 and rel_err(out[:, :N], ref) < 5e-5
+    if N % 4 == 0:
+        sp = ops.gemm_hp(a_s, w2, b, epilogue=epi, out_mode=ops.OUT_SPLIT)
+        assert sp.shape == (M, 2 * N) and rel_err(join(sp, N), ref) < 8e-5
+        assert torch.equal(sp[:, :N], out[:, :N].to(BF))           # hi half = the bf16 rounding of the fp32 result
+
+
+def ref_attn64(q, k, v, cq, ck, H, D):
+    out = torch.zeros(q.shape[0], H * D, dtype=torch.float64, device=q.device)
+    q, k, v = q.double(), k.double(), v.double()
+    for i in range(len(cq) - 1):
+        qs = q[cq[i]:cq[i + 1]].view(-1, H, D)
+        ks = k[ck[i]:ck[i + 1]].view(-1, H, D)
+        vs = v[ck[i]:ck[i + 1]].view(-1, H, D)
+        if qs.shape[0] == 0:
+            continue
+        s = torch.einsum("qhd,khd->hqk", qs, ks) * D ** -0.5
+        out[cq[i]:cq[i + 1]] = torch.einsum("hqk,khd->qhd", s.softmax(-1), vs).reshape(-1, H * D)
+    return out
+
+
+@pytest.mark.parametrize("D,H,lq,lk", [
+    (80, 16, [8, 5, 10], [529, 345, 16]),           # query→image: key chunks of 256 incl. a ragged last chunk
+    (80, 16, [8, 8], [8, 8]),                       # self-attention of the object queries
+    (80, 4, [20, 3, 0, 17], [300, 9, 4, 257]),      # > 16 queries per segment (two query blocks), empty segment
+    (80, 16, [2116, 64], [8, 7]),                   # image→query: thread per row
+    (80, 2, [300, 270], [40, 33]),                  # image→query with two key chunks (online rescale across chunks)
+    (32, 3, [5], [700]), (64, 2, [400], [5]), (128, 2, [7], [260]), (128, 2, [260], [7]),
+])
+def test_attn_f32(ops, D, H, lq, lk):
+    cq, ck = [0], [0]
+    for a, b in zip(lq, lk):
+        cq.append(cq[-1] + a)
+        ck.append(ck[-1] + b)
+    # fused-projection style inputs: k and v are column slices of one (Tk, 2*H*D) buffer
+    q = rndf(cq[-1], H * D, seed=21)
+    kv = rndf(ck[-1], 2 * H * D, seed=22)
+    k, v = kv[:, : H * D], kv[:, H * D:]
+    k[0] = q[0] * 3                                               # one dominant key → exercises the running-max path
+    out = ops.attn_f32(q, k, v, torch.tensor(cq, dtype=torch.int32, device="cuda"), torch.tensor(ck, dtype=torch.int32, device="cuda"),
+                       max(lq), max(lk), H, D)
+    ref = ref_attn64(q, k, v, cq, ck, H, D)
+    got = join(out, H * D)
+    rows = torch.cat([torch.arange(cq[i], cq[i + 1]) for i in range(len(lq)) if lk[i] > 0]).cuda()
+    split_close(got[rows], ref[rows], f"attn_f32 {lq}x{lk}")
+
+
+def test_rope_half_f32_and_mask_scatter_f32(ops):
+    T, H, D = 77, 16, 80
+    x = rndf(T, 2 * H * D, seed=30)
+    cos, sin = rndf(T, D, seed=31), rndf(T, D, seed=32)
+    ref = x.clone()
+    xv = ref[:, : H * D].view(T, H, D)
+    c, s = cos[:, None, : D // 2], sin[:, None, : D // 2]
+    x1, x2 = xv[..., : D // 2].clone(), xv[..., D // 2:].clone()
+    xv[..., : D // 2] = x1 * c - x2 * s
+    xv[..., D // 2:] = x2 * c + x1 * s
+    ops.rope_half_f32_(x[:, : H * D], cos, sin, H, D)              # strided view: the k half of a fused k|v projection
+    assert rel_err(x, ref) < 1e-6
+    dm, n_obj = 80, 3
+    grids = [(6, 8), (6, 8), (4, 4)]
+    pn = [h * w for h, w in grids]
+    cu = [0]
+    for p in pn:
+        cu.append(cu[-1] + p)
+    N = cu[-1]
+    e2, tok = rndf(4 * N, 4 * dm, seed=33), rndf(n_obj, dm, seed=34)
+    masks = torch.zeros(n_obj, 24, 32, device="cuda")
+    ops.mask_scatter_f32(e2, tok, torch.tensor(cu, dtype=torch.int32, device="cuda"),
+                         torch.tensor([w for _, w in grids], dtype=torch.int32, device="cuda"), masks, n_obj, N, dm)
+    ref = torch.zeros_like(masks)
+    e = e2.view(N, 2, 2, 2, 2, dm)
+    for o in range(n_obj):
+        W = grids[o][1]
+        for pi in range(pn[o]):
+            n = cu[o] + pi
+            r, c_ = pi // W, pi % W
+            ref[o, 4 * r: 4 * r + 4, 4 * c_: 4 * c_ + 4] = (e[n] * tok[o]).sum(-1).permute(0, 2, 1, 3).reshape(4, 4)
+    assert rel_err(masks, ref) < 1e-5
+
+
+def test_gemm_ex_argument_errors(ops):
+    from padt_amd import _lib
+    a = torch.zeros(8, 64, device="cuda", dtype=BF)
+    w = torch.zeros(16, 64, device="cuda", dtype=BF)
+    c = torch.zeros(8, 32, device="cuda", dtype=BF)
+    lib = _lib.load()
+    s = torch.cuda.current_stream().cuda_stream
+    # split output needs ldc >= lo_off + N and lo_off >= N
+    assert lib.padt_gemm_bf16_ex(s, a.data_ptr(), 64, w.data_ptr(), 64, 0, c.data_ptr(), 16, 0, 0, 8, 16, 64, 0, 0, 0, 0, 16) == -1
+    assert lib.padt_gemm_bf16_ex(s, a.data_ptr(), 64, w.data_ptr(), 64, 0, c.data_ptr(), 32, 0, 0, 8, 16, 64, 0, 0, 0, 0, 8) == -1
+    # fp32 residual needs epilogue 2 + fp32 output
+    assert lib.padt_gemm_bf16_ex(s, a.data_ptr(), 64, w.data_ptr(), 64, 0, c.data_ptr(), 32, c.data_ptr(), 32, 8, 16, 64, 2, 0, 0, 1, 0) == -1
+    assert lib.padt_gemm_bf16_ex(s, a.data_ptr(), 64, w.data_ptr(), 64, 0, c.data_ptr(), 32, 0, 0, 8, 16, 64, 0, 0, 0, 0, 16) == 0

@@ -63,13 +63,17 @@ def test_vit_block_real_shape_against_reference_output(golden_dir):
         assert rms < 1.5e-2 and mx < 6e-2, f"{key}: rel err max {mx:.3e} rms {rms:.3e}"   # bf16 weights + activations, 7 kernels deep
 
 
-def test_padt_decoder_real_shape_against_reference_output(golden_dir):
+@pytest.mark.parametrize("hp", [True, False])
+def test_padt_decoder_real_shape_against_reference_output(golden_dir, hp, monkeypatch):
+    """hp=True (default build of the model): split-precision decoder — the north star's 1e-3 on box coordinates / mask logits.
+    hp=False (PADT_DECODER_HP=0): plain bf16 activation storage, kept as the fast variant with its measured, documented distance."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import padt_amd
     import padt_oracle as O
     from padt_amd.modeling import PaDTForConditionalGeneration
     from padt_amd.weights import synthetic_state_dict
+    monkeypatch.setenv("PADT_DECODER_HP", "1" if hp else "0")
     z = np.load(f"{golden_dir}/real_decoder.npz")
     base = padt_amd.small_test_config(layers=1, vit_depth=1)
     cfg = dataclasses.replace(base, hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, intermediate_size=256,
@@ -81,6 +85,7 @@ def test_padt_decoder_real_shape_against_reference_output(golden_dir):
         if k.startswith("vl_decoder."):
             sd[k] = _seeded(shp, k, 0.1, True) if O._is_norm_weight(k) else _seeded(shp, k, 0.02 if k.endswith("bias") else 0.03)
     model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    assert model.W.dec_hp == hp
     g = torch.Generator().manual_seed(123)
     _ = torch.randn(2116, 1280, generator=g)                       # same stream position as make_golden.py
     _ = torch.randint(0, 2116, (48,), generator=g)
@@ -96,27 +101,36 @@ def test_padt_decoder_real_shape_against_reference_output(golden_dir):
                           (c.cuda(), s.cuda()))
     assert out["sample_idx"] == z["sample_idx"].tolist() and list(out["pred_mask"].shape) == z["mask_shape"].tolist()
     assert torch.equal(out["pred_mask_valid_hw"][0].cpu(), _t(z["valid_h"])) and torch.equal(out["pred_mask_valid_hw"][1].cpu(), _t(z["valid_w"]))
-    # (1) against the reference's fp32 run: the difference is dominated by rounding its fp32 weights / inputs to bf16 (what the
-    #     reference's own GPU path does too), measured ~1.4e-2 on box coordinates with these random N(0, 0.03^2) weights
+    # (1) against the reference's fp32 run on its fp32 weights / inputs: dominated by rounding those operands to bf16 — which the
+    #     reference's own GPU path (torch_dtype=bfloat16, test_demo.py:22) does too; ~1.4e-2 on box coordinates with these
+    #     random N(0, 0.03^2) weights, independent of the activation precision
     db = (out["pred_boxes"].float().cpu() - _t(z["pred_boxes"])).abs().max().item()
     ds = (out["pred_score"].float().cpu() - _t(z["pred_score"])).abs().max().item()
     mx, rms = rel(out["pred_mask"].flatten()[_t(z["mask_idx"]).cuda()], _t(z["mask_vals"]))
-    print(f"\n[real PaDT decoder] vs reference fp32: box |d|max {db:.3e} score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}")
+    print(f"\n[real PaDT decoder hp={hp}] vs reference fp32 (fp32 operands): box |d|max {db:.3e} score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}")
     assert db < 4e-2 and ds < 0.15 * (abs(z["pred_score"]).max() + 1) and rms < 6e-2
-    # (2) against the oracle (which test_oracle_golden pins to that same reference output to 1e-5) fed the SAME bf16-rounded
-    #     weights and inputs: isolates the kernels' own arithmetic
+    # (2) against the oracle (which test_oracle_golden pins to that same reference output to 1e-5) fed the SAME bf16-representable
+    #     weights and inputs — "the reference CPU path on the same inputs" of the north star: isolates the kernels' own arithmetic
     r = lambda t_: t_.to(bf).float()
     dwb = {k: r(v) for k, v in sd.items() if k.startswith("vl_decoder.")}
     odec = O.vl_decode(dwb, ocfg, [[r(f) for f in fs] for fs in feats], r(low), r(high), grids, (c, s))
     db2 = (out["pred_boxes"].float().cpu() - odec["pred_boxes"]).abs().max().item()
     ds2 = (out["pred_score"].float().cpu() - odec["pred_score"]).abs().max().item()
     mx2, rms2 = rel(out["pred_mask"], odec["pred_mask"])
-    print(f"[real PaDT decoder] vs oracle on bf16 operands: box |d|max {db2:.3e} score |d|max {ds2:.3e} mask rel max {mx2:.3e} rms {rms2:.3e}")
-    # ~35 kernel outputs are rounded to bf16 on the way (2^-9 relative each, random N(0, 0.03^2) weights of gain > 1): measured
-    # 7.6e-3 on box coordinates, 1.0e-2 rms on mask logits — the reference's own bf16 GPU path sits at the same distance
-    assert db2 < 2e-2, f"boxes differ from the oracle by {db2:.3e}"                        # boxes in [0, 1]
-    assert ds2 < 5e-2 * (odec["pred_score"].abs().max().item() + 1)
-    assert rms2 < 2e-2 and mx2 < 1e-1
+    dm2 = (out["pred_mask"].float().cpu() - odec["pred_mask"]).abs().max().item()
+    print(f"[real PaDT decoder hp={hp}] vs oracle on the same operands: box |d|max {db2:.3e} score |d|max {ds2:.3e} mask |d|max {dm2:.3e} "
+          f"(logit |max| {odec['pred_mask'].abs().max().item():.2f}) rel max {mx2:.3e} rms {rms2:.3e}")
+    if hp:
+        # north star: box coords / mask logits within 1e-3 of the reference CPU path on the same inputs
+        assert db2 < 1e-3, f"boxes differ from the oracle by {db2:.3e}"                    # boxes in [0, 1]
+        assert ds2 < 1e-3 * (odec["pred_score"].abs().max().item() + 1)
+        assert rms2 < 1e-3 and mx2 < 1e-3, f"mask logits: rel max {mx2:.3e} rms {rms2:.3e}"   # relative to the largest logit
+    else:
+        # ~35 kernel outputs are rounded to bf16 on the way (2^-9 relative each, random N(0, 0.03^2) weights of gain > 1): measured
+        # 7.6e-3 on box coordinates, 1.0e-2 rms on mask logits — the distance the reference's own bf16 GPU path sits at
+        assert db2 < 2e-2, f"boxes differ from the oracle by {db2:.3e}"
+        assert ds2 < 5e-2 * (odec["pred_score"].abs().max().item() + 1)
+        assert rms2 < 2e-2 and mx2 < 1e-1
 
 
 def test_llm_layer_real_width_against_hf_text_model(golden_dir):
