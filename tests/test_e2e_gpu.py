@@ -129,7 +129,7 @@ def test_generate_tokens_hidden_and_vl_decode(setup):
     db2 = (dec["pred_boxes"].cpu().float() - odec2["pred_boxes"]).abs().max().item()
     mx2, rms2 = rel_err(dec["pred_mask"], odec2["pred_mask"])
     print(f"[decoder-only parity] box |d|max {db2:.3e}  mask rel max {mx2:.3e} rms {rms2:.3e}")
-    assert db2 < 2e-3 and rms2 < 2e-2
+    assert db2 < 1e-3 and mx2 < 1e-3 and rms2 < 1e-3                  # split-precision decoder: the north star's 1e-3 on identical inputs
 
 
 def test_graph_replay_equals_eager_and_is_repeatable(setup):
