@@ -213,6 +213,13 @@ int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj
  * processor's rescale + normalize), fp32 or bf16.  HF Qwen2-VL image processor: _preprocess / patchify. */
 int padt_patchify_normalize(void* stream, const void* img_u8, int H, int W, const void* lut_f32, void* out, long ld_out,
                             int out_bf16, int patch, int merge, int temporal);
+/* One separable pass (horizontal: in_h == out_h, vertical: in_w == out_w) of Pillow's 8-bit ImagingResample over an interleaved
+ * (H, W, channels) uint8 image: out = clip8(((1 << 21) + sum_k in[first + k] * kk[k]) >> 22), bounds int32 [out][2] = (first, taps),
+ * kk int32 [out][ksize] fixed-point coefficients built on the host as Pillow's precompute_coeffs / normalize_coeffs_8bpc do
+ * (padt_amd/preprocess.py) — integer arithmetic, bit-exact with PIL.Image.resize for BICUBIC (HF Qwen2-VL image processor) and
+ * LANCZOS (eval/test_demo.py:67-73, eval/evaluation_scripts/utils.py:205-218). */
+int padt_resample_pass_u8(void* stream, const void* in_u8, int in_h, int in_w, int channels, void* out_u8, int out_h, int out_w,
+                          const int* bounds, const int* kk, int ksize, int horizontal);
 
 #ifdef __cplusplus
 }

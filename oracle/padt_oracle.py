@@ -730,7 +730,7 @@ def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Seq
 # (transformers/models/qwen2_vl/image_processing_pil_qwen2_vl.py: smart_resize, _preprocess, patchify; arithmetic of
 # image_transforms.rescale / normalize).  Pinned against the INSTALLED transformers 5.15 PIL processor
 # (tests/golden/make_golden_pre.py); the reference pins 4.50.0, whose processor is not in the container (parity with 4.50
-# unpinned).  The bicubic resize itself is PIL's and is not restated.
+# unpinned).  The resize is Pillow's ImagingResample, restated below (pil_resample) and pinned against PIL.Image.resize itself.
 def smart_resize(height: int, width: int, factor: int = 28, min_pixels: int = 56 * 56, max_pixels: int = 14 * 14 * 4 * 1280):
     if max(height, width) / min(height, width) > 200:
         raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(height, width) / min(height, width)}")
@@ -767,6 +767,78 @@ def patchify_normalize(image_u8, patch: int = 14, merge: int = 2, temporal: int 
     pt = v.reshape(C, gh // merge, merge, patch, gw // merge, merge, patch).transpose(1, 4, 2, 5, 0, 3, 6)
     pt = np.broadcast_to(pt[:, :, :, :, :, None, :, :], (*pt.shape[:5], temporal, *pt.shape[5:]))
     return pt.reshape(gh * gw, C * temporal * patch * patch), gh, gw
+
+
+def pil_resample(image_u8, out_w: int, out_h: int, filter_name: str = "bicubic"):
+    """Pillow's 8-bit ImagingResample (src/libImaging/Resample.c; Pillow is a dependency of the reference through
+    transformers' image processor and eval/test_demo.py:73 `image.resize(..., Image.Resampling.LANCZOS)`; unpinned in setup.py) restated
+    loop for loop: precompute_coeffs (double taps of the scaled filter, summed left to right, normalised), normalize_coeffs_8bpc
+    (22-bit fixed point, truncation after +-0.5), horizontal pass then vertical pass over uint8 with
+    clip8(((1 << 21) + sum) >> 22).  Pinned: byte-identical to PIL.Image.resize of the installed Pillow (tests/test_preprocess_cpu.py)."""
+    import numpy as np
+    PB = 32 - 8 - 2
+
+    def bicubic(x):
+        a = -0.5
+        x = abs(x)
+        if x < 1.0:
+            return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+        if x < 2.0:
+            return (((x - 5) * x + 8) * x - 4) * a
+        return 0.0
+
+    def sinc(x):
+        if x == 0.0:
+            return 1.0
+        x = x * math.pi
+        return math.sin(x) / x
+
+    def lanczos(x):
+        return sinc(x) * sinc(x / 3) if -3.0 <= x < 3.0 else 0.0
+    f, sup = {"bicubic": (bicubic, 2.0), "lanczos": (lanczos, 3.0)}[filter_name]
+
+    def coeffs(in_size, out_size):
+        scale = filterscale = in_size / out_size
+        if filterscale < 1.0:
+            filterscale = 1.0
+        support = sup * filterscale
+        ksize = int(math.ceil(support)) * 2 + 1
+        kk = np.zeros((out_size, ksize), np.int64)
+        bounds = np.zeros((out_size, 2), np.int64)
+        for xx in range(out_size):
+            center = (xx + 0.5) * scale
+            ss = 1.0 / filterscale
+            xmin = max(int(center - support + 0.5), 0)
+            xmax = min(int(center + support + 0.5), in_size) - xmin
+            k = [f((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+            ww = 0.0
+            for v in k:
+                ww += v
+            if ww != 0.0:
+                k = [v / ww for v in k]
+            for x, v in enumerate(k):
+                kk[xx, x] = int(-0.5 + v * (1 << PB)) if v < 0 else int(0.5 + v * (1 << PB))
+            bounds[xx] = (xmin, xmax)
+        return bounds, kk
+    cur = np.asarray(image_u8)
+    H, W, C = cur.shape
+    if out_w != W:
+        b, kk = coeffs(W, out_w)
+        out = np.zeros((H, out_w, C), np.uint8)
+        for x in range(out_w):
+            lo, n = b[x]
+            acc = (1 << (PB - 1)) + (cur[:, lo:lo + n, :].astype(np.int64) * kk[x, :n][None, :, None]).sum(1)
+            out[:, x, :] = np.clip(acc >> PB, 0, 255)
+        cur = out
+    if out_h != H:
+        b, kk = coeffs(H, out_h)
+        out = np.zeros((out_h, cur.shape[1], C), np.uint8)
+        for y in range(out_h):
+            lo, n = b[y]
+            acc = (1 << (PB - 1)) + (cur[lo:lo + n].astype(np.int64) * kk[y, :n][:, None, None]).sum(0)
+            out[y] = np.clip(acc >> PB, 0, 255)
+        cur = out
+    return cur
 
 
 def weight_shapes(cfg: OracleConfig) -> Dict[str, Tuple[int, ...]]:

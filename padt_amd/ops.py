@@ -453,6 +453,17 @@ def mask_scatter_f32(e2, mask_tok, cu_patch, obj_w, masks, n_obj, total_patches,
     return masks
 
 
+def resample_pass_u8(img, out, bounds, kk, horizontal):
+    """One pass of Pillow's 8-bit resample (csrc/resize.hip): img / out (H, W, C) uint8 device tensors, bounds (n, 2) / kk (n, ksize) int32."""
+    assert img.dtype == torch.uint8 and out.dtype == torch.uint8 and img.is_contiguous() and out.is_contiguous()
+    assert bounds.dtype == torch.int32 and kk.dtype == torch.int32 and bounds.is_contiguous() and kk.is_contiguous()
+    n = out.shape[1] if horizontal else out.shape[0]
+    assert bounds.shape == (n, 2) and kk.shape[0] == n and img.shape[2] == out.shape[2]
+    _lib.check(_lib.load().padt_resample_pass_u8(_stream(), _p(img), img.shape[0], img.shape[1], img.shape[2], _p(out), out.shape[0],
+                                                 out.shape[1], _p(bounds), _p(kk), kk.shape[1], 1 if horizontal else 0), "padt_resample_pass_u8")
+    return out
+
+
 def memset(t, value=0):
     lib = _lib.load()
     _lib.check(lib.padt_memset(_stream(), _p(t), value, t.numel() * t.element_size()), "padt_memset")

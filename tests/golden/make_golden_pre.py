@@ -20,12 +20,16 @@ def main():
     outs = [p(images=[im], return_tensors="np") for im in imgs]
     both = p(images=imgs, return_tensors="np")
     assert np.array_equal(both["pixel_values"], np.concatenate([o["pixel_values"] for o in outs]))
+    # images that are NOT at their smart_resize size: the processor resizes them itself (PIL bicubic) before patchifying
+    raws = [(rs.rand(61, 97, 3) * 255).astype(np.uint8), (rs.rand(150, 70, 3) * 255).astype(np.uint8)]
+    raw_out = p(images=raws, return_tensors="np")
     sizes = [(640, 640), (100, 37), (37, 100), (1, 1), (28, 28), (2000, 3000), (4096, 64), (333, 555), (27, 5400), (644, 644)]
     sr = [smart_resize(h, w, factor=28, min_pixels=p.size.shortest_edge, max_pixels=p.size.longest_edge) for h, w in sizes]
     np.savez_compressed(os.path.join(HERE, "preprocess.npz"), img0=imgs[0], img1=imgs[1], pix=both["pixel_values"],
                         grid=both["image_grid_thw"], mean=np.array(p.image_mean), std=np.array(p.image_std),
                         rescale=np.array(p.rescale_factor), sizes=np.array(sizes), smart=np.array(sr),
-                        min_max=np.array([p.size.shortest_edge, p.size.longest_edge]))
+                        min_max=np.array([p.size.shortest_edge, p.size.longest_edge]), raw0=raws[0], raw1=raws[1],
+                        pix_raw=raw_out["pixel_values"], grid_raw=raw_out["image_grid_thw"])
     print("wrote preprocess.npz", both["pixel_values"].shape, both["image_grid_thw"].tolist(), sr)
 
 

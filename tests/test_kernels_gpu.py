@@ -732,3 +732,37 @@ def test_patchify_normalize_matches_hf_processor_bit_exact(ops):
     assert torch.equal(pix.cpu(), exp) and grid.tolist() == z["grid"].tolist()
     with pytest.raises(Exception, match="multiples of patch"):
         ops.patchify_normalize(torch.zeros(30, 28, 3, dtype=torch.uint8, device="cuda"), lut, torch.zeros(4, 1176, device="cuda"))
+
+
+def test_gpu_resize_is_byte_exact_with_pillow_and_front_end_matches_pil_path(ops):
+    """csrc/resize.hip = Pillow's ImagingResample on the device: byte-identical to PIL.Image.resize (BICUBIC as the HF processor calls
+    it, LANCZOS as eval/test_demo.py:73 / utils.py:217 do), down- and up-scaling; the whole front-end (callers' LANCZOS rule →
+    smart_resize → bicubic → rescale/normalize/patchify) on the GPU gives bit-identical pixel_values to the host-PIL path, for RGB,
+    gray ('L'), palette and RGBA inputs of ragged sizes."""
+    import numpy as np
+    from PIL import Image
+    from padt_amd import preprocess as P
+    rng = np.random.default_rng(5)
+    fe = P.ImageFrontEnd("cuda", dtype=torch.float32)
+    for (H, W, oh, ow) in [(480, 640, 476, 644), (333, 500, 644, 448), (100, 37, 28, 56), (1200, 900, 644, 476), (20, 300, 28, 420)]:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        for name, pf in (("bicubic", Image.BICUBIC), ("lanczos", Image.LANCZOS)):
+            ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=pf))
+            got = fe.resize_device(torch.from_numpy(img).cuda(), ow, oh, name).cpu().numpy()
+            assert np.array_equal(got, ref), (H, W, oh, ow, name, int((got != ref).sum()))
+    images = [Image.fromarray(rng.integers(0, 256, (427, 640, 3), dtype=np.uint8)),
+              Image.fromarray(rng.integers(0, 256, (500, 333), dtype=np.uint8), mode="L"),
+              Image.fromarray(rng.integers(0, 256, (96, 20, 3), dtype=np.uint8)).convert("P"),
+              Image.fromarray(rng.integers(0, 256, (640, 480, 4), dtype=np.uint8), mode="RGBA"),
+              rng.integers(0, 256, (1100, 1700, 3), dtype=np.uint8)]
+    for pre in (None, "demo644", "min28"):
+        gpu = P.ImageFrontEnd("cuda", dtype=torch.float32, resize="gpu", pre_resize=pre)
+        pil = P.ImageFrontEnd("cuda", dtype=torch.float32, resize="pil", pre_resize=pre)
+        pg, gg = gpu(images)
+        pp, gp = pil(images)
+        assert gg.tolist() == gp.tolist() and torch.equal(pg, pp), pre
+    # and against the HF processor's own output (fixture generated from the installed transformers PIL processor, which resizes itself)
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "preprocess.npz"))
+    if "raw0" in z.files:
+        pix, grid = fe([z["raw0"], z["raw1"]])
+        assert torch.equal(pix.cpu(), torch.from_numpy(z["pix_raw"])) and grid.tolist() == z["grid_raw"].tolist()

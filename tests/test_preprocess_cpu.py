@@ -45,3 +45,56 @@ def test_smart_resize_and_lut_match_processor():
         assert False
     except ValueError:
         pass
+
+
+RESIZE_CASES = [(480, 640, 476, 644), (333, 500, 644, 448), (100, 37, 28, 56), (640, 640, 644, 644), (1200, 900, 644, 476), (20, 300, 28, 420),
+                (427, 640, 420, 644)]
+
+
+def test_pil_resample_restatement_and_coefficient_tables_are_byte_exact_with_pillow():
+    """The resize of the front-end is Pillow's ImagingResample.  Three statements of it must agree byte for byte with PIL.Image.resize
+    on random images (down- and up-scaling, both filters the reference uses): the oracle's loop restatement, and the product's
+    vectorised coefficient tables driven through the same integer pass the HIP kernel runs (csrc/resize.hip)."""
+    import padt_oracle as O
+    from PIL import Image
+    from padt_amd.preprocess import pil_resample_coeffs
+    rng = np.random.default_rng(0)
+    for (H, W, oh, ow) in RESIZE_CASES:
+        img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+        for name, pf in (("bicubic", Image.BICUBIC), ("lanczos", Image.LANCZOS)):
+            ref = np.asarray(Image.fromarray(img).resize((ow, oh), resample=pf))
+            assert np.array_equal(O.pil_resample(img, ow, oh, name), ref), (H, W, oh, ow, name)
+            cur = img
+            for axis, (n_in, n_out) in ((1, (W, ow)), (0, (H, oh))):          # horizontal pass, then vertical
+                if n_in == n_out:
+                    continue
+                b, kk = pil_resample_coeffs(n_in, n_out, name)
+                assert b.dtype == np.int32 and kk.dtype == np.int32 and b.shape == (n_out, 2)
+                src = np.moveaxis(cur, axis, 0).astype(np.int64)
+                out = np.stack([np.clip(((1 << 21) + np.tensordot(kk[i, :b[i, 1]].astype(np.int64), src[b[i, 0]: b[i, 0] + b[i, 1]], axes=(0, 0))) >> 22, 0, 255)
+                                for i in range(n_out)]).astype(np.uint8)
+                cur = np.moveaxis(out, 0, axis)
+            assert np.array_equal(cur, ref), (H, W, oh, ow, name, "coefficient tables")
+
+
+def test_caller_size_rules():
+    from padt_amd import preprocess as P
+    assert P.demo_max_side_size(1280, 720) == (644, 362) and P.demo_max_side_size(333, 500) == (428, 644)      # test_demo.py:67-73
+    assert P.eval_min_side_size(640, 480) == (640, 480) and P.eval_min_side_size(20, 300) == (28, 420)        # utils.py:205-218
+    assert P.eval_min_side_size(300, 20) == (420, 28)
+
+
+def test_oracle_front_end_with_resize_matches_hf_processor_bit_exact():
+    """Images that are not at their smart_resize size: smart_resize → pil_resample (bicubic) → patchify_normalize == the HF processor's
+    own pixel_values (fixture keys raw0/raw1 → pix_raw), float32 bit for bit."""
+    import padt_oracle as O
+    z = load()
+    mn, mx = (int(v) for v in z["min_max"])
+    rows, grids = [], []
+    for k in ("raw0", "raw1"):
+        im = z[k]
+        rh, rw = O.smart_resize(im.shape[0], im.shape[1], 28, mn, mx)
+        r, gh, gw = O.patchify_normalize(O.pil_resample(im, rw, rh, "bicubic"))
+        rows.append(r)
+        grids.append([1, gh, gw])
+    assert grids == z["grid_raw"].tolist() and np.array_equal(np.concatenate(rows), z["pix_raw"])
