@@ -22,9 +22,35 @@ import torch
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-ALG_TFLOP_PER_IMAGE = 6.33          # ViT 2.82 + prefill 3.25 + decode 0.18 + PaDT decoder 0.08
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
+
+
+def alg_tflop_per_image(cfg, L, T, n_obj, n_vrt, grid_hw):
+    """ALGORITHMIC work per image, SURVEY.md §8d formulas (3B REC, L=577, T=28, 1 obj x 5 VRT → 6.32: ViT 2.82 + prefill 3.25 +
+    decode 0.17 + PaDT decoder 0.07; only the last prompt position goes through the head)."""
+    v = cfg.vision_config
+    D, Lyr, Hq, Hkv, I, hd = cfg.hidden_size, cfg.num_hidden_layers, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.head_dim
+    V = cfg.vocab_size
+    P = grid_hw[0] * grid_hw[1]
+    N = P // 4
+    vh, vi = v.hidden_size, v.intermediate_size
+    wp = v.window_size // v.patch_size                                    # patches per window side
+    ws = [min(wp, grid_hw[0] - a) * min(wp, grid_hw[1] - b) for a in range(0, grid_hw[0], wp) for b in range(0, grid_hw[1], wp)]
+    n_full = len(v.fullatt_block_indexes)
+    vit = (2 * P * (v.depth * (3 * vh * vh + vh * vh + 3 * vh * vi) + v.in_channels * v.temporal_patch_size * v.patch_size ** 2 * vh)
+           + (v.depth - n_full) * sum(4 * x * x * vh for x in ws) + n_full * 4 * P * P * vh + 2 * N * ((4 * vh) ** 2 + 4 * vh * D))
+    per_tok = 2 * Lyr * (2 * D * Hq * hd + 2 * D * Hkv * hd + 3 * D * I)
+    prefill = L * per_tok + Lyr * 4 * (L * (L + 1) // 2) * Hq * hd
+    head = 2 * (V + N) * D
+    decode = sum(per_tok + Lyr * 4 * (L + t) * Hq * hd + head for t in range(1, T))
+    dh, di = cfg.vl_decoder["hidden_size"], cfg.vl_decoder["intermediate_size"]
+    Q = 3 + n_vrt
+
+    def block(M):
+        return 2 * Q * (8 * dh * dh + 2 * dh * di) + 2 * M * 4 * dh * dh + 4 * (Q * Q + 2 * Q * M) * dh
+    dec = n_obj * (block(N) + 2 * block(P) + 2 * P * dh * dh + 2 * 4 * P * (dh // 4) * (dh // 4))
+    return (vit + prefill + head + decode + dec) / 1e12
 
 
 def parse_args():
@@ -35,6 +61,9 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tnew", type=int, default=28)
     ap.add_argument("--model", default="3b", choices=["3b", "7b", "small"])
+    ap.add_argument("--task", default="rec", choices=["rec", "ovd"], help="rec: BASELINE configs[1] (L=577, T=28, 1 object x 5 VRT); "
+                    "ovd: BASELINE configs[3] shape per GPU (80-class prompt L=890, T=120, 7 objects x 5 VRT per image)")
+    ap.add_argument("--cap", type=int, default=0, help="object capacity of the per-batch result record (default: 2 x the scheduled objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--merge", type=int, default=8, help="consecutive batches of 8 whose decode steps share one session "
@@ -58,17 +87,32 @@ def build_model(args, device):
     return cfg, model, grid_hw
 
 
+def workload(args):
+    """→ (n_post text tokens after the image, T_new, objects per image, VRTs per object, schedule)."""
+    from padt_amd.synthetic import multi_object_schedule, rec_schedule
+    if args.task == "ovd":
+        T = args.tnew if args.tnew != 28 else 120
+        return 346, T, 7, 5, multi_object_schedule(T, n_obj=7, n_vrt=5)
+    T = args.tnew
+    if T >= 17:
+        return 33, T, 1, 5, rec_schedule(T, range(11, 16))
+    return 33, T, 1, 2, rec_schedule(T, range(2, 4))
+
+
 def make_inputs(cfg, args, grid_hw, device, seed):
-    from padt_amd.synthetic import FakeProcessor, rec_schedule, synthetic_batch
+    from padt_amd.synthetic import FakeProcessor, synthetic_batch
     import padt_amd
+    n_post, T, n_obj, n_vrt, sched = workload(args)
+    args.tnew = T
     grids = [[1, grid_hw[0], grid_hw[1]]] * args.batch
-    grid, pix, ids, am = synthetic_batch(cfg, grids, n_pre=15, n_post=33, seed=seed)
+    grid, pix, ids, am = synthetic_batch(cfg, grids, n_pre=15, n_post=n_post, seed=seed)
     n_m = grid_hw[0] * grid_hw[1] // 4
     proc = padt_amd.VisonTextProcessingClass(FakeProcessor(cfg, n_m), cfg.vision_config.spatial_merge_size)
     proc.model_embed_token_size = cfg.vocab_size
-    sched = rec_schedule(args.tnew, range(11, 16)) if args.tnew >= 17 else rec_schedule(args.tnew, range(2, 4))
+    if not args.cap:
+        args.cap = 2 * n_obj * args.batch
     return dict(grid=grid, pix=pix.to(device).to(torch.bfloat16), ids=ids.to(device), am=am.to(device), proc=proc,
-                sched=sched)
+                sched=sched, n_obj=n_obj, n_vrt=n_vrt, L=ids.shape[1])
 
 
 def run_step(model, inp, args, world):
@@ -77,7 +121,7 @@ def run_step(model, inp, args, world):
         model, inp["proc"], inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew,
         schedule=inp["sched"], sync_every=args.tnew, use_graph=not args.no_graph)
     if world > 1:
-        packed = pipeline.pack_results(decoded, cap=4 * args.batch, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
+        packed = pipeline.pack_results(decoded, cap=args.cap, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
                                        device=inp["pix"].device)
         pipeline.all_gather_results(packed)
     return decoded
@@ -186,19 +230,20 @@ def roofline_leg(model, inp, args, cfg):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg
-def cpu_baseline_leg(cfg, args):
-    """The fp32 CPU oracle (kind "port") on a bounded sample of the same workload: ONE image, real shapes, per-layer
-    timings of each distinct stage multiplied by that stage's count (weights of a stage are shared random tensors —
-    timing does not depend on their values).  ≈15-25 s of CPU work."""
+def cpu_baseline_leg(cfg, args, inp):
+    """The fp32 CPU oracle (kind "port": the reference is Python and cannot travel to the GPU box) actually RUN on a bounded sample of
+    the same workload: ONE image of the batch, same prompt, same scripted schedule, same random-init architecture — generate()
+    (ViT + prototypes + prefill + T-1 decode steps over the 152k + 529 table) + parse + vl_decode, timed end to end.  ≈25-40 s."""
     sys.path.insert(0, os.path.join(ROOT, "oracle"))
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import padt_oracle as O
     import parity_util as U
+    from padt_amd.weights import synthetic_state_dict
     oc = U.oracle_config(cfg)
-    g = torch.Generator().manual_seed(0)
-    # thread count: all cores of a big host oversubscribe the oracle's many small ops; pick the fastest of a few counts
-    # on a ViT-sized GEMM (the count used is what "cores" reports)
     ncpu = os.cpu_count() or 1
+    # thread count: all cores of a big host oversubscribe the oracle's many small ops; pick the fastest of a few counts on a
+    # ViT-sized GEMM (the count used is what "cores" reports)
+    g = torch.Generator().manual_seed(0)
     a_, b_ = torch.randn(2116, 1280, generator=g), torch.randn(3840, 1280, generator=g)
     best = (1e9, 1)
     for th in sorted({min(ncpu, c) for c in (8, 16, 32, 64)}):
@@ -212,70 +257,35 @@ def cpu_baseline_leg(cfg, args):
             best = (dt, th)
     cores = best[1]
     torch.set_num_threads(cores)
-    shapes = O.weight_shapes(oc)
-
-    def rand_w(prefix):
-        return {k: (torch.ones(s) if O._is_norm_weight(k) else torch.randn(s, generator=g) * 0.02)
-                for k, s in shapes.items() if k.startswith(prefix)}
-
-    def timed(fn, reps=1):
-        fn()
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            fn()
-        return (time.perf_counter() - t0) / reps
-    H = W_ = 10 if args.model == "small" else 46
-    grid = torch.tensor([[1, H, W_]])
-    P, N = H * W_, H * W_ // 4
-    L, T = 15 + N + 33, args.tnew
+    # random-init weights of the architecture, generated on the GPU and copied (15 GB of fp32 on the host for 3B)
+    sd = synthetic_state_dict(cfg, seed=0, device=inp["pix"].device, dtype=torch.bfloat16)
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    P = int(inp["grid"][0, 1] * inp["grid"][0, 2])
+    ids, am = inp["ids"][:1].cpu(), inp["am"][:1].cpu()
+    pix, grid = inp["pix"][:P].float().cpu(), inp["grid"][:1]
+    T, sched = args.tnew, inp["sched"]
     with torch.no_grad():
-        # ViT block (window and full) + patch embed + merger
-        bw = rand_w("visual.blocks.0.")
-        x = torch.randn(P, oc.vit_hidden, generator=g)
-        wi, cu_win = O.window_index(grid, 2, oc.window_size, oc.patch_size)
-        c, s = O.vit_rotary(oc, grid, wi)
-        t_win = timed(lambda: O.vit_block(bw, "visual.blocks.0.", oc, x, cu_win, c, s))
-        t_full = timed(lambda: O.vit_block(bw, "visual.blocks.0.", oc, x, [0, P], c, s))
-        pe = torch.randn(oc.vit_hidden, oc.patch_dim, generator=g) * 0.02
-        pix = torch.randn(P, oc.patch_dim, generator=g)
-        mw = rand_w("visual.merger.")
-        t_misc = timed(lambda: (pix @ pe.T, O.linear(torch.nn.functional.gelu(O.linear(
-            O.rms_norm(x, mw["visual.merger.ln_q.weight"]).reshape(N, -1), mw["visual.merger.mlp.0.weight"], mw["visual.merger.mlp.0.bias"])),
-            mw["visual.merger.mlp.2.weight"], mw["visual.merger.mlp.2.bias"])))
-        n_full = len(oc.fullatt_block_indexes)
-        t_vit = t_win * (oc.vit_depth - n_full) + t_full * n_full + t_misc
-        # LLM layer: prefill (L tokens) and one decode step against an L-token cache
-        lw = rand_w("model.layers.0.")
-        h = torch.randn(1, L, oc.hidden_size, generator=g)
-        pos = torch.arange(L).view(1, 1, L).expand(3, 1, L)
-        cos, sin = O.mrope_cos_sin(oc, pos, torch.float32)
-        bias = torch.zeros(1, 1, L, L).masked_fill(~torch.ones(L, L, dtype=torch.bool).tril(), float("-inf"))
-        cache = O.KVCache(1)
-        t_pre = timed(lambda: O.llm_layer(lw, "model.layers.0.", oc, h, cos, sin, bias, None, 0))
-        O.llm_layer(lw, "model.layers.0.", oc, h, cos, sin, bias, cache, 0)
-        k0, v0 = cache.k[0].clone(), cache.v[0].clone()
-        h1 = torch.randn(1, 1, oc.hidden_size, generator=g)
-        c1, s1 = O.mrope_cos_sin(oc, torch.full((3, 1, 1), L), torch.float32)
-
-        def dec_layer():
-            cache.k[0], cache.v[0] = k0, v0
-            O.llm_layer(lw, "model.layers.0.", oc, h1, c1, s1, torch.zeros(1, 1, 1, L + 1), cache, 0)
-        t_dec = timed(dec_layer, reps=3)
-        E = torch.randn(oc.vocab_size + N, oc.hidden_size, generator=g) * 0.02
-        t_head = timed(lambda: h1[0] @ E.T, reps=3)
-        # PaDT decoder, 1 object x 5 VRTs
-        dw = rand_w("vl_decoder.")
-        feats = [[torch.randn(5, oc.hidden_size, generator=g)]]
-        low = torch.randn(N, oc.hidden_size, generator=g)
-        high = torch.randn(P, oc.dec_hidden, generator=g)
-        t_vl = timed(lambda: O.vl_decode(dw, oc, feats, low, high, grid, (c, s)))
-    t_img = t_vit + oc.num_layers * t_pre + t_head + (T - 1) * (oc.num_layers * t_dec + t_head) + t_vl
+        t0 = time.perf_counter()
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched)
+        t_gen = time.perf_counter() - t0
+        st = ores["state"]
+        runs, cur = [], []
+        for t, m in enumerate(sched):                                  # VRT runs of the schedule = the objects the parser would find
+            if m == "v":
+                cur.append(t)
+            elif cur:
+                runs.append(cur)
+                cur = []
+        feats = [[torch.cat([ores["hidden"][t][0:1, -1] for t in r], 0) for r in runs]]
+        t1 = time.perf_counter()
+        O.vl_decode(w, oc, feats, st.proto, st.high_res, grid, st.visual_pe)
+        t_dec = time.perf_counter() - t1
+    t_img = t_gen + t_dec
     return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": cores, "kind": "port",
-            "sample": ("1 image, real shapes, fp32 CPU oracle: ViT block window %.3fs x%d + full %.3fs x%d + embed/merger "
-                       "%.3fs; LLM layer prefill(L=%d) %.3fs x%d; decode layer %.4fs x%d x%d steps; head %.4fs x%d; "
-                       "vl_decode(1 obj, mask on) %.3fs → %.2f s/image"
-                       % (t_win, oc.vit_depth - n_full, t_full, n_full, t_misc, L, t_pre, oc.num_layers, t_dec, oc.num_layers,
-                          T - 1, t_head, T, t_vl, t_img))}
+            "sample": "1 image of the workload (L=%d, T_new=%d, %d object(s) x %d VRT), fp32 CPU oracle run end to end: generate %.2f s "
+                      "(ViT + prefill + %d decode steps) + vl_decode %.2f s = %.2f s/image on %d threads of %d host cores"
+                      % (ids.shape[1], T, len(runs), len(runs[0]) if runs else 0, t_gen, T - 1, t_dec, t_img, cores, ncpu)}
 
 
 def main():
@@ -314,7 +324,7 @@ def main():
 
     def gather(decoded):
         if world > 1:
-            packed = pipeline.pack_results(decoded, cap=4 * args.batch, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
+            packed = pipeline.pack_results(decoded, cap=args.cap, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
                                            device=inp["pix"].device)
             pipeline.all_gather_results(packed)
 
@@ -364,7 +374,21 @@ def main():
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    assert decoded["pred_boxes"].shape == (args.batch, 4) and torch.isfinite(decoded["pred_boxes"]).all()
+    assert decoded["pred_boxes"].shape == (args.batch * inp["n_obj"], 4) and torch.isfinite(decoded["pred_boxes"]).all()
+    # latency of ONE batch running alone (depth 1, merge 1: no other batch in flight), same workload
+    lat = None
+    if world == 1 and not args.no_alt:
+        for _ in range(2):
+            run_step(model, inp, args, 1)
+        torch.cuda.synchronize()
+        tl = time.perf_counter()
+        kl = 4
+        for _ in range(kl):
+            run_step(model, inp, args, 1)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - tl) / kl
+        lat = {"ms_per_batch": round(el * 1e3, 3), "images_per_s": round(args.batch / el, 3),
+               "note": "one batch alone on the GPU (depth 1, merge 1): ViT + prefill + decode + parse + PaDT decoder back to back"}
 
     if args.timeline and runner is not None and rank == 0:
         # stream timeline of a few pipelined steps (events on the prefill / per-lane decode streams), ms from the first mark
@@ -400,27 +424,32 @@ def main():
     if rank == 0:
         n_img = args.batch * args.steps * world
         value = n_img / elapsed
+        alg_tf = alg_tflop_per_image(cfg, inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
+        wl = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 (split-precision "
+              "PaDT decoder), random-init weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps "
+              "of %d consecutive batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)"
+              % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
+                 args.batch, grid_hw[0], grid_hw[1], inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], args.batch, args.merge))
         line = {
             "metric": "images/sec PaDT_Pro_3B REC inference, 1/2/4/8 MI355X; box IoU vs ref",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
-            "config": {"workload": "PaDT_Pro_3B REC, batch=%d/GPU 640x640 synthetic (grid 46x46, L=577, T_new=%d, 1 obj x 5 VRT, "
-                                   "mask head on), bf16, random-init 3.85B weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder "
-                                   "per batch, decode steps of %d consecutive batches share one weight pass (in-flight batching, "
-                                   "per-sample results bit-identical to batch-at-a-time)" % (args.batch, args.tnew, args.batch, args.merge)
-                       if args.model == "3b" else ("PaDT_Pro_7B (untied head), same REC workload" if args.model == "7b" else "small_test_config (plumbing)"),
+            "config": {"workload": wl,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth * args.merge,
                        "decode_groups_in_flight": args.depth, "batches_per_decode_group": args.merge},
-            "alg_tflops_e2e": round(value * ALG_TFLOP_PER_IMAGE, 1) if args.model == "3b" else None,
-            "mfma_frac_e2e": round(value * ALG_TFLOP_PER_IMAGE / MFMA_BF16_PEAK_TFLOPS / world, 4) if args.model == "3b" else None,
+            "alg_tflop_per_image": round(alg_tf, 3),
+            "alg_tflops_e2e": round(value * alg_tf, 1),
+            "mfma_frac_e2e": round(value * alg_tf / MFMA_BF16_PEAK_TFLOPS / world, 4),
         }
+        if lat is not None:
+            line["single_batch_latency"] = lat
         if alt is not None:
             line["unmerged_decode"] = alt
         if not args.no_roofline:
             line["roofline"] = roofline_leg(model, inp, args, cfg)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_leg(cfg, args)
+            line["cpu_baseline"] = cpu_baseline_leg(cfg, args, inp)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

@@ -39,6 +39,22 @@ def rec_schedule(t_new=28, vrt_at=range(11, 16)):
     return s
 
 
+def multi_object_schedule(t_new=120, n_obj=7, n_vrt=5):
+    """OVD-shaped completion (src/preprocess/process_coco.py:135-164 answer template): n_obj runs of n_vrt VRTs separated by text
+    (label, quotes, separators), evenly spread, EOS forced at the last step."""
+    gap = (t_new - 2 - n_obj * n_vrt) // (n_obj + 1)
+    if gap < 1:
+        raise ValueError("t_new too short for the requested objects")
+    s = ["t"] * t_new
+    pos = gap
+    for _ in range(n_obj):
+        for i in range(pos, pos + n_vrt):
+            s[i] = "v"
+        pos += n_vrt + gap
+    s[-1] = "e"
+    return s
+
+
 class FakeTokenizer:
     def __init__(self, cfg: PaDTConfig, n_vrt: int):
         self.cfg, self.n_vrt = cfg, n_vrt

@@ -1,6 +1,6 @@
 """world_size-2 gloo run of the data-parallel result exchange (the only collective on the path):
-each rank packs its own vl_decode outputs into fixed-capacity buffers, one all_gather, every rank unpacks all ranks'
-results with globally re-based sample indices."""
+each rank packs its own vl_decode outputs into ONE fixed-capacity record, ONE all_gather_into_tensor, every rank unpacks all
+ranks' results with globally re-based sample indices — fp32 payload, bit for bit what vl_decode returned."""
 import os
 import socket
 
@@ -36,7 +36,9 @@ def _worker(rank, world, port, q):
     packed = pipeline.pack_results(dec, cap=8, mask_hw=32, device="cpu")
     gathered = pipeline.all_gather_results(packed)
     res = pipeline.unpack_results(gathered, batch_per_rank=4)
-    q.put((rank, [r["boxes"].clone() for r in res], [r["sample_idx"].clone() for r in res], [r["masks"].float().clone() for r in res]))
+    assert gathered.shape == (world, packed.numel()) and gathered.dtype == torch.int32
+    q.put((rank, [r["boxes"].clone() for r in res], [r["sample_idx"].clone() for r in res],
+           [None if r["masks"] is None else r["masks"].clone() for r in res], [r["scores"].clone() for r in res], [r["valid_hw"].clone() for r in res]))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -53,12 +55,13 @@ def test_result_all_gather_two_ranks():
         p.join(timeout=60)
         assert p.exitcode == 0
     ref = _fake_decoded(0, 3)
-    for rank, boxes, sidx, masks in got:
+    for rank, boxes, sidx, masks, scores, hw in got:
         assert len(boxes) == 2 and boxes[0].shape == (3, 4) and boxes[1].shape == (0, 4)
-        assert torch.equal(boxes[0], ref["pred_boxes"])
+        assert torch.equal(boxes[0], ref["pred_boxes"]) and torch.equal(scores[0], ref["pred_score"].reshape(-1))
         assert sidx[0].tolist() == [0, 1, 2] and sidx[1].tolist() == []
-        assert torch.allclose(masks[0][:, :24, :32], ref["pred_mask"].bfloat16().float())
-        assert (masks[0][:, 24:] == 0).all()
+        assert torch.equal(masks[0][:, :24, :32], ref["pred_mask"])              # fp32 on the wire: bit-exact
+        assert (masks[0][:, 24:] == 0).all() and masks[1] is None
+        assert hw[0].tolist() == [[6, 8]] * 3
 
 
 def test_pack_capacity_errors():

@@ -456,3 +456,53 @@ def test_repetition_penalty_and_eos_list(setup):
     assert torch.equal(oref["sequences"][:, L:], stop[:, : oref["sequences"].shape[1] - L])
     with pytest.raises(NotImplementedError):
         model.generate(eos_token_id=[extra], **kw)
+
+
+def test_ovd_shaped_completion_through_the_runner(setup):
+    """OVD-shaped workload (BASELINE configs[3]: several objects per image, eval/evaluation_scripts/inference_coco.py:101-110) end to
+    end on the throughput runner: 7 VRT runs per completion → 7 objects per image through parse + vl_decode, merged decode groups;
+    boxes / masks against the oracle's own end-to-end run, object bookkeeping exact."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    from padt_amd.synthetic import multi_object_schedule
+    O = U.O
+    grids = [[1, 10, 12], [1, 8, 8]]
+    T = 48
+    sched = multi_object_schedule(T, n_obj=7, n_vrt=3)
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 30), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = [U.synthetic_batch(cfg, grids, n_pre=6, n_post=20, ragged=True, seed=900 + i) for i in range(3)]
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=2)
+    results = []
+    for grid, pix, ids, am in batches:
+        results += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+    results += runner.flush()
+    assert len(results) == 3
+    segs, cur = [], []
+    for t, m in enumerate(sched):
+        if m == "v":
+            cur.append(t)
+        elif cur:
+            segs.append(cur)
+            cur = []
+    for i, ((grid, pix, ids, am), (decoded, completions, labels, vrts)) in enumerate(zip(batches, results)):
+        assert decoded["pred_boxes"].shape == (14, 4) and decoded["sample_idx"] == [0] * 7 + [1] * 7
+        assert all(len(v) == 7 for v in vrts)
+        # the same batch run alone: identical objects, bit for bit (merged decode groups change nothing per sample)
+        solo, _, _, svrts = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+        assert svrts == vrts and torch.equal(solo["pred_boxes"], decoded["pred_boxes"]) and torch.equal(solo["pred_mask"], decoded["pred_mask"])
+        if i:
+            continue
+        # oracle teacher-forced on the HIP tokens → its own features → its own decoder: end-to-end parity of all 14 objects
+        gids = proc.assign_to_global_vrt_id(ids.clone(), grid)
+        out = model.generate(input_ids=gids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid,
+                             max_new_tokens=T, schedule=sched)
+        toks = out.sequences.cpu()[:, ids.shape[1]:]
+        ores = O.generate(w, oc, gids, am, pix, grid, T, schedule=sched, force_tokens=toks)
+        st = ores["state"]
+        feats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in sg], 0) for sg in segs] for b in range(2)]
+        odec = O.vl_decode(w, oc, feats, st.proto, st.high_res, grid, st.visual_pe)
+        db = (decoded["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
+        mx, rms = rel_err(decoded["pred_mask"], odec["pred_mask"])
+        assert db < 5e-3 and rms < 3e-2, f"OVD e2e: box {db:.3e} mask rms {rms:.3e}"

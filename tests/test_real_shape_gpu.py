@@ -339,3 +339,45 @@ def test_full_depth_3b_teacher_forced_against_oracle():
           f"decoder alone on identical inputs: box |d|max {db2:.3e} mask rel max {mx2:.3e} rms {rms2:.3e}; ties {n_tie}/{T}, token noise {noise:.3e}")
     assert db2 < 1e-3 and mx2 < 1e-3                                 # north star: decoder kernels on the same inputs
     assert iou > 0.9 and db < 5e-2                                   # 32 + 36 bf16 layers upstream of the decoder's inputs
+
+
+def test_padt_decoder_ovd_shape_seven_objects_per_image():
+    """BASELINE configs[3] (OVD COCO: ≈7 objects x 5 VRTs per image, eval/evaluation_scripts/inference_coco.py:101-110): vl_decode at the
+    real decoder shape with 7 objects on each of two images (14 objects, 56 + 42 query rows → the tile-GEMM path on the query side,
+    29 624 + 19 320 image rows replicated per object as padt.py:362-376 does) against the oracle on the same operands, at the north
+    star's 1e-3."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    import padt_oracle as O
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    base = padt_amd.small_test_config(layers=1, vit_depth=1)
+    cfg = dataclasses.replace(base, hidden_size=2048, num_attention_heads=16, num_key_value_heads=2, intermediate_size=256,
+                              vision_config=dataclasses.replace(base.vision_config, out_hidden_size=2048),
+                              vl_decoder={"hidden_size": 1280, "intermediate_size": 3420, "num_heads": 16, "use_mask_loss": True})
+    sd = synthetic_state_dict(cfg, seed=0, device="cpu")
+    ocfg = O.OracleConfig()
+    for k, shp in O.weight_shapes(ocfg).items():
+        if k.startswith("vl_decoder."):
+            sd[k] = _seeded(shp, k, 0.1, True) if O._is_norm_weight(k) else _seeded(shp, k, 0.02 if k.endswith("bias") else 0.03)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    g = torch.Generator().manual_seed(321)
+    grids = torch.tensor([[1, 46, 46], [1, 46, 30]])
+    Ps = [46 * 46, 46 * 30]
+    bf = torch.bfloat16
+    r = lambda t_: t_.to(bf).float()
+    low = r(torch.randn(sum(Ps) // 4, 2048, generator=g))
+    high = r(torch.randn(sum(Ps), 1280, generator=g))
+    wi, _ = O.window_index(grids, 2, 112, 14)
+    c, s = O.vit_rotary(ocfg, grids, wi)
+    feats = [[r(torch.randn(5, 2048, generator=g)) for _ in range(7)] for _ in range(2)]
+    out = model.vl_decode([[f.to(bf).cuda() for f in fs] for fs in feats], low.to(bf).cuda(), high.to(bf).cuda(), grids, (c.cuda(), s.cuda()))
+    dwb = {k: r(v) for k, v in sd.items() if k.startswith("vl_decoder.")}
+    odec = O.vl_decode(dwb, ocfg, feats, low, high, grids, (c, s))
+    assert out["sample_idx"] == odec["sample_idx"] == [0] * 7 + [1] * 7 and out["pred_mask"].shape == odec["pred_mask"].shape
+    db = (out["pred_boxes"].float().cpu() - odec["pred_boxes"]).abs().max().item()
+    ds = (out["pred_score"].float().cpu() - odec["pred_score"]).abs().max().item()
+    mx, rms = rel(out["pred_mask"], odec["pred_mask"])
+    print(f"\n[OVD-shape decoder, 14 objects] vs oracle: box |d|max {db:.3e} score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}")
+    assert db < 1e-3 and ds < 1e-3 * (odec["pred_score"].abs().max().item() + 1) and mx < 1e-3 and rms < 1e-3
