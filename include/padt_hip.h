@@ -179,7 +179,7 @@ int padt_mask_scatter_f32(void* stream, const void* e2, long ld_e2, const void* 
  * embed_table_packed (nullable): fragment-packed copy of embed_table ([vocab/16][D/32][64][8], as padt_gemm_packed_bf16's
  * weights); when given, `hidden` must be in the 16-row fragment-packed activation layout (ldh = D) and text rows are
  * streamed as 1 KiB contiguous wave loads (0.62 GB per step is the decode step's largest single read).
- * gen_cfg (nullable, DEVICE memory: {float repetition_penalty; int eos[4]; int pad[3]}) + seen (nullable, device bitmap
+ * gen_cfg (nullable, DEVICE memory: {float repetition_penalty; int eos[4]; sampling fields, see padt_sample_token}) + seen (nullable, device bitmap
  * [batch][seen_words] of 32-bit words, bit r = table row r already occurs in that sample's input_ids): HF's
  * RepetitionPenaltyLogitsProcessor (score < 0 ? score*p : score/p) fused in front of the mask/arg-max, padt.py:570-580,717.
  * Kept in device memory so a captured decode graph does not bake the values in. */
@@ -195,6 +195,14 @@ int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, 
                       int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok, int* step, int* slot,
                       int* lens, int* pos3, const void* hidden, void* hidden_buf, int advance, const void* gen_cfg,
                       void* seen, long seen_words);
+/* Sampling branch (padt.py:740-743 multinomial over softmax of the warped scores): one token per row drawn from the fp32 logits
+ * padt_vrt_head wrote (logits_f32), after HF's Temperature → TopK → TopP warpers (generation/logits_process.py) with the
+ * parameters in gen_cfg (DEVICE: {float penalty; int eos[4]; int do_sample; unsigned seed; float temperature; int top_k;
+ * float top_p; int pad[2]}); exact top-k by radix select, nucleus over the sorted survivors (top_p < 1 needs 0 < top_k <= 1024),
+ * Gumbel-max draw keyed by (seed, *step, row, index) so a captured decode graph draws fresh numbers every replay.  Writes one
+ * (value, index) pair per row in padt_greedy_step's partial layout (nblk = 1). */
+int  padt_sample_token(void* stream, const void* logits_f32, long ld_logits, long n_rows_table, const void* gen_cfg, const int* step,
+                       void* part_val, void* part_idx, long batch);
 /* seen[rows[i]] |= bit(ids[i]) for the prompt tokens of a generate call (ids global in the session's table). */
 int  padt_seen_init(void* stream, const long* ids, const int* rows, long n, void* seen, long seen_words);
 

@@ -507,6 +507,25 @@ def generate(w, cfg: OracleConfig, input_ids: Tensor, attention_mask: Tensor, pi
     return {"sequences": seq, "hidden": hiddens, "state": st, "logits": all_logits}
 
 
+def warp_logits(scores: Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0, min_tokens_to_keep: int = 1) -> Tensor:
+    """HF logits warpers in the order _get_logits_processor appends them (transformers 4.50 generation/utils.py, called at padt.py:570-580;
+    classes in generation/logits_process.py): TemperatureLogitsWarper (scores / T), TopKLogitsWarper (-inf below the k-th largest: ties
+    with it stay), TopPLogitsWarper (sort ascending, drop the tokens whose cumulative probability is <= 1 - top_p, keep the last
+    min_tokens_to_keep).  The sampling branch then draws multinomial(softmax(result)) (padt.py:740-743)."""
+    s = scores.float() / temperature
+    if top_k and top_k > 0:
+        k = min(max(top_k, min_tokens_to_keep), s.shape[-1])
+        kth = torch.topk(s, k)[0][..., -1, None]
+        s = s.masked_fill(s < kth, float("-inf"))
+    if top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(s, descending=False)
+        cum = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cum <= (1 - top_p)
+        remove[..., -min_tokens_to_keep:] = 0
+        s = s.masked_fill(remove.scatter(-1, sorted_indices, remove), float("-inf"))
+    return s
+
+
 # --------------------------------------------------------------------------- PaDT decoder
 def _apply_rotary_half(x: Tensor, cos: Tensor, sin: Tensor) -> Tensor:
     """flash-attn non-interleaved rotary (padt_decoder.py:43,50): rot dim = 2*cos.shape[-1]; pairs (x_i, x_{i+rot/2})."""

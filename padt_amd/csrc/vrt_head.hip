@@ -21,7 +21,12 @@ extern "C" void padt_set_error(const char* msg);
 struct GenCfg {
     float penalty;                     // RepetitionPenaltyLogitsProcessor: score<0 ? score*p : score/p on every id already in the row
     int eos[4];                        // up to 4 EOS ids, -1 = unused
-    int pad[3];
+    int do_sample;                     // 0 greedy (arg-max), 1 multinomial sampling (padt.py:740-743) by sample_token_kernel
+    unsigned seed;                     // counter-based RNG key (the device step counter, row and table index are the counter)
+    float temperature;                 // TemperatureLogitsWarper
+    int top_k;                         // TopKLogitsWarper (0 = off)
+    float top_p;                       // TopPLogitsWarper (1 = off)
+    int pad[2];
 };
 
 struct HeadArgs {
@@ -235,6 +240,174 @@ extern "C" int padt_greedy_step(void* stream, const void* part_val, const void* 
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(greedy_step_kernel, dim3((unsigned)batch), dim3(256), 0, s, a);
     hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(1), 0, s, step);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Sampling branch of the loop (padt.py:740-743: probs = softmax(next_token_scores); next = multinomial(probs, 1)) with HF's
+// logits warpers (generation/logits_process.py: Temperature → TopK → TopP, the order _get_logits_processor builds at padt.py:570-580).
+// One block per row over the fp32 logits the head kernel wrote (mask / repetition penalty / scripted mode already applied):
+//   top-k: exact k-th largest by a 4-pass radix select on order-preserving keys; everything >= it stays (HF keeps ties);
+//   top-p: the survivors (<= 1024: top_p needs top_k) are sorted in LDS; rank r stays iff the probability mass of the ranks
+//          before it is < top_p (= HF's "remove ascending-cumulative <= 1 - top_p", at least one token kept);
+//   draw:  Gumbel-max — argmax((l - max)/T + g), g = -log(-log u), u from a counter-based hash of (seed, step, row, index) —
+//          an exact multinomial draw from softmax(l/T) over the survivors without normalising or building a CDF.
+// The draws cannot match torch.multinomial's (different generator); the DISTRIBUTION is what the tests check.
+PADT_DEV unsigned hash32(unsigned x) {
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
+}
+PADT_DEV float gumbel_noise(unsigned seed, unsigned step, unsigned row, unsigned idx) {
+    unsigned x = hash32(idx * 0x9E3779B1u + seed);
+    x = hash32(x ^ (row * 0x85EBCA77u + step * 0xC2B2AE3Du + 0x68bc21ebu));
+    const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    return -logf(-logf(u));
+}
+PADT_DEV unsigned float_key(float f) {                                    // order-preserving float → uint
+    const unsigned u = __builtin_bit_cast(unsigned, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ __launch_bounds__(1024) void sample_token_kernel(const float* __restrict__ logits, long ld, int n, const GenCfg* __restrict__ g,
+                                                            const int* __restrict__ step, float* __restrict__ out_val,
+                                                            int* __restrict__ out_idx) {
+    __shared__ unsigned hist[256];
+    __shared__ unsigned sel[2];                                           // chosen bin, remaining rank
+    __shared__ float sval[1024];
+    __shared__ int sidx[1024];
+    __shared__ float red_v[1024];
+    __shared__ int red_i[1024];
+    __shared__ int cnt;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = logits + (long)b * ld;
+    const float T = g->temperature > 0.f ? g->temperature : 1.f;
+    const int k = g->top_k;
+    const float top_p = g->top_p;
+    const unsigned seed = g->seed, st = step ? (unsigned)*step : 0u;
+    // ---- top-k threshold (key of the k-th largest entry), or keep everything finite
+    unsigned thresh = float_key(-INFINITY) + 1u;                          // any finite value
+    if (k > 0 && k < n) {
+        unsigned prefix = 0u, mask = 0u, remaining = (unsigned)k;
+        for (int pass = 3; pass >= 0; --pass) {
+            const int shift = pass * 8;
+            if (tid < 256) hist[tid] = 0u;
+            __syncthreads();
+            for (int i = tid; i < n; i += 1024) {
+                const unsigned key = float_key(row[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0u;
+                int bin = 255;
+                for (; bin > 0; --bin) {
+                    if (cum + hist[bin] >= remaining) break;
+                    cum += hist[bin];
+                }
+                sel[0] = (unsigned)bin;
+                sel[1] = remaining - cum;
+            }
+            __syncthreads();
+            prefix |= sel[0] << shift;
+            mask |= 0xffu << shift;
+            remaining = sel[1];
+            __syncthreads();
+        }
+        if (prefix > thresh) thresh = prefix;                             // fewer than k finite entries: -inf stays out
+    }
+    // ---- row maximum over the survivors (for the exponentials)
+    float mx = -INFINITY;
+    for (int i = tid; i < n; i += 1024) {
+        const float v = row[i];
+        if (float_key(v) >= thresh) mx = fmaxf(mx, v);
+    }
+    red_v[tid] = mx;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if (tid < s2) red_v[tid] = fmaxf(red_v[tid], red_v[tid + s2]);
+        __syncthreads();
+    }
+    mx = red_v[0];
+    __syncthreads();
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    if (top_p < 1.0f && k > 0 && k <= 1024) {
+        // ---- nucleus over the (<= 1024) top-k survivors: gather, sort descending, prefix mass, Gumbel over the kept ranks
+        if (tid == 0) cnt = 0;
+        sval[tid] = -INFINITY;
+        sidx[tid] = 0x7fffffff;
+        __syncthreads();
+        for (int i = tid; i < n; i += 1024) {
+            const float v = row[i];
+            if (float_key(v) >= thresh) {
+                const int slot = atomicAdd(&cnt, 1);
+                if (slot < 1024) { sval[slot] = v; sidx[slot] = i; }
+            }
+        }
+        __syncthreads();
+        for (int size = 2; size <= 1024; size <<= 1)                        // bitonic sort, descending by (value, then lower index first)
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                const int j = tid ^ stride;
+                if (j > tid) {
+                    const bool desc = (tid & size) == 0;
+                    const float a = sval[tid], c = sval[j];
+                    const int ai = sidx[tid], ci = sidx[j];
+                    const bool a_first = (a > c) || (a == c && ai < ci);
+                    if (a_first != desc) { sval[tid] = c; sval[j] = a; sidx[tid] = ci; sidx[j] = ai; }
+                }
+                __syncthreads();
+            }
+        const float pv = sval[tid] > -INFINITY ? expf((sval[tid] - mx) / T) : 0.f;
+        red_v[tid] = pv;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {                          // inclusive scan
+            const float add = tid >= off ? red_v[tid - off] : 0.f;
+            __syncthreads();
+            red_v[tid] += add;
+            __syncthreads();
+        }
+        const float total = red_v[1023];
+        const float before = (red_v[tid] - pv) / total;                   // probability mass of the ranks before this one
+        const bool keep = sval[tid] > -INFINITY && (tid == 0 || before < top_p);
+        if (keep) {
+            best = (sval[tid] - mx) / T + gumbel_noise(seed, st, (unsigned)b, (unsigned)sidx[tid]);
+            bidx = sidx[tid];
+        }
+    } else {
+        for (int i = tid; i < n; i += 1024) {
+            const float v = row[i];
+            if (float_key(v) >= thresh) {
+                const float sc = (v - mx) / T + gumbel_noise(seed, st, (unsigned)b, (unsigned)i);
+                if (sc > best || (sc == best && i < bidx)) { best = sc; bidx = i; }
+            }
+        }
+    }
+    __syncthreads();
+    red_v[tid] = best;
+    red_i[tid] = bidx;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if (tid < s2) {
+            const float ov = red_v[tid + s2];
+            const int oi = red_i[tid + s2];
+            if (ov > red_v[tid] || (ov == red_v[tid] && oi < red_i[tid])) { red_v[tid] = ov; red_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { out_val[b] = red_v[0]; out_idx[b] = red_i[0]; }
+}
+
+// next token per row by multinomial sampling from the warped logits; writes one (value, index) "partial" per row in the layout
+// padt_greedy_step reads with nblk = 1, so the bookkeeping kernel is shared with the greedy path.
+extern "C" int padt_sample_token(void* stream, const void* logits_f32, long ld_logits, long n_rows_table, const void* gen_cfg,
+                                 const int* step, void* part_val, void* part_idx, long batch) {
+    if (batch <= 0) return 0;
+    if (gen_cfg == nullptr || n_rows_table <= 0 || n_rows_table > 0x7fffffffL) { padt_set_error("padt_sample_token: gen_cfg and a table size are required"); return -1; }
+    hipLaunchKernelGGL(sample_token_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, (const float*)logits_f32, ld_logits,
+                       (int)n_rows_table, (const GenCfg*)gen_cfg, step, (float*)part_val, (int*)part_idx);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

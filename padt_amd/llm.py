@@ -174,7 +174,9 @@ class DecodeSession:
         self.err = z(1, dt=I32)
         self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
         self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
-        self.graph: Optional[torch.cuda.CUDAGraph] = None
+        self.graphs = {}                 # captured decode-step graph per mode (greedy / sampling: different kernel sequences)
+        self.do_sample = False
+        self.logits = None               # fp32 [B][V + np_max] rows for the sampling kernel, allocated on first use
         self.np_cur = np_max
 
     # one decode step, all on the current stream (eager or under capture)
@@ -205,15 +207,24 @@ class DecodeSession:
     def head_and_select(self, hn, advance: bool):
         cfg, W = self.cfg, self.W
         hp = W.get("llm.head.wp")
+        lg = None
+        if self.do_sample:                                   # the sampling kernel needs the whole masked / penalised logit row
+            if self.logits is None:
+                self.logits = torch.empty((self.B, cfg.vocab_size + self.np_max), device=hn.device, dtype=torch.float32)
+            lg = self.logits
         if hp is not None:                                   # packed table + packed hidden rows: 1 KiB contiguous wave loads
             ops.pack_rows(hn, self.hn_pk, self.B, to_packed=True)
             ops.vrt_head(self.hn_pk, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
                          mode_table=self.mode_table, step=self.step, table_packed=hp, rows=self.B, gen_cfg=self.gen_cfg,
-                         seen=self.seen)
+                         seen=self.seen, logits=lg)
         else:
             ops.vrt_head(hn, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
-                         mode_table=self.mode_table, step=self.step, gen_cfg=self.gen_cfg, seen=self.seen)
-        ops.greedy_step(self.part_val, self.part_idx, self.nblk, hn, self.hidden_buf, self.unfinished, self.tokens,
+                         mode_table=self.mode_table, step=self.step, gen_cfg=self.gen_cfg, seen=self.seen, logits=lg)
+        nblk = self.nblk
+        if self.do_sample:                                   # padt.py:740-743: multinomial over softmax of the warped scores
+            ops.sample_token(lg, cfg.vocab_size + self.np_max, self.gen_cfg, self.step, self.part_val, self.part_idx, self.B)
+            nblk = 1
+        ops.greedy_step(self.part_val, self.part_idx, nblk, hn, self.hidden_buf, self.unfinished, self.tokens,
                         self.cur_tok, self.step, self.slot, self.lens, self.pos3, cfg.eos_token_id, cfg.pad_token_id,
                         advance=advance, gen_cfg=self.gen_cfg, seen=self.seen)
 
@@ -224,15 +235,15 @@ class DecodeSession:
             for _ in range(n):
                 self.step_kernels()
             return
-        if self.graph is None:
+        if self.do_sample not in self.graphs:
             self.step_kernels()                              # real step; also pays every one-time kernel attribute call
             n -= 1
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self.step_kernels()
-            self.graph = g
+            self.graphs[self.do_sample] = g
         for _ in range(n):
-            self.graph.replay()
+            self.graphs[self.do_sample].replay()
 
 
 class LanguageModel:

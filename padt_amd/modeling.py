@@ -104,7 +104,7 @@ class PaDTForConditionalGeneration:
         # :570-580 logits processors / stopping criteria); from_pretrained fills it, explicit generate() kwargs override it
         self.generation_config = SimpleNamespace(repetition_penalty=1.0, eos_token_id=[config.eos_token_id],
                                                  pad_token_id=config.pad_token_id, do_sample=False, temperature=1.0,
-                                                 top_k=0, top_p=1.0)
+                                                 top_k=50, top_p=1.0)          # HF GenerationConfig defaults
 
     # ------------------------------------------------------------------ construction
     @classmethod
@@ -162,7 +162,9 @@ class PaDTForConditionalGeneration:
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
                  max_new_tokens=1024, do_sample=None, output_hidden_states=True, return_dict_in_generate=True,
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
-                 use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None, **unused):
+                 use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None,
+                 temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
+                 seed: Optional[int] = None, **unused):
         """Greedy generation over the unified text‖VRT vocabulary.
 
         ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
@@ -172,16 +174,20 @@ class PaDTForConditionalGeneration:
         ``repetition_penalty`` / ``eos_token_id`` (int or list) / ``do_sample``: default to the checkpoint's
         generation_config.json (self.generation_config), exactly the entries HF's generate turns into a logits processor /
         stopping criterion / sampling switch (padt.py:436,570-580,740-743); explicit arguments override.
+        ``do_sample=True``: multinomial sampling after HF's Temperature → TopK → TopP warpers (``temperature`` / ``top_k`` /
+        ``top_p``, defaults from generation_config, HF's own defaults 1.0 / 50 / 1.0) on a device counter-based generator keyed
+        by ``seed`` (default: drawn from torch's global generator, so torch.manual_seed makes runs repeatable).  The draws are
+        not torch.multinomial's; the distribution is.
         """
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
                                    schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
-                                   eos_token_id=eos_token_id)
+                                   eos_token_id=eos_token_id, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
         return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate)
 
     @torch.no_grad()
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=None,
                         schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
-                        repetition_penalty=None, eos_token_id=None):
+                        repetition_penalty=None, eos_token_id=None, temperature=None, top_k=None, top_p=None, seed=None):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -196,8 +202,18 @@ class PaDTForConditionalGeneration:
         gc = self.generation_config
         do_sample = gc.do_sample if do_sample is None else do_sample
         repetition_penalty = gc.repetition_penalty if repetition_penalty is None else repetition_penalty
+        temperature = gc.temperature if temperature is None else float(temperature)
+        top_k = gc.top_k if top_k is None else int(top_k)
+        top_p = gc.top_p if top_p is None else float(top_p)
+        if do_sample and top_k == 1:
+            do_sample = False                                     # sampling among the single best token IS the arg-max
         if do_sample:
-            raise NotImplementedError("sampling (padt.py:740-743) is not on the accelerated path; use do_sample=False")
+            if temperature <= 0:
+                raise ValueError("temperature must be strictly positive (HF TemperatureLogitsWarper)")
+            if top_p < 1.0 and not (0 < top_k <= 1024):
+                raise NotImplementedError("top_p < 1 is supported together with 0 < top_k <= 1024 (the nucleus is taken over the top-k survivors)")
+            if seed is None:
+                seed = int(torch.randint(0, 2 ** 31 - 1, (1,)).item())
         if pixel_values is None or image_grid_thw is None:
             raise ValueError("pixel_values and image_grid_thw are required (text-only input crashes in the reference too, "
                              "padt.py:292 with image_prototypes unbound)")
@@ -205,7 +221,8 @@ class PaDTForConditionalGeneration:
         eos_list = list(gc.eos_token_id) if eos_token_id is None else ([int(eos_token_id)] if isinstance(eos_token_id, int) else [int(e) for e in eos_token_id])
         if cfg.eos_token_id not in eos_list or len(eos_list) > 4:
             raise NotImplementedError("eos_token_id must contain config.eos_token_id and hold at most 4 ids")
-        gen_key = (float(repetition_penalty), tuple(eos_list))
+        samp = (float(temperature), int(top_k), float(top_p), int(seed)) if do_sample else None
+        gen_key = (float(repetition_penalty), tuple(eos_list), samp)
         grid = image_grid_thw.detach().cpu().long()
         B = input_ids.shape[0]
         T_max = int(max_new_tokens)
@@ -220,7 +237,10 @@ class PaDTForConditionalGeneration:
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
                          use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule,
                          gen_key=gen_key, eos_list=eos_list)
-            sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu").to(dev, non_blocking=True))
+            sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu", do_sample=samp is not None, seed=samp[3] if samp else 0,
+                                                  temperature=samp[0] if samp else 1.0, top_k=samp[1] if samp else 0,
+                                                  top_p=samp[2] if samp else 1.0).to(dev, non_blocking=True))
+            sess.do_sample = samp is not None
             if gen_key[0] != 1.0:
                 sess.seen.zero_()
             # neutral state for every row; the batches overwrite their own rows (unused rows stay finished / empty)

@@ -318,12 +318,21 @@ def seen_init(ids, rows, seen):
     _lib.check(_lib.load().padt_seen_init(_stream(), _p(ids), _p(rows), ids.numel(), _p(seen), seen.shape[1]), "padt_seen_init")
 
 
-def gen_cfg_tensor(repetition_penalty=1.0, eos_ids=(), device="cuda"):
-    """Device copy of the generation-config slots the head / greedy kernels read: {float penalty; int eos[4]; int pad[3]}."""
+def gen_cfg_tensor(repetition_penalty=1.0, eos_ids=(), device="cuda", do_sample=False, seed=0, temperature=1.0, top_k=0, top_p=1.0):
+    """Device copy of the generation-config slots the head / greedy / sampling kernels read:
+    {float penalty; int eos[4]; int do_sample; unsigned seed; float temperature; int top_k; float top_p; int pad[2]}."""
     import struct
     eos = list(eos_ids)[:4] + [-1] * (4 - min(4, len(eos_ids)))
-    raw = struct.pack("<f7i", float(repetition_penalty), *eos, 0, 0, 0)
+    raw = struct.pack("<f4iiIfifii", float(repetition_penalty), *eos, 1 if do_sample else 0, int(seed) & 0xFFFFFFFF, float(temperature),
+                      int(top_k), float(top_p), 0, 0)
     return torch.frombuffer(bytearray(raw), dtype=torch.int32).clone().to(device)
+
+
+def sample_token(logits, n_rows_table, gen_cfg, step, part_val, part_idx, batch):
+    """One multinomial draw per row from the warped fp32 logits (padt_sample_token) into the (value, index) partial layout."""
+    assert logits.dtype == torch.float32 and logits.stride(-1) == 1
+    _lib.check(_lib.load().padt_sample_token(_stream(), _p(logits), logits.stride(0), int(n_rows_table), _p(gen_cfg), _p(step), _p(part_val),
+                                             _p(part_idx), int(batch)), "padt_sample_token")
 
 
 def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens_out, cur_tok, step, slot, lens, pos3,

@@ -78,7 +78,7 @@ class PipelinedRunner:
         self.pending.append(g)
 
     def submit(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, schedule=None,
-               need_thinking_mask=None, sync_every=None, repetition_penalty=None, eos_token_id=None):
+               need_thinking_mask=None, sync_every=None, repetition_penalty=None, eos_token_id=None, **sampling):
         done = []
         bid = self.n_batches
         self.n_batches += 1
@@ -106,7 +106,7 @@ class PipelinedRunner:
                 ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
                                                  sched, sync_every or max_new_tokens, True, g["lane"],
                                                  self.decode_streams[g["lane"]], group=g["ctx"], n_slots=self.merge,
-                                                 repetition_penalty=repetition_penalty, eos_token_id=eos_token_id)
+                                                 repetition_penalty=repetition_penalty, eos_token_id=eos_token_id, **sampling)
             if ctx is not None:
                 break
             self._close_cur()                                     # batch does not fit this group's session: start a new one

@@ -506,3 +506,40 @@ def test_ovd_shaped_completion_through_the_runner(setup):
         db = (decoded["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
         mx, rms = rel_err(decoded["pred_mask"], odec["pred_mask"])
         assert db < 5e-3 and rms < 3e-2, f"OVD e2e: box {db:.3e} mask rms {rms:.3e}"
+
+
+def test_generate_with_sampling(setup):
+    """do_sample=True through generate(): repeatable for a seed (eager == hipGraph), different seeds differ, every drawn token lies in
+    the oracle's top-k of that step under teacher forcing (up to the bf16 noise floor at the k-th boundary), top_k=1 degenerates to
+    the greedy path, generation_config defaults are picked up."""
+    cfg, w, model, U, oc = setup
+    O = U.O
+    grids = [[1, 8, 8], [1, 10, 12]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=5, n_post=8, ragged=True, seed=31)
+    T, K = 10, 5
+    sched = ["t"] * T
+    sched[-1] = "e"
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    a = model.generate(do_sample=True, top_k=K, temperature=1.5, seed=11, **kw)
+    b = model.generate(do_sample=True, top_k=K, temperature=1.5, seed=11, use_graph=False, **kw)
+    c = model.generate(do_sample=True, top_k=K, temperature=1.5, seed=12, **kw)
+    assert torch.equal(a.sequences, b.sequences) and not torch.equal(a.sequences, c.sequences)
+    L = ids.shape[1]
+    toks = a.sequences.cpu()[:, L:]
+    ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    for t in range(T - 1):
+        lg = ores["logits"][t]
+        kth = lg.topk(K, dim=-1).values[:, -1]
+        floor = 2e-2 * lg[torch.isfinite(lg)].abs().max().item()
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        assert bool((chosen >= kth - floor).all()), f"step {t}: a drawn token is outside the oracle's top-{K}"
+    greedy = model.generate(do_sample=False, **kw)
+    assert torch.equal(model.generate(do_sample=True, top_k=1, **kw).sequences, greedy.sequences)
+    assert not torch.equal(a.sequences, greedy.sequences)
+    model.load_generation_config({"do_sample": True, "top_k": 1, "temperature": 0.1, "top_p": 0.001, "repetition_penalty": 1.0})
+    try:
+        assert torch.equal(model.generate(**kw).sequences, greedy.sequences)           # Qwen2.5-VL's shipped config: top_k = 1 → greedy
+    finally:
+        model.load_generation_config({"do_sample": False, "top_k": 50, "temperature": 1.0, "top_p": 1.0})
+    with pytest.raises(NotImplementedError):
+        model.generate(do_sample=True, top_k=0, top_p=0.9, **kw)

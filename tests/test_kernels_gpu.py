@@ -766,3 +766,53 @@ def test_gpu_resize_is_byte_exact_with_pillow_and_front_end_matches_pil_path(ops
     if "raw0" in z.files:
         pix, grid = fe([z["raw0"], z["raw1"]])
         assert torch.equal(pix.cpu(), torch.from_numpy(z["pix_raw"])) and grid.tolist() == z["grid_raw"].tolist()
+
+
+@pytest.mark.parametrize("T,top_k,top_p", [(1.0, 0, 1.0), (0.7, 40, 1.0), (1.3, 50, 0.9), (1.0, 3, 0.5)])
+def test_sample_token_distribution(ops, T, top_k, top_p):
+    """Sampling branch (padt.py:740-743 + HF warpers): the device draws are not torch.multinomial's, so the test is distribution-level —
+    131 072 draws from one logit row; support == the oracle's warped support exactly (top-k ties and the nucleus rule included),
+    empirical frequencies within 5 sigma of softmax(warped) on every kept token."""
+    import padt_oracle as O
+    n, B, reps = 3000, 64, 2048
+    g = torch.Generator().manual_seed(7)
+    row = torch.randn(n, generator=g) * 2.0
+    row[100] = row[7]                                             # a tie inside the interesting range
+    row[5] = float("-inf")                                        # masked rows stay impossible
+    logits = row[None, :].repeat(B, 1).cuda()
+    exp = O.warp_logits(row[None, :], T, top_k, top_p)[0]
+    p_ref = exp.softmax(-1)
+    counts = torch.zeros(n, dtype=torch.long, device="cuda")
+    pv = torch.zeros(B, device="cuda")
+    pi = torch.zeros(B, dtype=torch.int32, device="cuda")
+    cfg = ops.gen_cfg_tensor(1.0, (), "cuda", do_sample=True, seed=1234, temperature=T, top_k=top_k, top_p=top_p)
+    step = torch.zeros(1, dtype=torch.int32, device="cuda")
+    for r in range(reps):
+        step.fill_(r)
+        ops.sample_token(logits, n, cfg, step, pv, pi, B)
+        counts += torch.bincount(pi.long(), minlength=n)
+    N = B * reps
+    freq = counts.cpu().double() / N
+    kept = torch.isfinite(exp)
+    assert int(counts.cpu()[~kept].sum()) == 0, "a token outside the warped support was drawn"
+    pr = p_ref.double()
+    common = kept & (pr * N >= 50)                                # normal approximation holds: per-token 5-sigma test
+    sigma = (pr * (1 - pr) / N).sqrt()
+    dev = ((freq - pr).abs() / (sigma + 1e-12))[common]
+    assert dev.max().item() < 5.0, f"worst deviation {dev.max().item():.2f} sigma"
+    rare = kept & ~common                                         # rare tokens: their total mass, same bound
+    if bool(rare.any()):
+        pm, fm = pr[rare].sum().item(), freq[rare].sum().item()
+        assert abs(fm - pm) < 5.0 * math.sqrt(pm * (1 - pm) / N) + 1e-9, f"rare-token mass {fm:.5f} vs {pm:.5f}"
+    if top_k == 0:
+        assert int((counts > 0).sum()) > 500                      # the tail is really sampled
+    # same (seed, step) → same draw; another seed → another sequence of draws
+    step.fill_(3)
+    ops.sample_token(logits, n, cfg, step, pv, pi, B)
+    a = pi.clone()
+    ops.sample_token(logits, n, cfg, step, pv, pi, B)
+    assert torch.equal(a, pi)
+    cfg2 = ops.gen_cfg_tensor(1.0, (), "cuda", do_sample=True, seed=99, temperature=T, top_k=top_k, top_p=top_p)
+    ops.sample_token(logits, n, cfg2, step, pv, pi, B)
+    if top_k != 3:
+        assert not torch.equal(a, pi)
