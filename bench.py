@@ -61,8 +61,11 @@ def parse_args():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--tnew", type=int, default=28)
     ap.add_argument("--model", default="3b", choices=["3b", "7b", "small"])
-    ap.add_argument("--task", default="rec", choices=["rec", "ovd"], help="rec: BASELINE configs[1] (L=577, T=28, 1 object x 5 VRT); "
-                    "ovd: BASELINE configs[3] shape per GPU (80-class prompt L=890, T=120, 7 objects x 5 VRT per image)")
+    ap.add_argument("--task", default="rec", choices=["rec", "ovd", "ric"], help="rec: BASELINE configs[1] (L=577, T=28, 1 object x 5 VRT); "
+                    "ovd: BASELINE configs[3] shape per GPU (80-class prompt L=890, T=120, 7 objects x 5 VRT per image); "
+                    "ric: BASELINE configs[4] shape (caption with interleaved VRT runs: T=150, 6 runs x 5 VRT)")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8: LLM projection weights as OCP e4m3 + power-of-two "
+                    "row scales for the decode steps (BASELINE configs[4], 7B fp8 weight path)")
     ap.add_argument("--cap", type=int, default=0, help="object capacity of the per-batch result record (default: 2 x the scheduled objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -83,7 +86,7 @@ def build_model(args, device):
     from padt_amd.modeling import PaDTForConditionalGeneration
     cfg = {"3b": padt_amd.padt_pro_3b, "7b": padt_amd.padt_pro_7b, "small": padt_amd.small_test_config}[args.model]()
     grid_hw = (10, 12) if args.model == "small" else (46, 46)
-    model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device)
+    model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device, llm_weights=args.weights)
     return cfg, model, grid_hw
 
 
@@ -93,6 +96,9 @@ def workload(args):
     if args.task == "ovd":
         T = args.tnew if args.tnew != 28 else 120
         return 346, T, 7, 5, multi_object_schedule(T, n_obj=7, n_vrt=5)
+    if args.task == "ric":
+        T = args.tnew if args.tnew != 28 else 150
+        return 33, T, 6, 5, multi_object_schedule(T, n_obj=6, n_vrt=5)
     T = args.tnew
     if T >= 17:
         return 33, T, 1, 5, rec_schedule(T, range(11, 16))
@@ -425,11 +431,12 @@ def main():
         n_img = args.batch * args.steps * world
         value = n_img / elapsed
         alg_tf = alg_tflop_per_image(cfg, inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
-        wl = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 (split-precision "
-              "PaDT decoder), random-init weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps "
-              "of %d consecutive batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)"
-              % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
-                 args.batch, grid_hw[0], grid_hw[1], inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], args.batch, args.merge))
+        fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 (split-precision "
+               "PaDT decoder" + (", fp8 e4m3 LLM weights in the decode steps" if args.weights == "fp8" else "") + "), random-init weights; "
+               "batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps of %d consecutive batches share one "
+               "weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
+        wl = fmt % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
+                    args.batch, grid_hw[0], grid_hw[1], inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], args.batch, args.merge)
         line = {
             "metric": "images/sec PaDT_Pro_3B REC inference, 1/2/4/8 MI355X; box IoU vs ref",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,

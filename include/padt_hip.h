@@ -74,6 +74,14 @@ int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp,
                           long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
                           int split_k, void* workspace, int act_packed);
 int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long ld_dst, long M, long K, int to_packed);
+/* padt_gemm_packed_bf16 over FP8 weights (BASELINE configs[4]: PaDT_Pro_7B, "fp8 MFMA weight path"): Wq = OCP e4m3 bytes stored
+ * [N/16][Kp/64][64 lanes][16 B] — a lane's 16 bytes = its 8 elements of K-step 2t followed by its 8 elements of K-step 2t+1, so one
+ * 1-KiB wave load feeds two 16x16x32 MFMA K-steps and the decode step streams half the weight bytes; bytes are converted to bf16
+ * fragments in registers (exact), fp32 accumulation, scales fp32 [N] (one per weight row) applied to the accumulator before the
+ * bias: C = epi(rstd?(A) * scale[n] * (A · Wq^T) + bias).  Kp % 64 == 0, N % 16 == 0.  HF:727-757 at T = 1 with W ≈ scale * Wq. */
+int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias, void* C,
+                         long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps, int split_k,
+                         void* workspace, int act_packed);
 
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.

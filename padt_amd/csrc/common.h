@@ -29,6 +29,15 @@ PADT_DEV bf16x8 zero_frag() {
     return __builtin_bit_cast(bf16x8, z);
 }
 
+// 8 OCP e4m3 bytes (two dwords, element j = byte j) → one bf16 MFMA fragment; exact (e4m3 ⊂ bf16): v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+PADT_DEV bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
+    const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
+    const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
+    const u32x4 r = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c[0], c[1]), pack2bf(d[0], d[1])};
+    return __builtin_bit_cast(bf16x8, r);
+}
+
 PADT_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
 // Cross-block hand-off inside one kernel (split-K / split-KV "last block reduces"): the 8 XCDs have separate L2s, so

@@ -35,6 +35,7 @@ struct GemmArgs {
     RopeEpi rope = {nullptr, nullptr, 0, 0, 0};   // optional fused RoPE of the leading output columns (EPI_NONE only)
     int a_pack = 0;              // skinny kernel: A / (C and R) stored in the 16-row fragment-packed activation layout
     int c_pack = 0;              //   element (m, k) at (m/16)*16*ld + ((k/8)*16 + m%16)*8 + k%8   (see padt_hip.h)
+    const float* cs = nullptr;   // optional per-output-column scale applied to the accumulator before bias (fp8 weights: dequantisation scale of weight row n)
     int r_f32 = 0;               // EPI_RESID: R is fp32 [M][ldr] (fp32 residual stream; with OUT_F32)
     long lo_off = 0;             // bf16 output: also store lo = bf16(x - hi) at C + lo_off (split-precision pair, padt_gemm_bf16_ex)
 };
@@ -74,6 +75,10 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         const float sc = p.rs[m];
 #pragma unroll
         for (int r = 0; r < 4; ++r) o[r] *= sc;
+    }
+    if (p.cs) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o[r] *= (n + r < p.N) ? p.cs[n + r] : 1.f;
     }
     if (n + 3 < p.N) {                                   // full fragment: 8-byte bias / residual loads, one vector store
         const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
@@ -138,8 +143,10 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     unpack4(*reinterpret_cast<const u32x2*>(bp + 16), ub);
     float o[4];
     const float sc = p.rs ? p.rs[m] : 1.0f;
+    f32x4 gs = f32x4{1.f, 1.f, 1.f, 1.f}, us = gs;
+    if (p.cs) { gs = *reinterpret_cast<const f32x4*>(p.cs + n_gate); us = *reinterpret_cast<const f32x4*>(p.cs + n_gate + 16); }
 #pragma unroll
-    for (int r = 0; r < 4; ++r) o[r] = silu(g[r] * sc + gb[r]) * (u[r] * sc + ub[r]);
+    for (int r = 0; r < 4; ++r) o[r] = silu(g[r] * sc * gs[r] + gb[r]) * (u[r] * sc * us[r] + ub[r]);
     bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
     *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
 }
@@ -238,7 +245,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 
     // epilogue: acc[mi][ni][r] = C[m0 + wm*64 + mi*16 + (lane&15)][n0 + wn*64 + ni*16 + (lane>>4)*4 + r]
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (interior && EPI != EPI_SWIGLU && !p.r_f32 && !p.lo_off) {
+    if (interior && EPI != EPI_SWIGLU && !p.r_f32 && !p.lo_off && !p.cs) {
         // block-uniform fast path: no per-fragment bounds checks; every bias / residual load is issued up front
         const int mb = m0 + wm * 64 + frow, nb = n0 + wn * 64 + fq * 4;
         u32x2 braw[4], rraw[4][4];
@@ -307,7 +314,10 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 //   y = (x * rsqrt(mean(x^2)+eps) * g) @ W^T  ==  rstd[m] * (x @ (W·diag(g))^T)[m]  — the norm weight g is folded into the
 //   weight matrix once at load time (weights.py), the per-row sum of squares is accumulated from the x fragments the
 //   MFMA consumes anyway, and rstd scales the fp32 accumulator.
-template <int MT, int NT, int NW, int EPI, bool OUT_F32, bool NORM, bool PACKED>
+// WQ = 1: fp8 weights (OCP e4m3, per-output-row scale in p.cs) in the fp8 fragment-packed image [N/16][Kp/64][64 lanes][16 B]: a lane's
+//   16 bytes hold its 8 elements of K-step 2t and its 8 elements of K-step 2t + 1 — one 1-KiB wave load feeds two MFMA K-steps, the
+//   weight stream is half the bf16 bytes; bytes are converted to bf16 fragments in registers (exact), accumulation stays fp32.
+template <int MT, int NT, int NW, int EPI, bool OUT_F32, bool NORM, bool PACKED, int WQ = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float norm_eps) {
     __shared__ __attribute__((aligned(16))) float red[NW - 1][NT * MT][64][4];
     __shared__ __attribute__((aligned(16))) float red0[NT * (MT > 1 ? MT - 1 : 1)][64][4];
@@ -359,6 +369,17 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             const bool kok = (ks < nks) && (k < p.K);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
+                if (WQ) {
+                    if ((u & 1) == 0) {                           // U is even and groups start at even K-steps: one load = K-steps (ks, ks + 1)
+                        const unsigned char* wq = reinterpret_cast<const unsigned char*>(p.W) +
+                                                  (((long)(n0 / 16 + i) * (p.ldw / 64) + (ks >> 1)) * 64 + lane) * 16;
+                        u32x4 q = u32x4{0u, 0u, 0u, 0u};
+                        if (ks < nks) q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq));
+                        wf[u][i] = fp8x8_to_bf16x8(q[0], q[1]);
+                        wf[u + (U > 1 ? 1 : 0)][i] = fp8x8_to_bf16x8(q[2], q[3]);
+                    }
+                    continue;
+                }
                 // PACKED: tile (n16, k32) of the fragment-packed image is 1 KiB in lane order → one contiguous wave load
                 const bf16_t* wp = PACKED ? p.W + ((long)(n0 / 16 + i) * (p.ldw / 32) + ks) * 512 + lane * 8 : wrow[i] + k;
                 wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp)) : zero_frag();
@@ -496,26 +517,26 @@ static void launch_tile(const GemmArgs& a, hipStream_t s) {
     else launch_tile_bk<EPI, F32, 64>(a, s);
 }
 
-template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false>
+template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false, int WQ = 0>
 static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int split = (a.ws && !NORM) ? a.split : 1;
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED>), dim3(nb, split), dim3(NW * 64), 0, s, a, eps);
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>), dim3(nb, split), dim3(NW * 64), 0, s, a, eps);
 }
 
 // waves per block: enough waves chip-wide (>= ~2048) to keep HBM busy even when N/16 < #CUs
-template <int MT, int EPI, bool F32, bool NORM, bool PACKED = false>
+template <int MT, int EPI, bool F32, bool NORM, bool PACKED = false, int WQ = 0>
 static void launch_skinny(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = (a.K + 31) / 32 / (a.ws ? a.split : 1);   // per block; each wave keeps U = 8 K-steps in flight
     static const int force_nw = getenv("PADT_SKINNY_NW") ? atoi(getenv("PADT_SKINNY_NW")) : 0;   // tuning knob
     if constexpr (MT == 1 && NT == 1) {
-        if (force_nw == 16 || (!force_nw && nb <= 256 && ksteps >= 128)) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED>(a, eps, s); return; }
+        if (force_nw == 16 || (!force_nw && nb <= 256 && ksteps >= 128)) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED, WQ>(a, eps, s); return; }
     }
-    if (force_nw == 8 || (!force_nw && nb <= 512 && ksteps >= 64)) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED>(a, eps, s);
-    else launch_skinny_nw<MT, 4, EPI, F32, NORM, PACKED>(a, eps, s);
+    if (force_nw == 8 || (!force_nw && nb <= 512 && ksteps >= 64)) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
+    else launch_skinny_nw<MT, 4, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
 }
 
 template <int EPI, bool F32>
@@ -652,11 +673,11 @@ extern "C" int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, flo
 }
 
 // Same kernel over the fragment-packed weight image (see include/padt_hip.h): the decode step's projections.
-template <int EPI, bool NORM>
+template <int EPI, bool NORM, int WQ = 0>
 static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
-    if (a.M <= 16) launch_skinny<1, EPI, false, NORM, true>(a, eps, s);
-    else if (a.M <= 32) launch_skinny<2, EPI, false, NORM, true>(a, eps, s);
-    else launch_skinny<4, EPI, false, NORM, true>(a, eps, s);
+    if (a.M <= 16) launch_skinny<1, EPI, false, NORM, true, WQ>(a, eps, s);
+    else if (a.M <= 32) launch_skinny<2, EPI, false, NORM, true, WQ>(a, eps, s);
+    else launch_skinny<4, EPI, false, NORM, true, WQ>(a, eps, s);
 }
 
 static long splitk_ticket_bytes(long N) { return (((N + 15) / 16 * 4 + 255) / 256) * 256; }
@@ -665,10 +686,14 @@ extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
     return splitk_ticket_bytes(N) + (N + 15) / 16 * (long)split_k * 4 * 64 * 16;   // up to 4 row blocks of fp32 fragments
 }
 
-extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
-                                     long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
-                                     int split_k, void* workspace, int act_packed) {
+static int gemm_packed_impl(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
+                            long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
+                            int split_k, void* workspace, int act_packed, const float* wscale) {
     if (M <= 0 || N <= 0) return 0;
+    if (wscale && ((Kp & 63) || (N & 15) || ((uintptr_t)wscale & 15))) {
+        padt_set_error("padt_gemm_packed_fp8: Kp % 64 == 0, N % 16 == 0 and 16-byte aligned scales required");
+        return -1;
+    }
     if ((act_packed & ~3) || ((act_packed & 1) && (lda & 7)) || ((act_packed & 2) && ((ldc & 7) || (R != nullptr && ldr != ldc)))) {
         padt_set_error("padt_gemm_packed_bf16: act_packed bit 0 = A packed (lda % 8), bit 1 = C and R packed (ldc % 8, ldr == ldc)");
         return -1;
@@ -696,10 +721,32 @@ extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, cons
         a.split = split_k;
     }
     hipStream_t s = (hipStream_t)stream;
-    if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false>(a, 0.f, s); }
+    if (wscale) {
+        a.cs = wscale;
+        if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true, 1>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false, 1>(a, 0.f, s); }
+        else if (epilogue == EPI_RESID) dispatch_packed<EPI_RESID, false, 1>(a, 0.f, s);
+        else { if (norm) dispatch_packed<EPI_NONE, true, 1>(a, norm_eps, s); else dispatch_packed<EPI_NONE, false, 1>(a, 0.f, s); }
+    } else if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false>(a, 0.f, s); }
     else if (epilogue == EPI_RESID) dispatch_packed<EPI_RESID, false>(a, 0.f, s);
     else { if (norm) dispatch_packed<EPI_NONE, true>(a, norm_eps, s); else dispatch_packed<EPI_NONE, false>(a, 0.f, s); }
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;
+}
+
+extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
+                                     long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
+                                     int split_k, void* workspace, int act_packed) {
+    return gemm_packed_impl(stream, A, lda, Wp, Kp, bias, C, ldc, R, ldr, M, N, K, epilogue, norm_eps, split_k, workspace, act_packed, nullptr);
+}
+
+// Same decode-step projection over fp8 weights (BASELINE configs[4], the 7B "fp8 MFMA weight path"): Wq = OCP e4m3 bytes in the fp8
+// fragment-packed image [N/16][Kp/64][64 lanes][16 B] (ops.pack_weight_fp8), scales fp32 [N] (one per weight row; powers of two in
+// weights.py, so the bf16 prefill copy of the same matrix is bit-consistent).  C = epi(rstd?(A) * scale[n] * (A · Wq^T) + bias).
+extern "C" int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias,
+                                    void* C, long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
+                                    int split_k, void* workspace, int act_packed) {
+    if (scales == nullptr) { padt_set_error("padt_gemm_packed_fp8: scales are required"); return -1; }
+    return gemm_packed_impl(stream, A, lda, Wq, Kp, bias, C, ldc, R, ldr, M, N, K, epilogue, norm_eps, split_k, workspace, act_packed,
+                            (const float*)scales);
 }

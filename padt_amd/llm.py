@@ -190,6 +190,18 @@ class DecodeSession:
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
             # 6 launches per layer: [norm+qkv] [rope+append+split attention] [merge] [o+resid] [norm+gate/up+SwiGLU] [down+resid]
+            if W.llm_weights == "fp8":                            # fp8 weight images (+ per-row scales): half the bytes per step
+                ops.gemm_packed_fp8(self.x, W[p + "qkv.wq"], W[p + "qkv.ws"], self.n_qkv, W[p + "qkv.b"], out=self.qkv,
+                                    norm_eps=cfg.rms_norm_eps, a_packed=True, rows=B)
+                ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
+                                     hd, self.s_max, self.s_max, out_packed=True)
+                ops.gemm_packed_fp8(self.att, W[p + "o.wq"], W[p + "o.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                    split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+                ops.gemm_packed_fp8(self.x, W[p + "gu.wq"], W[p + "gu.ws"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU,
+                                    norm_eps=cfg.rms_norm_eps, a_packed=True, c_packed=True, rows=B)
+                ops.gemm_packed_fp8(self.h, W[p + "down.wq"], W[p + "down.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                    split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+                continue
             ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps,
                             a_packed=True, rows=B)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,

@@ -86,14 +86,14 @@ class CustomGenerateDecoderOnlyOutput(dict):
 
 
 class PaDTForConditionalGeneration:
-    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16):
+    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16"):
         if dtype != torch.bfloat16:
             raise ValueError("the MI355X path computes in bf16 (fp32 accumulate); pass torch_dtype=torch.bfloat16")
         _lib.load()                                            # fail loudly before touching any weight
         self.config = config
         self.device = torch.device(device)
         self.dtype = dtype
-        self.W = prepare_weights(state_dict, config, self.device)
+        self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights)
         self.visual = VisionEncoder(config, self.W, self.device)
         self.lm = LanguageModel(config, self.W, self.device)
         self.vl_decoder = PaDTDecoder(config, self.W, self.device, dtype)
@@ -109,7 +109,7 @@ class PaDTForConditionalGeneration:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.bfloat16, attn_implementation=None,
-                        device_map=None, config=None, **_):
+                        device_map=None, config=None, llm_weights: str = "bf16", **_):
         """Loads ``config.json`` + ``*.safetensors`` (checkpoint key layout of PaDT-MLLM/PaDT_*).  ``attn_implementation``
         is accepted and ignored: attention is always the HIP flash kernel."""
         path = str(pretrained_model_name_or_path)
@@ -125,7 +125,7 @@ class PaDTForConditionalGeneration:
             device = f"cuda:{d}" if isinstance(d, int) else str(d)
         elif isinstance(device_map, (str, torch.device)):
             device = str(device_map)
-        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype)
+        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights)
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             model.load_generation_config(json.load(open(gpath)))
@@ -150,9 +150,10 @@ class PaDTForConditionalGeneration:
     @classmethod
     def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
         """Random-init weights of the given architecture (no checkpoints offline)."""
+        kw_llm = kw.pop("llm_weights", "bf16")
         sd = state_dict if state_dict is not None else synthetic_state_dict(config, seed=seed, device=device,
                                                                             dtype=torch.bfloat16, **kw)
-        return cls(config, sd, device=device)
+        return cls(config, sd, device=device, llm_weights=kw_llm)
 
     def eval(self):
         return self

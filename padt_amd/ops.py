@@ -97,6 +97,49 @@ def pack_weight(w):
     return w.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np, Kp)
 
 
+def quantize_fp8_rows(w):
+    """Per-output-row fp8 quantisation with POWER-OF-TWO scales: → (wq uint8 OCP e4m3 bits [N][K], scale fp32 [N], w_deq bf16 [N][K]).
+    scale[n] = 2^ceil(log2(max|w[n]| / 448)); e4m3 x 2^k is exactly representable in bf16, so w_deq (what prefill multiplies with and
+    what the oracle sees) and scale * wq (what the decode kernel computes) are the same numbers, bit for bit."""
+    wf = w.float()
+    amax = wf.abs().amax(dim=1).clamp_min(1e-30)
+    scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
+    q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
+    deq = (q.float() * scale[:, None]).to(BF16)
+    return q.view(torch.uint8), scale.contiguous(), deq
+
+
+def pack_weight_fp8(wq):
+    """uint8 e4m3 [N][K] → fp8 fragment-packed image [N/16][K/64][64 lanes][16 B] (N, K zero-padded to 16 / 64): lane fq*16 + frow holds
+    row n16*16 + frow, k = kp*64 + half*32 + fq*8 + e at byte half*8 + e."""
+    N, K = wq.shape
+    Np, Kp = (N + 15) // 16 * 16, (K + 63) // 64 * 64
+    if (Np, Kp) != (N, K):
+        t = wq.new_zeros((Np, Kp))
+        t[:N, :K] = wq
+        wq = t
+    return wq.view(Np // 16, 16, Kp // 64, 2, 4, 8).permute(0, 2, 4, 1, 3, 5).contiguous().view(Np, Kp)
+
+
+def gemm_packed_fp8(a, wq_packed, scales, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None,
+                    a_packed=False, c_packed=False, rows=None):
+    """gemm_packed over fp8 weights: out = epi(rstd?(a) * scales[n] * (a @ wq^T) + bias)."""
+    lib = _lib.load()
+    _chk_bf16(a, bias, residual)
+    assert wq_packed.dtype == torch.uint8 and scales.dtype == torch.float32 and scales.is_contiguous()
+    M, K = a.shape
+    if rows is not None:
+        M = rows
+    n_out = n // 2 if epilogue == EPI_SWIGLU else n
+    if out is None:
+        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
+    _lib.check(lib.padt_gemm_packed_fp8(_stream(), _p(a), a.stride(0), _p(wq_packed), wq_packed.shape[1], _p(scales), _p(bias), _p(out),
+                                        out.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
+                                        -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace),
+                                        (1 if a_packed else 0) | (2 if c_packed else 0)), "padt_gemm_packed_fp8")
+    return out
+
+
 def new_splitk_workspace(n, split_k, device):
     """Zero-initialised split-K workspace (ticket header must start at zero), one per concurrently decoding stream."""
     return torch.zeros(_lib.load().padt_gemm_splitk_workspace(n, split_k), dtype=torch.uint8, device=device)

@@ -203,11 +203,18 @@ class PreparedWeights(dict):
     llm_ipad: int
     dec_ipad: int
     dec_hp: bool = False
+    llm_weights: str = "bf16"
 
 
-def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda") -> PreparedWeights:
+def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16") -> PreparedWeights:
+    """llm_weights = "fp8": the LLM's projection matrices (after the norm folding) are quantised per output row to OCP e4m3 with
+    power-of-two scales (ops.quantize_fp8_rows); the decode step streams the fp8 images (half the bytes), prefill multiplies with the
+    bf16 image of the SAME numbers (scale * q is exact in bf16) — BASELINE configs[4], the 7B "fp8 MFMA weight path"."""
+    if llm_weights not in ("bf16", "fp8"):
+        raise ValueError("llm_weights must be 'bf16' or 'fp8'")
     dev = torch.device(device)
     W = PreparedWeights()
+    W.llm_weights = llm_weights
 
     def put(name, t):
         W[name] = t.to(device=dev, dtype=BF16).contiguous()
@@ -269,11 +276,17 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda")
         put(d + "down.w", _pad_cols(get(s + "mlp.down_proj.weight"), li_pad))
     # decode-step copies of the LLM matrices in MFMA-fragment order (ops.pack_weight): the single-token GEMVs stream
     # them with fully coalesced 1 KiB wave loads.  +5.5 GB for PaDT_Pro_3B — HBM capacity is not the constraint here.
-    from .ops import pack_weight
+    from .ops import pack_weight, pack_weight_fp8, quantize_fp8_rows
     for i in range(cfg.num_hidden_layers):
         d = f"llm.{i}."
         for nm in ("qkv", "o", "gu", "down"):
-            W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
+            if llm_weights == "fp8":
+                q, sc, deq = quantize_fp8_rows(W[d + nm + ".w"])
+                W[d + nm + ".w"] = deq                           # prefill: bf16 image of the quantised matrix (exact)
+                W[d + nm + ".wq"] = pack_weight_fp8(q)           # decode: fp8 fragment-packed image + per-row scales
+                W[d + nm + ".ws"] = sc
+            else:
+                W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
     # fragment-packed copy of the head table for the decode-step logit head (+0.62 GB at 3B; the row-major table stays: it is
     # the embedding table too, and the prefill-side gathers read rows)
     if cfg.vocab_size % 16 == 0 and cfg.hidden_size % 32 == 0 and os.environ.get("PADT_HEAD_PACKED", "1") != "0":

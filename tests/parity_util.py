@@ -39,3 +39,28 @@ def bf16_weights(cfg: PaDTConfig, seed=0, std=0.02, bias_std=0.02, norm_jitter=0
 
 
 from padt_amd.synthetic import FakeProcessor, FakeTokenizer, rec_schedule, synthetic_batch  # noqa: E402,F401
+
+
+def effective_llm_weights(model, w):
+    """Oracle weights for a model built with llm_weights="fp8": the reference-layout fp32 dict `w` with the LLM projections replaced by
+    the DEQUANTISED matrices the HIP path multiplies with (prepare_weights keeps them as bf16 images: scale * q is exact), un-fused
+    (q | k | v), un-interleaved and un-padded (gate / up), with the RMSNorm weights they were folded with set to one — the same
+    function of the input, parameterised the way the reference's modules are."""
+    cfg, W = model.config, model.W
+    hd, Hq, Hkv, I = cfg.head_dim, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size
+    out = dict(w)
+    for i in range(cfg.num_hidden_layers):
+        s, d = f"model.layers.{i}.", f"llm.{i}."
+        qkv = W[d + "qkv.w"].float().cpu()
+        out[s + "self_attn.q_proj.weight"] = qkv[: Hq * hd]
+        out[s + "self_attn.k_proj.weight"] = qkv[Hq * hd: (Hq + Hkv) * hd]
+        out[s + "self_attn.v_proj.weight"] = qkv[(Hq + Hkv) * hd:]
+        out[s + "self_attn.o_proj.weight"] = W[d + "o.w"].float().cpu()
+        gu = W[d + "gu.w"].float().cpu()
+        gu = gu.view(gu.shape[0] // 32, 2, 16, gu.shape[1])
+        out[s + "mlp.gate_proj.weight"] = gu[:, 0].reshape(-1, gu.shape[-1])[:I]
+        out[s + "mlp.up_proj.weight"] = gu[:, 1].reshape(-1, gu.shape[-1])[:I]
+        out[s + "mlp.down_proj.weight"] = W[d + "down.w"].float().cpu()[:, :I]
+        out[s + "input_layernorm.weight"] = torch.ones_like(w[s + "input_layernorm.weight"])
+        out[s + "post_attention_layernorm.weight"] = torch.ones_like(w[s + "post_attention_layernorm.weight"])
+    return out

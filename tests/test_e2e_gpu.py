@@ -543,3 +543,55 @@ def test_generate_with_sampling(setup):
         model.load_generation_config({"do_sample": False, "top_k": 50, "temperature": 1.0, "top_p": 1.0})
     with pytest.raises(NotImplementedError):
         model.generate(do_sample=True, top_k=0, top_p=0.9, **kw)
+
+
+def test_fp8_llm_weights_against_oracle_on_dequantised_weights():
+    """BASELINE configs[4] (PaDT_Pro_7B-style: untied head, GQA group of 2, fp8 weight path): LLM projections quantised to e4m3 with
+    power-of-two row scales; prefill multiplies the bf16 image, decode streams the fp8 image — the oracle runs the SAME dequantised
+    matrices in fp32 (parity_util.effective_llm_weights).  Ids by the margin rule, hidden rows, boxes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import dataclasses
+    import padt_amd
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    import parity_util as U
+    O = U.O
+    cfg = padt_amd.small_test_config()
+    cfg = dataclasses.replace(cfg, tie_word_embeddings=False, num_attention_heads=4, num_key_value_heads=2, hidden_size=512)
+    cfg = dataclasses.replace(cfg, vision_config=dataclasses.replace(cfg.vision_config, out_hidden_size=512))
+    w = U.bf16_weights(cfg, seed=19, std=0.05)
+    model = PaDTForConditionalGeneration(cfg, w, device="cuda", llm_weights="fp8")
+    assert model.W.llm_weights == "fp8" and "llm.0.qkv.wq" in model.W and "llm.0.qkv.wp" not in model.W
+    wo = U.effective_llm_weights(model, w)
+    oc = U.oracle_config(cfg)
+    grids = [[1, 8, 8], [1, 10, 12]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=5, n_post=8, ragged=True, seed=77)
+    T = 12
+    sched = U.rec_schedule(T, vrt_at=range(4, 8))
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T,
+                         schedule=sched)
+    L = ids.shape[1]
+    toks = out.sequences.cpu()[:, L:]
+    ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    n_tie = 0
+    for t in range(T):
+        lg = ores["logits"][t]
+        top2 = lg.topk(2, dim=-1).values
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        floor = 2e-2 * lg[torch.isfinite(lg)].abs().max().item()
+        for b in range(2):
+            second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
+            if (top2[b, 0] - second).item() > floor:
+                assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
+            else:
+                n_tie += 1
+                assert (top2[b, 0] - chosen[b]).item() <= floor
+    assert n_tie <= T
+    hid = out.hidden_states.last_layer_rows().cpu().float()
+    for t in range(T):
+        mx, rms = rel_err(hid[t], ores["hidden"][t][:, -1].float())
+        assert rms < 2e-2 and mx < 8e-2, f"hidden step {t}: rel err max {mx:.3e} rms {rms:.3e}"
+    # the quantisation itself is visible against the UN-quantised oracle (sanity: the test is not vacuous)
+    ores0 = O.generate(w, oc, ids, am, pix, grid, 1, schedule=sched)
+    _, rms0 = rel_err(hid[0], ores0["hidden"][0][:, -1].float())
+    assert rms0 > 2e-2

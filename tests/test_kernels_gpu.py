@@ -816,3 +816,43 @@ def test_sample_token_distribution(ops, T, top_k, top_p):
     ops.sample_token(logits, n, cfg2, step, pv, pi, B)
     if top_k != 3:
         assert not torch.equal(a, pi)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 2560, 2048), (1, 2048, 3584), (40, 704, 512), (64, 2048, 2080), (16, 22016, 2048), (33, 96, 256)])
+def test_gemm_packed_fp8_weights(ops, M, N, K):
+    """fp8 (OCP e4m3, power-of-two row scales) decode projections: the kernel converts the bytes to bf16 fragments in registers
+    (exact) and scales the fp32 accumulator — against fp32 statements on the DEQUANTISED matrix: same tolerance as the bf16 kernel,
+    and bit-identical to the bf16 packed kernel run on the dequantised matrix (same fragments, same accumulation order)."""
+    x = rnd(M, K, seed=81)
+    w, b, r = rnd(N, K, scale=0.05, seed=82), rnd(N, seed=83), rnd(M, N, seed=84)
+    w[3] *= 40.0                                                   # rows of very different magnitude → different scales
+    w[5] *= 0.001
+    q, sc, deq = ops.quantize_fp8_rows(w)
+    assert torch.equal((q.view(torch.float8_e4m3fn).float() * sc[:, None]).to(BF), deq)
+    assert torch.equal(torch.exp2(torch.round(torch.log2(sc))), sc)                # powers of two
+    rel_q = ((deq.float() - w.float()).abs() / (w.float().abs().amax(1, keepdim=True) + 1e-30)).max().item()
+    assert rel_q < 2 ** -4                                                          # 3 mantissa bits, scale wastes < 1 bit of range
+    wq = ops.pack_weight_fp8(q)
+    wp = ops.pack_weight(deq)
+    xf = x.float()
+    rstd = torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+    lin = xf @ deq.float().T
+    got = ops.gemm_packed_fp8(x, wq, sc, N, b, norm_eps=1e-6)
+    close_bf16(got, lin * rstd + b.float(), f"fp8 norm+bias {M}x{N}x{K}")
+    assert torch.equal(got, ops.gemm_packed(x, wp, N, b, norm_eps=1e-6)), "fp8 path != bf16 path on the dequantised matrix"
+    out = r.clone()
+    ops.gemm_packed_fp8(x, wq, sc, N, out=out, epilogue=ops.EPI_RESID, residual=out)
+    close_bf16(out, lin + r.float(), f"fp8 resid {M}x{N}x{K}")
+    if N >= 256:
+        ws = ops.new_splitk_workspace(N, 2, "cuda")
+        close_bf16(ops.gemm_packed_fp8(x, wq, sc, N, b, split_k=2, workspace=ws), lin + b.float(), "fp8 split-K")
+    M16 = (M + 15) // 16 * 16
+    xp = torch.zeros(M16, K, device="cuda", dtype=BF)
+    ops.pack_rows(x, xp, M, to_packed=True)
+    if N % 32 == 0:
+        hp = torch.zeros(M16, N // 2, device="cuda", dtype=BF)
+        ops.gemm_packed_fp8(xp, wq, sc, N, b, out=hp, epilogue=ops.EPI_SWIGLU, norm_eps=1e-6, a_packed=True, c_packed=True, rows=M)
+        un = torch.zeros(M, N // 2, device="cuda", dtype=BF)
+        ops.pack_rows(hp, un, M, to_packed=False)
+        y = (lin * rstd + b.float()).view(M, N // 32, 2, 16)
+        close_bf16(un, (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, N // 2), f"fp8 SwiGLU {M}x{N}x{K}")

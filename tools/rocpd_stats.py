@@ -6,8 +6,8 @@ import sys
 
 
 def short(name):
+    name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     name = re.sub(r"\(.*$", "", name)
-    name = name.replace("void ", "")
     return name[:110]
 
 
@@ -31,7 +31,19 @@ def main(path, out=None):
     lines = ["| kernel | calls | total ms | avg us | min us | max us | % |", "|---|---|---|---|---|---|---|"]
     for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1]):
         lines.append(f"| {k} | {a[0]} | {a[1] / 1e6:.3f} | {a[1] / a[0] / 1e3:.2f} | {a[2] / 1e3:.2f} | {a[3] / 1e3:.2f} | {100 * a[1] / total:.1f} |")
-    lines.append(f"\nkernel time total {total / 1e6:.2f} ms over wall span {(t1 - t0) / 1e6:.2f} ms ({len(rows)} dispatches)")
+    # union of the kernels' [start, end) intervals = time the GPU ran at least one kernel; 1 - union/span = idle (host or dependency gaps)
+    ev = sorted((s, e) for _, s, e in rows)
+    busy, cs, ce = 0, ev[0][0], ev[0][1]
+    for s_, e_ in ev[1:]:
+        if s_ > ce:
+            busy += ce - cs
+            cs, ce = s_, e_
+        else:
+            ce = max(ce, e_)
+    busy += ce - cs
+    lines.append(f"\nkernel time total {total / 1e6:.2f} ms over wall span {(t1 - t0) / 1e6:.2f} ms ({len(rows)} dispatches); "
+                 f"GPU busy (union of kernel intervals) {busy / 1e6:.2f} ms = {100.0 * busy / (t1 - t0):.1f} % of the span, "
+                 f"mean concurrency while busy {total / busy:.2f}")
     txt = "\n".join(lines)
     print(txt)
     if out:
