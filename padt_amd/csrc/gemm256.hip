@@ -69,6 +69,18 @@ PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, in
                                      (__attribute__((address_space(3))) void*)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
 }
 
+PADT_DEV void dma1(const char* base, unsigned off, char* dst, int piece) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
+                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
+}
+
+#ifndef PADT_PHASES2
+#define PADT_PHASES2 1     // 1 (default): two 32-MFMA phases per K-tile; 0: the round-1 schedule of four 16-MFMA phases (build-time A/B knob)
+#endif
+#ifndef PADT_DMAPOS
+#define PADT_DMAPOS 0      // where a phase issues its two LDS-DMA pieces: 0 load segment (after the ds_reads), 1 inside the MFMA
+#endif                     // segment (after the 8th MFMA), 2 one piece each.  Build-time A/B knob (profiles/r02_gemm256_experiments.md)
+
 PADT_DEV bf16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
 
 PADT_DEV void unpack4b(u32x2 v, float* f) {
@@ -122,7 +134,102 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         if (is_b) dma2(tileW + (long)t * (TK * 2), offB[h][0], offB[h][1], dst, wave);
         else dma2(tileA + (long)t * (TK * 2), offA[h][0], offA[h][1], dst, wave);
     };
+    auto stage_piece = [&](int t, int is_b, int h, char* dst, int i) {
+        if (is_b) dma1(tileW + (long)t * (TK * 2), offB[h][i], dst, wave * 2 + i);
+        else dma1(tileA + (long)t * (TK * 2), offA[h][i], dst, wave * 2 + i);
+    };
 
+#if PADT_PHASES2
+    // ---- TWO phases of 32 MFMAs per K-tile instead of four of 16: a 16-MFMA segment is ≈270 cycles and every interval between two
+    // barriers carries ≈150 cycles of synchronisation cost, so halving the barrier count is worth more than the finer DMA / ds_read
+    // interleave (same-call A/B, profiles/r02_gemm256_experiments.md: 8192^3 1342 → 1437 TFLOP/s, prefill down +13 %, gate/up +5 %;
+    // a variant with 4 + 4 DMA pieces per phase and the counted wait inside the load segment measured 3 % below this 2 + 6 split):
+    //   phase A(t): reads B n-half 0, B n-half 1, A m-half 0 (16 ds_read_b128) | stages A1(t+1)            | MFMA (m0,n0) (m0,n1)
+    //   phase B(t): reads A m-half 1 (8)                                     | stages A0, B0, B1 of t + 2 | MFMA (m1,n1) (m1,n0)
+    // Hazards (g0 = leading group, g1 one barrier behind; interval numbering per K-tile t: g0 loads A(t) in I(4t), multiplies in
+    // I(4t+1) while g1 loads A(t); g0 loads B(t) in I(4t+2), ...):
+    //   WAR  A1(t-1) is last read by g1 in I(4t-1), re-staged from I(4t) on; A0/B0/B1(t) last read in I(4t+1), re-staged from I(4t+2);
+    //   RAW  A0/B0/B1(t+1) are issued in I(4t-2)/I(4t-1), retired by the wait at the end of MFMA A(t) (g0 I(4t+1), g1 I(4t+2)) with
+    //        only phase A(t)'s 2 pieces younger → vmcnt(2), first read in I(4t+4); A1(t+1) is issued in I(4t)/I(4t+1), retired at
+    //        the end of MFMA B(t) (I(4t+3)/I(4t+4)) with phase B(t)'s 6 pieces younger → vmcnt(6), first read in I(4t+6).
+    stage_half(0, 0, 0, slot(smem, 0, 0, 0));
+    stage_half(0, 1, 0, slot(smem, 0, 1, 0));
+    stage_half(0, 1, 1, slot(smem, 0, 1, 1));
+    stage_half(0, 0, 1, slot(smem, 0, 0, 1));
+    if (nk > 1) {
+        stage_half(1, 0, 0, slot(smem, 1, 0, 0));
+        stage_half(1, 1, 0, slot(smem, 1, 1, 0));
+        stage_half(1, 1, 1, slot(smem, 1, 1, 1));
+    }
+    const int wr_u = __builtin_amdgcn_readfirstlane(wr);          // provably wave-uniform → scalar branch around s_barrier
+    if (wr_u == 1) __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // tile 0 complete (A0, B0, B1 of tile 1 may still fly)
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_s_barrier();                                 // both groups have waited before anyone reads tile 0
+    auto phase2 = [&](int t, auto ph_tag, auto steady_tag) {
+        constexpr int PH = decltype(ph_tag)::value;               // 0 = A, 1 = B
+        constexpr bool STEADY = decltype(steady_tag)::value;
+        const int par = t & 1;
+        if (PH == 0) {
+            const char* bh0 = slot(smem, par, 1, 0);
+            const char* bh1 = slot(smem, par, 1, 1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) {
+                    b0[i][kk] = rd(bh0, wc * 32 + i * 16 + frow, kk * 4 + fq);
+                    b1[i][kk] = rd(bh1, wc * 32 + i * 16 + frow, kk * 4 + fq);
+                }
+        }
+        {
+            const char* ah = slot(smem, par, 0, PH);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+#pragma unroll
+                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, kk * 4 + fq);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (PH == 0) { if (STEADY || t + 1 < nk) stage_half(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1)); }
+        else if (STEADY || t + 2 < nk) {
+            stage_half(t + 2, 0, 0, slot(smem, par, 0, 0));
+            stage_half(t + 2, 1, 0, slot(smem, par, 1, 0));
+            stage_half(t + 2, 1, 1, slot(smem, par, 1, 1));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {                             // quadrant order (m0,n0) (m0,n1) | (m1,n1) (m1,n0)
+            const int NHq = (PH == 0) ? q : 1 - q;
+#pragma unroll
+            for (int kk = 0; kk < 2; ++kk)
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[PH * MF + i][NHq * 2 + j] = mfma16(NHq ? b1[j][kk] : b0[j][kk], af[i][kk], acc[PH * MF + i][NHq * 2 + j]);
+        }
+        __builtin_amdgcn_s_setprio(0);
+        if (STEADY) { if (PH == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    {
+        using Q0 = std::integral_constant<int, 0>;
+        using Q1 = std::integral_constant<int, 1>;
+        int t = 0;
+        for (; t + 2 < nk; ++t) {
+            phase2(t, Q0{}, std::true_type{});
+            phase2(t, Q1{}, std::true_type{});
+        }
+        for (; t < nk; ++t) {
+            phase2(t, Q0{}, std::false_type{});
+            phase2(t, Q1{}, std::false_type{});
+        }
+    }
+#else
     // ---- prologue: the issue order of the steady state: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
     stage_half(0, 0, 0, slot(smem, 0, 0, 0));
     stage_half(0, 1, 0, slot(smem, 0, 1, 0));
@@ -157,6 +264,12 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
             if (PH == 2) { if (STEADY || t + 2 < nk) stage_half(t + 2, 0, 0, slot(smem, par, 0, 0)); }
             if (PH == 3) { if (STEADY || t + 2 < nk) stage_half(t + 2, 1, 0, slot(smem, par, 1, 0)); }
         };
+        auto stage1 = [&](int i) {                                // one of the phase's two pieces
+            if (PH == 0) { if (STEADY || t + 1 < nk) stage_piece(t + 1, 1, 1, slot(smem, par ^ 1, 1, 1), i); }
+            if (PH == 1) { if (STEADY || t + 1 < nk) stage_piece(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1), i); }
+            if (PH == 2) { if (STEADY || t + 2 < nk) stage_piece(t + 2, 0, 0, slot(smem, par, 0, 0), i); }
+            if (PH == 3) { if (STEADY || t + 2 < nk) stage_piece(t + 2, 1, 0, slot(smem, par, 1, 0), i); }
+        };
         if (PH == 0) {
             const char* bh = slot(smem, par, 1, 0);
 #pragma unroll
@@ -179,18 +292,25 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, kk * 4 + fq);
         }
         __builtin_amdgcn_sched_barrier(0);                        // ds_reads are issued BEFORE the LDS-DMA pieces (measured +4-8 %:
-        stage();                                                  // the reads' latency hides behind the DMA issue cost)
+        if (PADT_DMAPOS == 0) stage();                            // the reads' latency hides behind the DMA issue cost)
+        if (PADT_DMAPOS == 2) stage1(0);
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
         __builtin_amdgcn_sched_barrier(0);
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-        for (int kk = 0; kk < 2; ++kk)
+        for (int kk = 0; kk < 2; ++kk) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j)
                     acc[MH * MF + i][NH * 2 + j] = mfma16(NH ? b1[j][kk] : b0[j][kk], af[i][kk], acc[MH * MF + i][NH * 2 + j]);
+            if (kk == 0 && PADT_DMAPOS != 0) {                    // experiment: DMA issue in the shadow of the MFMA queue
+                __builtin_amdgcn_sched_barrier(0);
+                if (PADT_DMAPOS == 1) stage(); else stage1(1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
         __builtin_amdgcn_s_setprio(0);
         // retire this wave's DMA pieces of everything up to 4 stages back: the NEXT-BUT-ONE load segment reads them after
         // two more barriers, by which time the lagging group has executed the same wait
@@ -216,6 +336,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         phase(t, P2{}, std::false_type{});
         phase(t, P3{}, std::false_type{});
     }
+#endif
     if (wr_u == 0) __builtin_amdgcn_s_barrier();                  // matches the extra barrier of the lagging group
 
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
