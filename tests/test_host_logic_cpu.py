@@ -180,3 +180,24 @@ def test_config_from_hf_dict_both_layouts():
               "vision_config": flat["vision_config"], "vl_decoder": flat["vl_decoder"], "tie_word_embeddings": True}
     assert padt_amd.PaDTConfig.from_hf_dict(nested).to_dict() == c.to_dict()
     assert padt_amd.padt_pro_7b().head_dim == 128 and not padt_amd.padt_pro_7b().tie_word_embeddings
+
+
+def test_oracle_logits_warpers_match_installed_transformers():
+    """oracle.warp_logits (Temperature → TopK → TopP, the sampling branch's processors, padt.py:570-580) against the installed
+    transformers' own warper classes on random scores incl. ties and -inf rows: identical supports and values."""
+    import padt_oracle as O
+    from transformers.generation.logits_process import TemperatureLogitsWarper, TopKLogitsWarper, TopPLogitsWarper
+    g = torch.Generator().manual_seed(3)
+    scores = torch.randn(4, 500, generator=g) * 3
+    scores[:, 17] = scores[:, 3]                      # a tie
+    scores[1, 40:60] = float("-inf")                  # masked rows
+    ids = torch.zeros(4, 1, dtype=torch.long)
+    for T, k, p in [(1.0, 0, 1.0), (0.7, 40, 1.0), (1.3, 50, 0.9), (1.0, 3, 0.5), (2.0, 0, 0.8)]:
+        ref = TemperatureLogitsWarper(T)(ids, scores.clone()) if T != 1.0 else scores.clone()
+        if k:
+            ref = TopKLogitsWarper(k)(ids, ref)
+        if p < 1.0:
+            ref = TopPLogitsWarper(p)(ids, ref)
+        got = O.warp_logits(scores, T, k, p)
+        assert torch.equal(torch.isfinite(got), torch.isfinite(ref)), (T, k, p)
+        assert torch.allclose(got[torch.isfinite(got)], ref[torch.isfinite(ref)], rtol=0, atol=0), (T, k, p)
