@@ -11,11 +11,14 @@ Pinning: the reference has no tests and its only fixture needs real weights
 (SURVEY.md §4).  The oracle is pinned against outputs of the reference itself,
 imported in the build container under three shims (``tests/golden/make_golden.py``)
 with seeded synthetic weights; the resulting vectors are committed under
-``tests/golden/`` and ``tests/test_oracle_golden.py`` replays them.  Two pieces are
-NOT covered by the reference import and are therefore "parity unpinned" (restated
-from upstream transformers==4.50.0, which is not in the container):
-``rope_index`` (4.50 ``get_rope_index``) and the greedy loop in ``generate``
-(padt.py:670-762 calls 4.50-only GenerationMixin helpers).
+``tests/golden/`` and ``tests/test_oracle_golden.py`` replays them.  Not covered by
+the reference import and therefore "parity unpinned" (restated from upstream
+transformers==4.50.0, which is not in the container): the greedy loop in ``generate``
+(padt.py:670-762 calls 4.50-only GenerationMixin helpers) and two 4.50 conventions of
+``rope_index`` (filler 1 at padded positions, rope_deltas against the PADDED length).
+The valid-token positions of ``rope_index`` (incl. left-padded ragged batches),
+``warp_logits``, ``pil_resample`` and ``patchify_normalize`` are pinned against the
+installed transformers 5.15 / Pillow (tests/test_host_logic_cpu.py, test_preprocess_cpu.py).
 
 Citations are ``file:line`` into the reference repository (``src/PaDT/models/...``)
 or ``HF:`` = transformers ``models/qwen2_5_vl/modeling_qwen2_5_vl.py`` /
@@ -277,7 +280,7 @@ def embed_inputs(w: Dict[str, Tensor], cfg: OracleConfig, input_ids: Tensor, pro
     return x
 
 
-# --------------------------------------------------------------------------- positions (4.50 semantics; unpinned)
+# --------------------------------------------------------------------------- positions (4.50 semantics; valid-token ids pinned vs 5.15)
 def rope_index(cfg: OracleConfig, input_ids: Tensor, grid_thw: Tensor,
                attention_mask: Optional[Tensor]) -> Tuple[Tensor, Tensor]:
     """transformers==4.50.0 ``get_rope_index`` restated (called at padt.py:263).

@@ -201,3 +201,35 @@ def test_oracle_logits_warpers_match_installed_transformers():
         got = O.warp_logits(scores, T, k, p)
         assert torch.equal(torch.isfinite(got), torch.isfinite(ref)), (T, k, p)
         assert torch.allclose(got[torch.isfinite(got)], ref[torch.isfinite(ref)], rtol=0, atol=0), (T, k, p)
+
+
+def test_rope_index_left_padded_rows_against_installed_transformers():
+    """a5 (padt.py:256-277 → HF get_rope_index): the oracle's restatement of transformers 4.50 and the product's packed variant against
+    the INSTALLED transformers' Qwen2_5_VLModel.get_rope_index on left-padded, ragged batches with different grids.  The 3-D position
+    of every VALID token is identical in both HF versions and must match exactly; what differs between 4.50 (pinned by the reference)
+    and 5.15 is only (a) the filler at padded positions (1 vs 0 — never read: those keys are masked) and (b) rope_deltas =
+    max + 1 - PADDED length (4.50) vs - valid length (5.15), i.e. exactly the pad count apart — asserted as such."""
+    import types
+    from transformers.models.qwen2_5_vl import modeling_qwen2_5_vl as M
+    cfg = padt_amd.padt_pro_3b()
+    oc = U.oracle_config(cfg)
+    grids = [[1, 46, 46], [1, 10, 12], [1, 46, 30], [1, 8, 8]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=7, n_post=11, ragged=True, seed=5)
+    assert int((am == 0).sum()) > 0                                  # really left-padded
+    fake = types.SimpleNamespace(config=types.SimpleNamespace(vision_config=types.SimpleNamespace(spatial_merge_size=2, tokens_per_second=2)))
+    fake.get_vision_position_ids = types.MethodType(M.Qwen2_5_VLModel.get_vision_position_ids, fake)
+    mm = (ids == cfg.image_token_id).int()
+    hf_pos, hf_delta = M.Qwen2_5_VLModel.get_rope_index(fake, ids, mm, image_grid_thw=grid, attention_mask=am)
+    pos, deltas = O.rope_index(oc, ids, grid, am)
+    valid = am == 1
+    assert torch.equal(pos[:, valid], hf_pos[:, valid])
+    n_pad = (am == 0).sum(1, keepdim=True)
+    assert torch.equal(deltas, hf_delta.to(deltas.dtype) - n_pad)     # 4.50: minus the padded length
+    assert bool((pos[:, ~valid] == 1).all())
+    plan = plan_prompt(cfg, ids, am, grid, "cpu")
+    packed = torch.cat([hf_pos[:, b, am[b] == 1] for b in range(len(grids))], dim=1)
+    assert torch.equal(plan.pos3.long(), packed) and torch.equal(plan.rope_deltas, deltas)
+    # decode-step position (padt.py:268-277: cache_position + rope_deltas) = the sample's own max + 1 + t, padding-independent
+    L = ids.shape[1]
+    for b in range(len(grids)):
+        assert L + int(deltas[b, 0]) == int(hf_pos[:, b, am[b] == 1].max()) + 1 == plan.next_pos[b]
