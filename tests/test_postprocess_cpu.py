@@ -86,3 +86,36 @@ def test_box_iou_matches_reference_definition():
     for b1, b2, exp in cases:
         a, b = O.box_iou_xywh(b1, b2), P.box_iou_xywh(b1, b2)
         assert a == b and (exp is None or abs(a - exp) < 1e-12)
+
+
+def test_rle_round_trip_and_refcoco_score_aggregation():
+    """scoring.py: COCO RLE string decode is the inverse of the encoder (random masks incl. empty / full / long runs, which exercise the
+    difference coding and negative deltas), and the AP@0.5 / cIoU aggregation follows eval_refcoco.py:82-119 on a hand-checked case."""
+    import numpy as np
+    from padt_amd import postprocess as P
+    from padt_amd import scoring as S
+    rng = np.random.default_rng(3)
+    for shape in [(7, 5), (64, 48), (1, 1), (480, 640)]:
+        for dens in (0.0, 0.03, 0.5, 1.0):
+            m = (rng.random(shape) < dens).astype(np.uint8)
+            if shape == (480, 640):
+                m[100:300, 200:500] = 1                     # long runs → multi-character counts
+            counts = P.rle_counts(m)
+            assert S.rle_counts_from_string(P.rle_string(counts)) == counts
+            assert np.array_equal(S.rle_decode({"size": list(shape), "counts": P.rle_string(counts)}), m)
+    H, W = 100, 200
+    gm = np.zeros((H, W), np.uint8)
+    gm[20:60, 40:120] = 1
+    gts = [{"id": 1, "label": "dog", "bbox": [0.2, 0.2, 0.6, 0.6], "width": W, "height": H, "mask": gm},
+           {"id": 2, "label": "cat", "bbox": [0.0, 0.0, 0.5, 0.5], "width": W, "height": H, "mask": gm},
+           {"id": 3, "label": "bird", "bbox": [0.1, 0.1, 0.2, 0.2], "width": W, "height": H, "mask": gm}]
+    pm = np.zeros((H, W), np.uint8)
+    pm[20:60, 40:80] = 1                                     # half of the gt mask → cIoU 0.5
+    enc = lambda m: {"size": [H, W], "counts": P.rle_string(P.rle_counts(m))}
+    preds = [{"image_id": 1, "category": "dog", "bbox": [40, 20, 80, 40], "mask": enc(pm)},          # exact box → IoU 1
+             {"image_id": 1, "category": "dog", "bbox": [0, 0, 10, 10], "mask": enc(np.zeros((H, W), np.uint8))},   # worse duplicate: max kept
+             {"image_id": 2, "category": "cat", "bbox": [90, 40, 100, 50], "mask": enc(gm)},           # box IoU < 0.5, mask perfect
+             {"image_id": 9, "category": "none", "bbox": [0, 0, 1, 1], "mask": None}]                  # unknown expression: ignored
+    r = S.score_refcoco(preds, gts)
+    assert r["n_expressions"] == 3 and r["n_scored_masks"] == 2          # "bird" got no prediction: counts in AP, not in the cIoU mean
+    assert abs(r["rec_ap50"] - 1 / 3) < 1e-12 and abs(r["res_ciou"] - 0.75) < 1e-12
