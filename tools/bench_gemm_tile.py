@@ -16,6 +16,30 @@ SHAPES = [  # (M, N, K, epilogue)
 
 def main():
     reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    knob = sys.argv[2] if len(sys.argv) > 2 else None             # optional env knob to A/B inside one process: NAME=v0,v1
+    if knob:
+        name, vals = knob.split("=")
+        for (M, N, K, epi) in SHAPES:
+            a = torch.randn(M, K, device="cuda").to(BF)
+            w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
+            out = torch.zeros(M, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
+            res = out if epi == 2 else None
+            line = f"M={M:6d} N={N:6d} K={K:6d} epi={epi}:"
+            for v in vals.split(",") * 2:
+                os.environ[name] = v
+                for _ in range(2):
+                    ops.gemm(a, w, out=out, epilogue=epi, residual=res)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(reps):
+                    ops.gemm(a, w, out=out, epilogue=epi, residual=res)
+                e1.record()
+                torch.cuda.synchronize()
+                us = e0.elapsed_time(e1) / reps * 1e3
+                line += f"  {name}={v}: {us:7.1f} us {2.0 * M * N * K / us / 1e6:7.1f} TF"
+            print(line, flush=True)
+        return
     for (M, N, K, epi) in SHAPES:
         a = torch.randn(M, K, device="cuda").to(BF)
         w = (torch.randn(N, K, device="cuda") * 0.02).to(BF)
