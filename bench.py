@@ -218,21 +218,33 @@ def roofline_leg(model, inp, args, cfg):
     lib.padt_event_destroy(ev1)
     ms_per_pass = total / reps
     achieved = flops / (ms_per_pass * 1e-3) / 1e12
-    # HBM-side bytes per launch of the same 293 launches from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction +
-    # WRITE_SIZE), collected separately and committed under profiles/ — only quoted for the workload they were measured on
-    traffic, traffic_src = None, None
-    tp = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
-    if os.path.exists(tp):
+    # HBM-side bytes per launch of the same launches from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
+    # and the family's IN-SITU rate from a rocprofv3 kernel trace of this command (tools/collect_profiles.sh, tools/insitu.py) — both
+    # collected separately, committed under profiles/, and only quoted for the workload / launch count they were measured on
+    import glob
+    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+    traffic, traffic_src, in_situ = None, None, None
+    for tp in sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic.json")), reverse=True):
         tj = json.load(open(tp))
         wl = tj.get("workload", {})
-        if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and tj.get("launches") == len(tile):
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/r01_pmc_traffic.json"
+        if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and wl.get("task", "rec") == args.task \
+                and tj.get("gemm_calls", tj.get("launches")) == len(tile):
+            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tp)
+            break
+    for tp in sorted(glob.glob(os.path.join(pdir, "r*_insitu.json")), reverse=True):
+        tj = json.load(open(tp))
+        wl = tj.get("workload", {})
+        if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and wl.get("task", "rec") == args.task \
+                and tj.get("gemm_calls_per_step") == len(tile):
+            in_situ = {"tflops": tj["in_situ_tflops"], "avg_launch_us": tj["avg_launch_us"], "source": "profiles/" + os.path.basename(tp),
+                       "note": "same launches inside the running pipeline (rocprofv3 kernel trace of bench.py --steps 20 --warmup 5)"}
+            break
     return {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
             "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
             "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes / max(len(tile), 1), 0),
             "launches_per_step": len(tile), "avg_launch_us": round(ms_per_pass * 1e3 / max(len(tile), 1), 2),
-            "alg_tflop_per_step": round(flops / 1e12, 3), "ms_per_step_in_kernel": round(ms_per_pass, 3)}
+            "alg_tflop_per_step": round(flops / 1e12, 3), "ms_per_step_in_kernel": round(ms_per_pass, 3), "in_situ": in_situ}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg

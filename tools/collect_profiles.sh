@@ -15,6 +15,7 @@ DB=$(find $OUT/prof_trace -name "*.db" | head -1)
 python tools/rocpd_stats.py $DB $OUT/kernel_stats.md > /dev/null 2>&1
 python tools/pmc_sum.py $OUT/prof_fetch gemm_tile > $OUT/pmc_fetch.md 2>&1
 python tools/pmc_sum.py $OUT/prof_write gemm_tile > $OUT/pmc_write.md 2>&1
-tail -2 $OUT/prof_trace.log; head -12 $OUT/kernel_stats.md; cat $OUT/pmc_fetch.md $OUT/pmc_write.md
+timeout 900 python bench.py --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_line.err
+tail -2 $OUT/prof_trace.log; cat $OUT/bench_line.json; head -12 $OUT/kernel_stats.md; cat $OUT/pmc_fetch.md $OUT/pmc_write.md
 # keep the merged-back payload small
 find $OUT/prof_trace $OUT/prof_fetch $OUT/prof_write -type f -size +20M -delete
