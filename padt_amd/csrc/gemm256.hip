@@ -341,6 +341,104 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
     const bf16_t* zpage = reinterpret_cast<const bf16_t*>(g_zero_page256);
+    // FAST PATH (full column tile, plain bf16 / fp32 residual-free layouts): straight-line code.  gfx9 counts loads and stores in ONE
+    // in-order vmcnt, so an epilogue that loads (bias / residual / RoPE angles) right before every store waits for the previous
+    // store's round trip 32 times per wave — measured 12-14 us per tile whatever the number of busy CUs, a third of a K = 1280 GEMM
+    // (profiles/r02_gemm256_experiments.md).  Here bias and row scales are loaded once, the per-row-block operands (residual quads,
+    // cos / sin pairs) are fetched one 16-row block AHEAD of the stores, nothing branches per fragment, and rows past M are masked
+    // at the store only (their loads are clamped to row M - 1): the stores are fire-and-forget and drain while the CU already runs
+    // its next block.
+    if (n0 + TN <= p.N && p.lo_off == 0 && !p.r_f32) {
+        const int nb = n0 + wc * 64 + fq * 4;                     // this lane's first column of fragment column ni: nb + 16 * ni
+        const int mb = m0 + wr * (32 * MF) + frow;                // this lane's row of fragment row mi: mb + 16 * mi
+        float bv[4][4];
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) unpack4b(*reinterpret_cast<const u32x2*>(p.bias ? p.bias + nb + ni * 16 : zpage), bv[ni]);
+        float rsc[2 * MF];
+#pragma unroll
+        for (int mi = 0; mi < 2 * MF; ++mi) rsc[mi] = 1.0f;
+        if (p.rs) {
+#pragma unroll
+            for (int mi = 0; mi < 2 * MF; ++mi) rsc[mi] = p.rs[min(mb + mi * 16, p.M - 1)];
+        }
+        auto run = [&](auto rope_tag) {
+            constexpr bool ROPE = decltype(rope_tag)::value;
+            u32x2 rr[2][4];                                       // residual quads of one row block, double-buffered
+            float2 cc[2][4], ss[2][4];                            // RoPE angle pairs
+            int pi[4];
+            float keep[4];                                        // 0 → column is not rotated (v part): cos 1, sin 0
+            if (ROPE) {
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    pi[ni] = ((nb + ni * 16) % p.rope.D) >> 1;
+                    keep[ni] = (nb + ni * 16 < p.rope.cols) ? 1.0f : 0.0f;
+                }
+            }
+            auto prefetch = [&](int mi, int b) {
+                const long mc = min(mb + mi * 16, p.M - 1);
+#pragma unroll
+                for (int ni = 0; ni < 4; ++ni) {
+                    if (EPI == EPI_RESID) rr[b][ni] = *reinterpret_cast<const u32x2*>(p.R + mc * p.ldr + nb + ni * 16);
+                    if (ROPE) {
+                        cc[b][ni] = *reinterpret_cast<const float2*>(p.rope.cos + mc * p.rope.ld + pi[ni]);
+                        ss[b][ni] = *reinterpret_cast<const float2*>(p.rope.sin + mc * p.rope.ld + pi[ni]);
+                    }
+                }
+            };
+            if (EPI == EPI_RESID || ROPE) prefetch(0, 0);
+#pragma unroll
+            for (int mi = 0; mi < 2 * MF; ++mi) {
+                const int b = mi & 1;
+                if ((EPI == EPI_RESID || ROPE) && mi + 1 < 2 * MF) prefetch(mi + 1, b ^ 1);
+                const int m = mb + mi * 16;
+                const bool live = m < p.M;
+                if (EPI == EPI_SWIGLU) {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ni += 2) {
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
+                        const int no = (n0 >> 1) + wc * 32 + (ni >> 1) * 16 + fq * 4;
+                        if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    }
+                } else {
+#pragma unroll
+                    for (int ni = 0; ni < 4; ++ni) {
+                        float o[4];
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc[mi] + bv[ni][r];
+                        if (ROPE) {
+                            const float c0 = keep[ni] != 0.f ? cc[b][ni].x : 1.0f, c1 = keep[ni] != 0.f ? cc[b][ni].y : 1.0f;
+                            const float s0 = keep[ni] != 0.f ? ss[b][ni].x : 0.0f, s1 = keep[ni] != 0.f ? ss[b][ni].y : 0.0f;
+                            const float a0 = o[0], b0r = o[1], a1 = o[2], b1r = o[3];
+                            o[0] = a0 * c0 - b0r * s0;
+                            o[1] = b0r * c0 + a0 * s0;
+                            o[2] = a1 * c1 - b1r * s1;
+                            o[3] = b1r * c1 + a1 * s1;
+                        }
+                        if (EPI == EPI_GELU) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
+                        }
+                        if (EPI == EPI_RESID) {
+                            float rv[4];
+                            unpack4b(rr[b][ni], rv);
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                        }
+                        const long off = (long)m * p.ldc + nb + ni * 16;
+                        if (live) {
+                            if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
+                            else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        }
+                    }
+                }
+            }
+        };
+        if (EPI == EPI_NONE && p.rope.cos != nullptr) run(std::true_type{});
+        else run(std::false_type{});
+        return;
+    }
 #pragma unroll
     for (int mi = 0; mi < 2 * MF; ++mi) {
         const int m = m0 + wr * (32 * MF) + mi * 16 + frow;
