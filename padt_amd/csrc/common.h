@@ -81,7 +81,9 @@ PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
 }
 
 PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }
-PADT_DEV float silu(float x) { return x / (1.0f + __expf(-x)); }
+// x * sigmoid(x) with v_rcp_f32 (1 ulp) instead of an IEEE division: the SwiGLU epilogue of the gate/up GEMMs evaluates 64 of these per
+// lane per tile and the division's ~10-instruction sequence was a third of that epilogue (profiles/r02_gemm256_experiments.md)
+PADT_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
 // unpack 8 bf16 (one 16-byte vector) to floats
 PADT_DEV void unpack8(const u32x4& v, float* f) {

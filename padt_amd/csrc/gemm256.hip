@@ -41,7 +41,8 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
 namespace {
 constexpr int TM = 256, TN = 256, TK = 64;
 constexpr int HALF_BYTES = 128 * TK * 2;            // 16 KiB: 128 rows x 128 B
-constexpr int LDS_BYTES = 8 * HALF_BYTES;           // 2 K-tiles x {A0, A1, B0, B1}
+constexpr int OUT_PITCH = 512 + 32;                 // epilogue staging of a bf16 output tile: 256 columns + 32 B (ds_write_b64 of 16 rows x 32 B: 2-way conflicts)
+constexpr int LDS_BYTES = 256 * OUT_PITCH;          // >= 8 * HALF_BYTES: 2 K-tiles x {A0, A1, B0, B1} in the main loop
 
 PADT_DEV char* slot(char* smem, int parity, int is_b, int h) { return smem + ((parity * 4) + is_b * 2 + h) * HALF_BYTES; }
 
@@ -349,6 +350,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     // at the store only (their loads are clamped to row M - 1): the stores are fire-and-forget and drain while the CU already runs
     // its next block.
     if (n0 + TN <= p.N && p.lo_off == 0 && !p.r_f32) {
+        // bf16 tiles leave through LDS (free after the main loop) so that the global stores are whole 512-byte rows
+        const bool wide = !OUT_F32 && EPI != EPI_SWIGLU && (reinterpret_cast<unsigned long>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
         const int nb = n0 + wc * 64 + fq * 4;                     // this lane's first column of fragment column ni: nb + 16 * ni
         const int mb = m0 + wr * (32 * MF) + frow;                // this lane's row of fragment row mi: mb + 16 * mi
         float bv[4][4];
@@ -427,9 +430,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                             for (int r = 0; r < 4; ++r) o[r] += rv[r];
                         }
                         const long off = (long)m * p.ldc + nb + ni * 16;
-                        if (live) {
-                            if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
-                            else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        if (OUT_F32) {
+                            if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
+                        } else if (wide) {                        // bf16 tile → LDS in row-major order, written out as full rows below
+                            *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
+                                u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        } else if (live) {
+                            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                         }
                     }
                 }
@@ -437,6 +444,18 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         };
         if (EPI == EPI_NONE && p.rope.cos != nullptr) run(std::true_type{});
         else run(std::false_type{});
+        if (wide) {
+            // 8-byte fragment stores put 16 x 32-byte pieces on the wire per instruction and cost 4-8 us per tile in the memory system
+            // (same instruction count into one 512-byte region: 1.5 us); full 512-byte rows, 16 bytes per lane, do not.
+            __syncthreads();
+            const int c16 = lane & 31;
+#pragma unroll
+            for (int it = 0; it < 4 * MF; ++it) {
+                const int row = wave * (8 * MF) + it * 2 + (lane >> 5);
+                const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * OUT_PITCH + c16 * 16);
+                if (m0 + row < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + row) * p.ldc + n0 + c16 * 8) = v;
+            }
+        }
         return;
     }
 #pragma unroll
