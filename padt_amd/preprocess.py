@@ -207,7 +207,7 @@ class ImageFrontEnd:
     def __call__(self, images: List) -> Tuple[torch.Tensor, torch.Tensor]:
         """→ (pixel_values (ΣP, 1176) on the device, image_grid_thw (B, 3) int64 on the host)."""
         if self.resize == "pil":
-            imgs = [torch.from_numpy(np.ascontiguousarray(self.resize_host(im))).to(self.device, non_blocking=True) for im in images]
+            imgs = [torch.from_numpy(np.array(self.resize_host(im), dtype=np.uint8, order="C")).to(self.device, non_blocking=True) for im in images]
         else:
             imgs = []
             for im in images:
