@@ -55,7 +55,10 @@ template <int D> struct AttnCfg {
 // ROPE (window layers of the ViT, HF apply_rotary_pos_emb_vision :160-171): q fragments are rotated in registers when
 // they are loaded, the staged K tile is rotated in place in LDS — same fp32 expressions and single bf16 rounding as the
 // stand-alone rope_half kernel, without its extra pass over q and k in HBM.
-template <int D, bool CAUSAL, int QR, bool ROPE>
+// GQA: the block's 64 QR query rows are (token, q head of ONE kv group) pairs, row r = token r / group, head r % group, so a staged
+// K / V tile is multiplied by all q heads that share it (the prompt pass: 8 q heads per kv head — one eighth of the K / V tile loads
+// and LDS fills per MFMA of the head-per-block mapping); blockIdx.y is the kv head.
+template <int D, bool CAUSAL, int QR, bool ROPE, bool GQA = false>
 __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     using C = AttnCfg<D>;
     constexpr int HALF = D / 2;
@@ -69,10 +72,18 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     const int q_beg = p.cu_q[seg], Lq = p.cu_q[seg + 1] - q_beg;
     const int k_beg = p.cu_k[seg], Lk = p.cu_k[seg + 1] - k_beg;
     constexpr int TQ = 64 * QR;                                   // query rows per block
-    if (tile * TQ >= Lq) return;
-    const int hk = h / p.group;
+    const int G = GQA ? p.group : 1;
+    const int TPB = GQA ? TQ / G : TQ;                            // query tokens per block
+    if (tile * TPB >= Lq) return;
+    const int hk = GQA ? h : h / p.group;
     const int shift = Lk - Lq;                                    // causal: key j visible to query i iff j <= i + shift
-    const int wq0 = tile * TQ + wave * 16 * QR;                   // this wave's first query row
+    const int wr0 = wave * 16 * QR;                               // this wave's first row of the block
+    // row r of the block → (query token, q head); rows past the block's last whole token are dead
+    auto tok_of = [&](int r) { return GQA ? tile * TPB + r / G : tile * TQ + r; };
+    auto head_of = [&](int r) { return GQA ? hk * G + r % G : h; };
+    auto live = [&](int r) { return (!GQA || r / G < TPB) && tok_of(r) < Lq; };
+    const int w_tok0 = tok_of(wr0);                               // this wave's first / last query token
+    const int w_tok1 = GQA ? tile * TPB + (wr0 + 16 * QR - 1) / G : tile * TQ + wr0 + 16 * QR - 1;
 
     // ---- Q fragments (B operand): column = query row
     bf16x8 qf[QR][C::KQ];
@@ -80,9 +91,10 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     for (int rb = 0; rb < QR; ++rb)
 #pragma unroll
         for (int kk = 0; kk < C::KQ; ++kk) {
-            const int qrow = wq0 + rb * 16 + frow;
+            const int r = wr0 + rb * 16 + frow;
+            const int qrow = tok_of(r), hq = head_of(r);
             const int d = kk * 32 + fq * 8;
-            qf[rb][kk] = (qrow < Lq && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + h * D + d) : zero_frag();
+            qf[rb][kk] = (live(r) && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + hq * D + d) : zero_frag();
             if (ROPE && qrow < Lq && d < D) {
                 const bool lo = d < HALF;
                 const bf16_t* qp = p.q + (long)(q_beg + qrow) * p.ldq + h * D + (lo ? d + HALF : d - HALF);
@@ -112,7 +124,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 
     int nkt = (Lk + 63) / 64;
     if (CAUSAL) {
-        const int last = tile * TQ + TQ - 1 + shift;              // last visible key for this block
+        const int last = tile * TPB + TPB - 1 + shift;            // last visible key for this block
         int lim = last < 0 ? 0 : (last / 64 + 1);
         nkt = lim < nkt ? lim : nkt;
     }
@@ -183,7 +195,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             __syncthreads();
         }
         if (kt + 1 < nkt) fetch(kt + 1);
-        if (CAUSAL && kt * 64 > wq0 + 16 * QR - 1 + shift) continue;   // tile entirely above this wave's diagonal
+        if (CAUSAL && kt * 64 > w_tok1 + shift) continue;         // tile entirely above this wave's diagonal
 
         // ---- S^T = K Q^T: lane holds S[query = frow][key = kt*64 + kb*16 + fq*4 + r]
         f32x4 s[QR][4];
@@ -199,11 +211,11 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
                 for (int rb = 0; rb < QR; ++rb) s[rb][kb] = mfma16(kf, qf[rb][kk], s[rb][kb]);
             }
         }
-        const bool edge = (kt * 64 + 64 > Lk) || (CAUSAL && kt * 64 + 63 > wq0 + shift);
+        const bool edge = (kt * 64 + 64 > Lk) || (CAUSAL && kt * 64 + 63 > w_tok0 + shift);
         if (edge) {
 #pragma unroll
             for (int rb = 0; rb < QR; ++rb) {
-                const int qi = wq0 + rb * 16 + frow;
+                const int qi = tok_of(wr0 + rb * 16 + frow);
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
@@ -276,10 +288,11 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
         float l = l_run[rb];
         l += __shfl_xor(l, 16, 64);
         l += __shfl_xor(l, 32, 64);
-        const int qi = wq0 + rb * 16 + frow;
-        if (qi >= Lq) continue;
+        const int r = wr0 + rb * 16 + frow;
+        const int qi = tok_of(r);
+        if (!live(r)) continue;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
-        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + h * D + fq * 4;
+        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + head_of(r) * D + fq * 4;
 #pragma unroll
         for (int i = 0; i < C::NB; ++i) {
             u32x2 w;
@@ -647,6 +660,13 @@ extern "C" void padt_set_error(const char* msg);
 
 template <int D, bool CAUSAL, int QR>
 static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
+    static const int gqa = getenv("PADT_ATTN_GQA") ? atoi(getenv("PADT_ATTN_GQA")) : 1;      // 0 off, 1 auto, (A/B knob)
+    if (gqa && a.group > 1 && a.group <= 16 * QR && a.rcos == nullptr) {                      // q heads of a kv group share the block's K / V tiles
+        const int tpb = 64 * QR / a.group;
+        hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, false, true>), dim3((max_seqlen_q + tpb - 1) / tpb, H / a.group, nseg), dim3(256),
+                           AttnCfg<D>::LDS, s, a);
+        return;
+    }
     const int tiles = (max_seqlen_q + 64 * QR - 1) / (64 * QR);
     if constexpr (!CAUSAL && QR == 1 && D % 16 == 0) {
         if (a.rcos) {

@@ -288,6 +288,9 @@ def ref_attn(q, k, v, cu_q, cu_k, H, Hkv, D, causal):
     (128, 16, 2, [577, 100, 1, 65], True),                     # LLM prefill, GQA 8:1, ragged
     (32, 4, 2, [10, 130, 64], True),
     (64, 2, 2, [70], False),
+    (128, 28, 4, [577, 33, 7], True),                          # 7B heads: group 7 (64 rows = 9 tokens x 7 heads + 1 dead row)
+    (80, 16, 4, [300, 64, 257], False),                        # 32 query rows per wave with a kv group of 4
+    (80, 8, 1, [290, 5], True),                                # group 8 at 128 rows per block, causal
 ])
 def test_attn_self(ops, D, H, Hkv, lens, causal):
     T = sum(lens)
