@@ -342,16 +342,16 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
     const bf16_t* zpage = reinterpret_cast<const bf16_t*>(g_zero_page256);
-    // FAST PATH (full column tile, plain bf16 / fp32 residual-free layouts): straight-line code.  gfx9 counts loads and stores in ONE
+    // FAST PATH (full column tile): straight-line code.  gfx9 counts loads and stores in ONE
     // in-order vmcnt, so an epilogue that loads (bias / residual / RoPE angles) right before every store waits for the previous
     // store's round trip 32 times per wave — measured 12-14 us per tile whatever the number of busy CUs, a third of a K = 1280 GEMM
     // (profiles/r02_gemm256_experiments.md).  Here bias and row scales are loaded once, the per-row-block operands (residual quads,
     // cos / sin pairs) are fetched one 16-row block AHEAD of the stores, nothing branches per fragment, and rows past M are masked
     // at the store only (their loads are clamped to row M - 1): the stores are fire-and-forget and drain while the CU already runs
     // its next block.
-    if (n0 + TN <= p.N && p.lo_off == 0 && !p.r_f32) {
+    if (n0 + TN <= p.N) {
         // bf16 tiles leave through LDS (free after the main loop) so that the global stores are whole 512-byte rows
-        const bool wide = !OUT_F32 && EPI != EPI_SWIGLU && (reinterpret_cast<unsigned long>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
+        const bool wide = !OUT_F32 && EPI != EPI_SWIGLU && p.lo_off == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
         const int nb = n0 + wc * 64 + fq * 4;                     // this lane's first column of fragment column ni: nb + 16 * ni
         const int mb = m0 + wr * (32 * MF) + frow;                // this lane's row of fragment row mi: mb + 16 * mi
         float bv[4][4];
@@ -364,9 +364,11 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
             for (int mi = 0; mi < 2 * MF; ++mi) rsc[mi] = p.rs[min(mb + mi * 16, p.M - 1)];
         }
-        auto run = [&](auto rope_tag) {
+        auto run = [&](auto rope_tag, auto rf32_tag) {
             constexpr bool ROPE = decltype(rope_tag)::value;
+            constexpr bool RF32 = decltype(rf32_tag)::value;      // fp32 residual stream (split-precision decoder)
             u32x2 rr[2][4];                                       // residual quads of one row block, double-buffered
+            f32x4 rr32[RF32 ? 2 : 1][4];
             float2 cc[2][4], ss[2][4];                            // RoPE angle pairs
             int pi[4];
             float keep[4];                                        // 0 → column is not rotated (v part): cos 1, sin 0
@@ -381,7 +383,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 const long mc = min(mb + mi * 16, p.M - 1);
 #pragma unroll
                 for (int ni = 0; ni < 4; ++ni) {
-                    if (EPI == EPI_RESID) rr[b][ni] = *reinterpret_cast<const u32x2*>(p.R + mc * p.ldr + nb + ni * 16);
+                    if (EPI == EPI_RESID && !RF32) rr[b][ni] = *reinterpret_cast<const u32x2*>(p.R + mc * p.ldr + nb + ni * 16);
+                    if (EPI == EPI_RESID && RF32) rr32[RF32 ? b : 0][ni] = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.R) + mc * p.ldr + nb + ni * 16);
                     if (ROPE) {
                         cc[b][ni] = *reinterpret_cast<const float2*>(p.rope.cos + mc * p.rope.ld + pi[ni]);
                         ss[b][ni] = *reinterpret_cast<const float2*>(p.rope.sin + mc * p.rope.ld + pi[ni]);
@@ -423,11 +426,15 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] = gelu_erf(o[r]);
                         }
-                        if (EPI == EPI_RESID) {
+                        if (EPI == EPI_RESID && !RF32) {
                             float rv[4];
                             unpack4b(rr[b][ni], rv);
 #pragma unroll
                             for (int r = 0; r < 4; ++r) o[r] += rv[r];
+                        }
+                        if (EPI == EPI_RESID && RF32) {
+#pragma unroll
+                            for (int r = 0; r < 4; ++r) o[r] += rr32[RF32 ? b : 0][ni][r];
                         }
                         const long off = (long)m * p.ldc + nb + ni * 16;
                         if (OUT_F32) {
@@ -436,14 +443,22 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                             *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
                                 u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                         } else if (live) {
-                            *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                            const u32x2 hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
+                            *reinterpret_cast<u32x2*>(cp) = hi;
+                            if (p.lo_off) {                       // split-precision pair: lo = bf16(x - hi)
+                                float hv[4];
+                                unpack4b(hi, hv);
+                                *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2bf(o[0] - hv[0], o[1] - hv[1]), pack2bf(o[2] - hv[2], o[3] - hv[3])};
+                            }
                         }
                     }
                 }
             }
         };
-        if (EPI == EPI_NONE && p.rope.cos != nullptr) run(std::true_type{});
-        else run(std::false_type{});
+        if (EPI == EPI_NONE && p.rope.cos != nullptr) run(std::true_type{}, std::false_type{});
+        else if (EPI == EPI_RESID && OUT_F32 && p.r_f32) run(std::false_type{}, std::true_type{});
+        else run(std::false_type{}, std::false_type{});
         if (wide) {
             // 8-byte fragment stores put 16 x 32-byte pieces on the wire per instruction and cost 4-8 us per tile in the memory system
             // (same instruction count into one 512-byte region: 1.5 us); full 512-byte rows, 16 bytes per lane, do not.
