@@ -248,7 +248,7 @@ def roofline_leg(model, inp, args, cfg):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg
-def cpu_baseline_leg(cfg, args, inp):
+def cpu_baseline_leg(cfg, args, inp, model):
     """The fp32 CPU oracle (kind "port": the reference is Python and cannot travel to the GPU box) actually RUN on a bounded sample of
     the same workload: ONE image of the batch, same prompt, same scripted schedule, same random-init architecture — generate()
     (ViT + prototypes + prefill + T-1 decode steps over the 152k + 529 table) + parse + vl_decode, timed end to end.  ≈25-40 s."""
@@ -283,9 +283,24 @@ def cpu_baseline_leg(cfg, args, inp):
     ids, am = inp["ids"][:1].cpu(), inp["am"][:1].cpu()
     pix, grid = inp["pix"][:P].float().cpu(), inp["grid"][:1]
     T, sched = args.tnew, inp["sched"]
+    # the HIP path's own tokens and boxes for the same image (sample 0 of the batch: its global VRT ids are its local ones), so that the
+    # timed oracle run doubles as the parity check of the metric's "box IoU vs ref": the oracle is TEACHER-FORCED on the HIP tokens (same
+    # work per step as free running — it still computes every logit row; only the appended token is overridden)
+    from padt_amd.processor import parseVRTintoCompletion
+    from padt_amd.postprocess import box_iou_xywh, box_to_pixels
+    L = inp["ids"].shape[1]
+    gids = inp["proc"].assign_to_global_vrt_id(inp["ids"].clone(), inp["grid"])
+    hout = model.generate(input_ids=gids, attention_mask=inp["am"], pixel_values=inp["pix"], image_grid_thw=inp["grid"], use_cache=True,
+                          max_new_tokens=T, do_sample=False, output_hidden_states=True, return_dict_in_generate=True, schedule=sched)
+    hseq = hout["sequences"].cpu()
+    hloc = inp["proc"].assign_to_local_vrt_id(hseq.clone(), inp["grid"].cpu())
+    _, hfeats, _, _, _ = parseVRTintoCompletion(inp["proc"], hloc[:, L:], hout["hidden_states"], torch.Tensor([False] * hseq.shape[0]))
+    hdec = model.vl_decode(hfeats, hout.past_image_embeds, hout.past_high_res_image_embeds, inp["grid"], hout.past_visual_pe)
+    hip_boxes = [hdec["pred_boxes"][i].float().cpu().tolist() for i, si in enumerate(hdec["sample_idx"]) if int(si) == 0]
+    hip_tok = hseq[:1, L:]
     with torch.no_grad():
         t0 = time.perf_counter()
-        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched)
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, force_tokens=hip_tok, collect_logits=True)
         t_gen = time.perf_counter() - t0
         st = ores["state"]
         runs, cur = [], []
@@ -297,10 +312,20 @@ def cpu_baseline_leg(cfg, args, inp):
                 cur = []
         feats = [[torch.cat([ores["hidden"][t][0:1, -1] for t in r], 0) for r in runs]]
         t1 = time.perf_counter()
-        O.vl_decode(w, oc, feats, st.proto, st.high_res, grid, st.visual_pe)
+        odec = O.vl_decode(w, oc, feats, st.proto, st.high_res, grid, st.visual_pe)
         t_dec = time.perf_counter() - t1
     t_img = t_gen + t_dec
-    return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": cores, "kind": "port",
+    # parity read-out of the same run: how many HIP tokens are the oracle's own (scheduled) arg-max, and the IoU of the boxes (xywh pixel
+    # boxes as utils.py:258-260 derives them, IoU as eval_refcoco.py:15-41)
+    n_steps = min(len(ores["logits"]), hip_tok.shape[1])
+    same = sum(int(torch.argmax(ores["logits"][t][0]).item() == int(hip_tok[0, t])) for t in range(n_steps))
+    side = 640, 640                                                  # the synthetic image's own size (boxes are normalised; utils.py:258 scales by it)
+    ious = [round(box_iou_xywh(box_to_pixels(hb, side[1], side[0]), box_to_pixels(ob, side[1], side[0])), 4)
+            for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist())]
+    parity = {"tokens_equal_oracle_argmax": "%d/%d" % (same, n_steps), "box_iou_vs_oracle": ious,
+              "box_abs_diff_max": round(max((abs(a - b) for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist()) for a, b in zip(hb, ob)), default=0.0), 5),
+              "note": "sample 0 of the batch, oracle teacher-forced on the HIP tokens (bf16 HIP path vs fp32 oracle, random-init weights)"}
+    return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": cores, "kind": "port", "parity": parity,
             "sample": "1 image of the workload (L=%d, T_new=%d, %d object(s) x %d VRT), fp32 CPU oracle run end to end: generate %.2f s "
                       "(ViT + prefill + %d decode steps) + vl_decode %.2f s = %.2f s/image on %d threads of %d host cores"
                       % (ids.shape[1], T, len(runs), len(runs[0]) if runs else 0, t_gen, T - 1, t_dec, t_img, cores, ncpu)}
@@ -468,7 +493,7 @@ def main():
         if not args.no_roofline:
             line["roofline"] = roofline_leg(model, inp, args, cfg)
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_leg(cfg, args, inp)
+            line["cpu_baseline"] = cpu_baseline_leg(cfg, args, inp, model)
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist
