@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
                 *reinterpret_cast<f32x4*>(sn) = *reinterpret_cast<const f32x4*>(p.rsin + ci);
                 *reinterpret_cast<f32x4*>(sn + 4) = *reinterpret_cast<const f32x4*>(p.rsin + ci + 4);
 #pragma unroll
-                for (int e = 0; e < 8; ++e) x[e] = lo ? (x[e] * c[e] - y[e] * sn[e]) : (x[e] * c[e] + y[e] * sn[e]);
+                for (int e = 0; e < 8; ++e) x[e] = lo ? rope_lo(x[e], y[e], c[e], sn[e]) : rope_hi(y[e], x[e], c[e], sn[e]);
                 qf[rb][kk] = __builtin_bit_cast(bf16x8, pack8(x));
             }
         }
@@ -185,8 +185,8 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
                         const float cc = rc[it][e >> 2][e & 3], ss = rs[it][e >> 2][e & 3];
-                        o1[e] = x1[e] * cc - x2[e] * ss;
-                        o2[e] = x2[e] * cc + x1[e] * ss;
+                        o1[e] = rope_lo(x1[e], x2[e], cc, ss);
+                        o2[e] = rope_hi(x1[e], x2[e], cc, ss);
                     }
                     *reinterpret_cast<u32x4*>(k1) = pack8(o1);
                     *reinterpret_cast<u32x4*>(k1 + HALF) = pack8(o2);
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         const int hh = i / HALF, d = i % HALF;
         const float c = Cs[2 * d], sn = Cs[2 * d + 1];
         const float x1 = bf2f(Raw[hh * D + d]), x2 = bf2f(Raw[hh * D + d + HALF]);
-        const bf16_t o1 = f2bf(x1 * c - x2 * sn), o2 = f2bf(x2 * c + x1 * sn);
+        const bf16_t o1 = f2bf(rope_lo(x1, x2, c, sn)), o2 = f2bf(rope_hi(x1, x2, c, sn));
         if (hh < group) {
             Qs[hh * QROW + d] = o1; Qs[hh * QROW + d + HALF] = o2;
         } else {

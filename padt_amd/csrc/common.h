@@ -66,6 +66,12 @@ struct RopeEpi {
     int D;                                         // head width (D % 4 == 0)
 };
 
+// One rotation pair — the SAME two roundings at every rope site of the library.  Left to itself hipcc contracts x1*c - x2*s into
+// fma(x1, c, -(x2*s)) in one kernel and fma(-x2, s, x1*c) in another, so the prompt and the decode path of one token could differ in the
+// last fp32 bit (a rare bf16 flip, caught by a test that draws fresh positions on every run).
+PADT_DEV float rope_lo(float x1, float x2, float c, float s) { return __builtin_fmaf(-x2, s, x1 * c); }   // x1 cos - x2 sin
+PADT_DEV float rope_hi(float x1, float x2, float c, float s) { return __builtin_fmaf(x1, s, x2 * c); }    // x2 cos + x1 sin
+
 PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
     if (r.cos == nullptr || n >= r.cols) return;
     const int i = (n % r.D) >> 1;                  // pair index of columns (n, n+1); (n+2, n+3) is pair i + 1
@@ -74,10 +80,10 @@ PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
     const float2 ss = *reinterpret_cast<const float2*>(r.sin + (long)m * r.ld + i);
     const float c0 = cc.x, c1 = cc.y, s0 = ss.x, s1 = ss.y;
     const float a0 = o[0], b0 = o[1], a1 = o[2], b1 = o[3];
-    o[0] = a0 * c0 - b0 * s0;
-    o[1] = b0 * c0 + a0 * s0;
-    o[2] = a1 * c1 - b1 * s1;
-    o[3] = b1 * c1 + a1 * s1;
+    o[0] = rope_lo(a0, b0, c0, s0);
+    o[1] = rope_hi(a0, b0, c0, s0);
+    o[2] = rope_lo(a1, b1, c1, s1);
+    o[3] = rope_hi(a1, b1, c1, s1);
 }
 
 PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f)); }

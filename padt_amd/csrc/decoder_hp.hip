@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void rope_half_f32_kernel(float* __restrict__ 
         float* q = x + t * ldx + (long)h * D;
         const float c = cs[t * ld_cs + d], s = sn[t * ld_cs + d];
         const float x1 = q[d], x2 = q[d + half];
-        q[d] = x1 * c - x2 * s;
-        q[d + half] = x2 * c + x1 * s;
+        q[d] = rope_lo(x1, x2, c, s);
+        q[d + half] = rope_hi(x1, x2, c, s);
     }
 }
 

@@ -134,8 +134,8 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
         bf16_t* p = x + t * ldx + (long)h * D;
         const float c = cs[t * ld_cs + d], s = sn[t * ld_cs + d];
         const float x1 = bf2f(p[d]), x2 = bf2f(p[d + half]);
-        p[d] = f2bf(x1 * c - x2 * s);
-        p[d + half] = f2bf(x2 * c + x1 * s);
+        p[d] = f2bf(rope_lo(x1, x2, c, s));
+        p[d + half] = f2bf(rope_hi(x1, x2, c, s));
     }
 }
 
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(256) void rope_half_vec_kernel(bf16_t* __restrict__
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
             const float cc = e < 4 ? c0[e & 3] : c1[e & 3], ss = e < 4 ? s0[e & 3] : s1[e & 3];
-            o1[e] = x1[e] * cc - x2[e] * ss;
-            o2[e] = x2[e] * cc + x1[e] * ss;
+            o1[e] = rope_lo(x1[e], x2[e], cc, ss);
+            o2[e] = rope_hi(x1[e], x2[e], cc, ss);
         }
         *reinterpret_cast<u32x4*>(p) = pack8(o1);
         *reinterpret_cast<u32x4*>(p + half) = pack8(o2);
@@ -460,8 +460,8 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
                 const float c = cs[0][d + e], sn = cs[1][d + e];
-                o1[e] = x1[e] * c - x2[e] * sn;
-                o2[e] = x2[e] * c + x1[e] * sn;
+                o1[e] = rope_lo(x1[e], x2[e], c, sn);
+                o2[e] = rope_hi(x1[e], x2[e], c, sn);
             }
             const u32x4 r1 = pack8(o1), r2 = pack8(o2);
             if (h < p.Hq) {
@@ -487,7 +487,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
             const float c = cs[0][d], s = cs[1][d];
             const bf16_t* x = row + (long)h * p.D;
             const float x1 = bf2f(x[d]), x2 = bf2f(x[d + half]);
-            const bf16_t o1 = f2bf(x1 * c - x2 * s), o2 = f2bf(x2 * c + x1 * s);
+            const bf16_t o1 = f2bf(rope_lo(x1, x2, c, s)), o2 = f2bf(rope_hi(x1, x2, c, s));
             if (h < p.Hq) {
                 bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
                 q[d] = o1; q[d + half] = o2;

@@ -417,10 +417,10 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                             const float c0 = keep[ni] != 0.f ? cc[b][ni].x : 1.0f, c1 = keep[ni] != 0.f ? cc[b][ni].y : 1.0f;
                             const float s0 = keep[ni] != 0.f ? ss[b][ni].x : 0.0f, s1 = keep[ni] != 0.f ? ss[b][ni].y : 0.0f;
                             const float a0 = o[0], b0r = o[1], a1 = o[2], b1r = o[3];
-                            o[0] = a0 * c0 - b0r * s0;
-                            o[1] = b0r * c0 + a0 * s0;
-                            o[2] = a1 * c1 - b1r * s1;
-                            o[3] = b1r * c1 + a1 * s1;
+                            o[0] = rope_lo(a0, b0r, c0, s0);
+                            o[1] = rope_hi(a0, b0r, c0, s0);
+                            o[2] = rope_lo(a1, b1r, c1, s1);
+                            o[3] = rope_hi(a1, b1r, c1, s1);
                         }
                         if (EPI == EPI_GELU) {
 #pragma unroll

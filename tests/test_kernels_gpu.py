@@ -400,9 +400,23 @@ def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     kc = rnd(B, Hkv, S_max, D, seed=34)
     v = rnd(B, Hkv, S_max, D, seed=35)
     vt = v.transpose(2, 3).contiguous()
-    pos = torch.randint(0, 900, (3, B), dtype=torch.int32, device="cuda")
     slot_t = torch.tensor(slots, dtype=torch.int32, device="cuda")
     inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).cuda()
+    # the prompt path (llm_qkv_post) and the decode path (decode_attn_rope) must rotate a token bit-identically at EVERY position: a
+    # draw of positions where hipcc's differing fma contraction of x1*c - x2*s flipped one bf16 was found by an unseeded run of this test
+    for seed in range(1, 12):
+        gpos = torch.randint(0, 4000, (3, B), dtype=torch.int32, generator=torch.Generator().manual_seed(seed)).cuda()
+        qa, qb = torch.zeros(B, Hq * D, device="cuda", dtype=BF), torch.zeros(B, Hq * D, device="cuda", dtype=BF)
+        ka, va, kb, vb = kc.clone(), vt.clone(), kc.clone(), vt.clone()
+        csx = torch.zeros(B, D // 2, 2, device="cuda")
+        ops.rope_table(gpos, inv, csx, D, sec)
+        ops.decode_attn_rope(qkv, csx, slot_t, ka, va, qa, ops.new_decode_workspace(B, Hkv, D, S_max, "cuda"), Hq, Hkv, D, S_max, S_max)
+        ops.llm_qkv_post(qkv, gpos, inv, qb, kb, vb, Hq, Hkv, D, S_max, sec, slot=slot_t)
+        assert torch.equal(ka, kb) and torch.equal(va, vb), f"rotated K / V differ between the decode and the prompt path (positions seed {seed})"
+        ob = torch.zeros_like(qa)
+        ops.decode_attn(qb, kb, vb, slot_t + 1, ob, ops.new_decode_workspace(B, Hkv, D, S_max, "cuda"), Hq, Hkv, D, S_max, max(slots) + 1)
+        assert torch.equal(qa, ob), f"attention over the rotated q differs between the two paths (positions seed {seed})"
+    pos = torch.randint(0, 900, (3, B), dtype=torch.int32, generator=torch.Generator().manual_seed(0)).cuda()
     kc1, vt1, kc2, vt2 = kc.clone(), vt.clone(), kc.clone(), vt.clone()
     cs = torch.zeros(B, D // 2, 2, device="cuda")
     ops.rope_table(pos, inv, cs, D, sec)
