@@ -595,3 +595,34 @@ def test_fp8_llm_weights_against_oracle_on_dequantised_weights():
     ores0 = O.generate(w, oc, ids, am, pix, grid, 1, schedule=sched)
     _, rms0 = rel_err(hid[0], ores0["hidden"][0][:, -1].float())
     assert rms0 > 2e-2
+
+
+def test_bench_contract_small_config():
+    """`python bench.py` prints ONE JSON line with the driver's contract fields, the roofline and cpu_baseline objects and the parity
+    read-out — exercised on the small plumbing config so that it runs in seconds (the numbers mean nothing at this size)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--model", "small", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, timeout=600, cwd=root)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
+              "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
+    assert d["unit"] == "images/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
+    rf = d["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert k in rf, k
+    assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    cb = d["cpu_baseline"]
+    for k in ("value", "unit", "cores", "kind", "sample", "parity"):
+        assert k in cb, k
+    assert cb["kind"] == "port" and cb["value"] > 0 and cb["cores"] >= 1
+    same, total = (int(v) for v in cb["parity"]["tokens_equal_oracle_argmax"].split("/"))
+    assert total > 0 and same >= total - 2, cb["parity"]
+    assert all(iou > 0.9 for iou in cb["parity"]["box_iou_vs_oracle"]), cb["parity"]
