@@ -358,13 +358,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
         xrow[j] = p.a_pack ? p.A + (long)j * 16 * p.lda + lane * 8 : p.A + (long)(xok[j] ? m : 0) * p.lda + fq * 8;
     }
 
-    // wave w owns groups w, w+NW, ... of U CONSECUTIVE K-steps: one round = U*64 B contiguous per weight row
-    // split-K: gridDim.y blocks share an n-block, block y takes groups y*NW + wave, stepping by NW*gridDim.y
-    for (int grp = blockIdx.y * NW + wave; grp * U < nks; grp += NW * gridDim.y) {
+    // wave w owns K-step PAIRS w, w+NW, ... (KG = 2 consecutive K-steps = 2 KiB of a packed weight row block) and keeps U K-steps =
+    // U/2 of its pairs in flight, consumed in K order.  The pair → wave map does NOT depend on the row count (MT) — only U does — so a
+    // row's fp32 summation order, and with it every output bit, is the same whether 8, 16, 32 or 64 rows share the launch (in-flight
+    // batching of decode groups must not change a sample's tokens; tools/check_rows_invariance.py).
+    // split-K: gridDim.y blocks share an n-block, block y takes pairs y*NW + wave, stepping by NW*gridDim.y
+    constexpr int KG = 2, GPI = U / KG;
+    static_assert(U % KG == 0, "U is a whole number of K-step pairs");
+    const int g_stride = NW * gridDim.y;
+    for (int gi = blockIdx.y * NW + wave; gi * KG < nks; gi += g_stride * GPI) {
         bf16x8 wf[U][NT], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
-            const int ks = grp * U + u;
+            const int ks = (gi + (u / KG) * g_stride) * KG + (u % KG);
             const int k = ks * 32 + fq * 8;
             const bool kok = (ks < nks) && (k < p.K);
 #pragma unroll
@@ -532,8 +538,10 @@ static void launch_skinny(const GemmArgs& a, float eps, hipStream_t s) {
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = (a.K + 31) / 32 / (a.ws ? a.split : 1);   // per block; each wave keeps U = 8 K-steps in flight
     static const int force_nw = getenv("PADT_SKINNY_NW") ? atoi(getenv("PADT_SKINNY_NW")) : 0;   // tuning knob
+    // (the wave count must not depend on MT either: the cross-wave sum runs in wave order.  A 16-wave variant for <= 16 rows was 5 %
+    //  faster on the 8-row down-projection and is gone for that reason.)
     if constexpr (MT == 1 && NT == 1) {
-        if (force_nw == 16 || (!force_nw && nb <= 256 && ksteps >= 128)) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED, WQ>(a, eps, s); return; }
+        if (force_nw == 16) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED, WQ>(a, eps, s); return; }
     }
     if (force_nw == 8 || (!force_nw && nb <= 512 && ksteps >= 64)) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
     else launch_skinny_nw<MT, 4, EPI, F32, NORM, PACKED, WQ>(a, eps, s);

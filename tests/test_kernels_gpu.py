@@ -158,6 +158,36 @@ def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
     close_bf16(outs["2"][0], a.float() @ w.float().T + b.float() + r.float(), "column split resid")
 
 
+@pytest.mark.parametrize("name,N,K,epi,split", [("qkv", 2560, 2048, 0, 1), ("o", 2048, 2048, 2, 1), ("gate/up", 22016, 2048, 3, 1),
+                                                 ("down", 2048, 11008, 2, 2), ("down 7B", 3584, 18944, 2, 2)])
+def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi, split):
+    """In-flight batching must not change a sample: a row's output bits are the same whether 8, 16, 32 or 64 rows share the launch
+    (the K-step-pair → wave map and the wave count of gemm_skinny_kernel do not depend on the row count; only the number of pairs in
+    flight does).  Real PaDT_Pro_3B / 7B decode shapes — the small test config has too few K-steps to tell."""
+    w = rnd(N, K, scale=0.02, seed=171)
+    wp = ops.pack_weight(w)
+    x64 = rnd(64, K, seed=172)
+    n_out = N // 2 if epi == 3 else N
+    res64 = rnd(64, n_out, seed=173)
+    first = None
+    for B in (8, 16, 32, 64):
+        B16 = (B + 15) // 16 * 16
+        xp = torch.zeros(B16, K, device="cuda", dtype=BF)
+        ops.pack_rows(x64[:B].contiguous(), xp, B, to_packed=True)
+        o = torch.zeros(B16, n_out, device="cuda", dtype=BF)
+        if epi == 2:
+            ops.pack_rows(res64[:B].contiguous(), o, B, to_packed=True)
+            ops.gemm_packed(xp, wp, N, out=o, epilogue=2, residual=o, split_k=split, workspace=ops.new_splitk_workspace(N, 2, "cuda"),
+                            a_packed=True, c_packed=True, rows=B)
+        else:
+            ops.gemm_packed(xp, wp, N, out=o, epilogue=epi, norm_eps=1e-6, a_packed=True, c_packed=True, rows=B)
+        un = torch.zeros(B, n_out, device="cuda", dtype=BF)
+        ops.pack_rows(o, un, B, to_packed=False)
+        if first is None:
+            first = un[:8].clone()
+        assert torch.equal(un[:8], first), f"{name}: rows 0..7 change when {B} rows share the launch"
+
+
 @pytest.mark.parametrize("M,K", [(1000, 640), (40, 256), (2 * 256 + 24, 512), (300, 136)])
 def test_gemm_rope_epilogue(ops, M, K, monkeypatch):
     """qkv projection with RoPE fused into the epilogue (pair-interleaved q/k rows) vs Linear → rotate-half RoPE in fp32 on the
