@@ -241,6 +241,35 @@ def test_vrt_head_real_vocabulary():
                 assert int(tok[b]) == int(top2.indices[b, 0])
 
 
+def test_vrt_head_logits_do_not_depend_on_the_batch():
+    """A sample's logit row (real table, packed path of the decode step) is bit-identical whether 8, 32 or 64 rows share the launch
+    (vrt_head_kernel<1 / 2 / 4>): merged decode groups pick the same tokens as a batch decoding alone."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from padt_amd import ops
+    V, D = 151936, 2048
+    g = torch.Generator(device="cuda").manual_seed(12)
+    E = (torch.randn(V, D, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
+    Ep = ops.pack_weight(E)
+    h64 = torch.randn(64, D, device="cuda", generator=g).to(torch.bfloat16)
+    first = None
+    for B in (8, 32, 64):
+        NP = B * 529
+        P = (torch.randn(64 * 529, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(13)) * 0.02).to(torch.bfloat16)[:NP]
+        off = torch.arange(0, NP + 1, 529, dtype=torch.int32, device="cuda")
+        nblk = ops.vrt_head_nblk(V, NP)
+        hp = torch.zeros((B + 15) // 16 * 16, D, device="cuda", dtype=torch.bfloat16)
+        ops.pack_rows(h64[:B].contiguous(), hp, B, to_packed=True)
+        pv = torch.zeros(nblk * ((B + 15) // 16 * 16), device="cuda")
+        pi = torch.zeros(nblk * ((B + 15) // 16 * 16), dtype=torch.int32, device="cuda")
+        lg = torch.zeros(B, V + NP, device="cuda")
+        ops.vrt_head(hp, E, P, off, pv, pi, 151645, logits=lg, table_packed=Ep, rows=B)
+        rows = torch.cat([lg[:8, :V], torch.stack([lg[b, V + b * 529: V + (b + 1) * 529] for b in range(8)])], 1)   # text + own VRT columns
+        if first is None:
+            first = rows.clone()
+        assert torch.equal(rows, first), f"logit rows 0..7 change when {B} rows share the launch"
+
+
 def test_full_depth_3b_teacher_forced_against_oracle():
     """The WHOLE PaDT_Pro_3B geometry (32 ViT blocks at 2116 x 1280, 36 LLM layers at D = 2048 / 16:2 heads / MLP 11008,
     151 936 + 529 table rows, 98 M-parameter decoder) for one 46 x 46 image, seeded random weights (bf16-representable, biases
