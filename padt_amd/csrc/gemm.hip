@@ -319,15 +319,19 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 //   weight stream is half the bf16 bytes; bytes are converted to bf16 fragments in registers (exact), accumulation stays fp32.
 template <int MT, int NT, int NW, int EPI, bool OUT_F32, bool NORM, bool PACKED, int WQ = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float norm_eps) {
-    __shared__ __attribute__((aligned(16))) float red[NW - 1][NT * MT][64][4];
-    __shared__ __attribute__((aligned(16))) float red0[NT * (MT > 1 ? MT - 1 : 1)][64][4];
-    __shared__ float ssq[NW][MT][16];
+    // LDS (dynamic: 64 rows x 2 weight-row blocks x 8 waves do not fit the 64 KiB static limit): every wave's partial fragments
+    // red[NW][NT * MT][64][4] fp32, then the per-wave row sums of squares ssq[NW][MT][16]
+    extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+    typedef float RedT[NT * MT][64][4];
+    typedef float SsqT[MT][16];
+    RedT* red = reinterpret_cast<RedT*>(smem_raw);
+    SsqT* ssq = reinterpret_cast<SsqT*>(smem_raw + sizeof(RedT) * NW);
     __shared__ int flag;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
     const int n0 = blockIdx.x * (16 * NT);
     const int nks = (p.K + 31) / 32;
-    constexpr int U = (MT <= 2) ? 8 : (MT * NT >= 8 ? 2 : 4);   // K-steps in flight per wave (VGPR budget)
+    constexpr int U = (MT <= 2) ? 8 : ((MT * NT >= 8 || MT > 4) ? 2 : 4);   // K-steps in flight per wave (VGPR budget)
 
     f32x4 acc[NT][MT];
 #pragma unroll
@@ -419,45 +423,43 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             if (fq == 0) ssq[wave][j][frow] = t;
         }
     }
-    // Cross-wave reduction + epilogue, spread over the waves: wave j (< MT) sums the NW partials of batch row block j and
-    // runs its epilogue — with 64 decode rows the tail is as long as the K loop, one wave doing all of it left the other
-    // waves of the block idle.  Partials are summed in wave order (the order the single-wave version used).
-    constexpr int NWK = NW - 1;
-    const bool worker = wave < MT;
-    if (wave > 0) {
+    // Cross-wave reduction + epilogue, spread over the waves: wave w sums the NW partials of row blocks w, w + NW, ... (< MT) and
+    // runs their epilogues — with 64+ decode rows the tail is as long as the K loop, one wave doing all of it left the other
+    // waves of the block idle.  Partials are summed in wave order whatever wave does the summing.
+    constexpr int JW = (MT + NW - 1) / NW;                       // row blocks per finishing wave
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave - 1][i * MT + j][lane][0]) = acc[i][j];
-    }
-    if (MT > 1 && wave == 0) {                                    // wave 0's partials of the row blocks other waves finish
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 1; j < MT; ++j) *reinterpret_cast<f32x4*>(&red0[i * (MT - 1) + (j - 1)][lane][0]) = acc[i][j];
-    }
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * MT + j][lane][0]) = acc[i][j];
     __syncthreads();
-    f32x4 sum[NT];
-    const int jw = worker ? wave : 0;                             // row block this wave finishes
-    if (worker) {
+    f32x4 sum[JW][NT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            sum[i] = (wave == 0) ? acc[i][0] : *reinterpret_cast<f32x4*>(&red0[i * (MT - 1) + (jw - 1)][lane][0]);
+    for (int q = 0; q < JW; ++q) {
+        const int jw = wave + q * NW;
+        if (jw < MT) {
 #pragma unroll
-            for (int w = 0; w < NWK; ++w) sum[i] += *reinterpret_cast<f32x4*>(&red[w][i * MT + jw][lane][0]);
+            for (int i = 0; i < NT; ++i) {
+                sum[q][i] = *reinterpret_cast<f32x4*>(&red[0][i * MT + jw][lane][0]);
+#pragma unroll
+                for (int w = 1; w < NW; ++w) sum[q][i] += *reinterpret_cast<f32x4*>(&red[w][i * MT + jw][lane][0]);
+            }
         }
     }
     if (!NORM && gridDim.y > 1) {
         // split-K: the last of the n-block's split blocks to arrive sums the partials and runs the epilogue
         const int S = gridDim.y;
-        if (worker) {
-            float* mine = p.ws + (((long)(blockIdx.x * S + blockIdx.y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+        for (int q = 0; q < JW; ++q) {
+            const int jw = wave + q * NW;
+            if (jw < MT) {
+                float* mine = p.ws + (((long)(blockIdx.x * S + blockIdx.y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                for (int r = 0; r < 4; ++r) st_agent(mine + (i * MT + jw) * 256 + r, sum[i][r]);
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's partial stores are acknowledged
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) st_agent(mine + (i * MT + jw) * 256 + r, sum[q][i][r]);
+            }
         }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial stores are acknowledged
         __syncthreads();
         if (tid == 0) {
             const int old = __hip_atomic_fetch_add(&p.ticket[blockIdx.x], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -467,32 +469,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
         }
         __syncthreads();
         if (!flag) return;
-        if (worker) {
-            for (int y = 0; y < S; ++y) {
-                if (y == (int)blockIdx.y) continue;
-                const float* other = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
+        for (int q = 0; q < JW; ++q) {
+            const int jw = wave + q * NW;
+            if (jw < MT) {
+                for (int y = 0; y < S; ++y) {
+                    if (y == (int)blockIdx.y) continue;
+                    const float* other = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                    for (int r = 0; r < 4; ++r) sum[i][r] += ld_agent(other + (i * MT + jw) * 256 + r);
+                    for (int i = 0; i < NT; ++i)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) sum[q][i][r] += ld_agent(other + (i * MT + jw) * 256 + r);
+                }
             }
         }
     }
-    if (!worker) return;
-    const int m = jw * 16 + frow;
-    if (NORM) {
-        float t = 0.f;
 #pragma unroll
-        for (int w = 0; w < NW; ++w) t += ssq[w][jw][frow];
-        const float rstd = rsqrtf(t / (float)p.K + norm_eps);
+    for (int q = 0; q < JW; ++q) {
+        const int jw = wave + q * NW;
+        if (jw >= MT) continue;
+        const int m = jw * 16 + frow;
+        if (NORM) {
+            float t = 0.f;
 #pragma unroll
-        for (int i = 0; i < NT; ++i) sum[i] *= rstd;
-    }
-    if (EPI == EPI_SWIGLU) {
-        store_swiglu(p, m, n0 + fq * 4, sum[0], sum[NT - 1]);
-    } else {
+            for (int w = 0; w < NW; ++w) t += ssq[w][jw][frow];
+            const float rstd = rsqrtf(t / (float)p.K + norm_eps);
 #pragma unroll
-        for (int i = 0; i < NT; ++i) store_frag<EPI, OUT_F32>(p, m, n0 + i * 16 + fq * 4, sum[i]);
+            for (int i = 0; i < NT; ++i) sum[q][i] *= rstd;
+        }
+        if (EPI == EPI_SWIGLU) {
+            store_swiglu(p, m, n0 + fq * 4, sum[q][0], sum[q][NT - 1]);
+        } else {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) store_frag<EPI, OUT_F32>(p, m, n0 + i * 16 + fq * 4, sum[q][i]);
+        }
     }
 }
 
@@ -528,7 +538,16 @@ static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int split = (a.ws && !NORM) ? a.split : 1;
-    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>), dim3(nb, split), dim3(NW * 64), 0, s, a, eps);
+    constexpr int lds = NW * NT * MT * 64 * 16 + NW * MT * 16 * 4;      // red + ssq (gemm_skinny_kernel)
+    if constexpr (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>), dim3(nb, split), dim3(NW * 64), lds, s, a, eps);
 }
 
 // waves per block: enough waves chip-wide (>= ~2048) to keep HBM busy even when N/16 < #CUs
