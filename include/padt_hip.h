@@ -56,7 +56,7 @@ int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long row
 int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, const void* W, long ldw, const void* bias,
                            void* C, long ldc, long M, long N, long K, int epilogue);
 
-/* Decode-step projection over FRAGMENT-PACKED weights, M <= 64 (HBM-bound weight streaming): same math as
+/* Decode-step projection over FRAGMENT-PACKED weights, M <= 128 (HBM-bound weight streaming): same math as
  * padt_gemm_bf16 / padt_gemm_rmsnorm_bf16, but W is stored as [N/16][Kp/32][64 lanes][8] so every wave instruction
  * reads 1 KiB contiguous bytes (row-major fragments load 16 rows x 64 B and run the address unit at a quarter rate).
  * Kp = padded K (multiple of 32) of the packed image, N must be a multiple of 16.  epilogue 0 none, 2 += R, 3 SwiGLU;

@@ -704,13 +704,14 @@ template <int EPI, bool NORM, int WQ = 0>
 static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
     if (a.M <= 16) launch_skinny<1, EPI, false, NORM, true, WQ>(a, eps, s);
     else if (a.M <= 32) launch_skinny<2, EPI, false, NORM, true, WQ>(a, eps, s);
-    else launch_skinny<4, EPI, false, NORM, true, WQ>(a, eps, s);
+    else if (a.M <= 64) launch_skinny<4, EPI, false, NORM, true, WQ>(a, eps, s);
+    else launch_skinny<8, EPI, false, NORM, true, WQ>(a, eps, s);
 }
 
 static long splitk_ticket_bytes(long N) { return (((N + 15) / 16 * 4 + 255) / 256) * 256; }
 
 extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
-    return splitk_ticket_bytes(N) + (N + 15) / 16 * (long)split_k * 4 * 64 * 16;   // up to 4 row blocks of fp32 fragments
+    return splitk_ticket_bytes(N) + (N + 15) / 16 * (long)split_k * 8 * 64 * 16;   // up to 8 row blocks (128 rows) of fp32 fragments
 }
 
 static int gemm_packed_impl(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
@@ -729,8 +730,8 @@ static int gemm_packed_impl(void* stream, const void* A, long lda, const void* W
         padt_set_error("padt_gemm_packed_bf16: split_k in [2, 8] needs a workspace, no fused norm and epilogue 0 or 2");
         return -1;
     }
-    if (M > 64 || K <= 0 || (K & 7) || K > Kp || (Kp & 31) || (lda & 7) || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) {
-        padt_set_error("padt_gemm_packed_bf16: M <= 64, K % 8 == 0, K <= Kp, Kp % 32 == 0, 16-byte aligned A/Wp required");
+    if (M > 128 || K <= 0 || (K & 7) || K > Kp || (Kp & 31) || (lda & 7) || ((uintptr_t)A & 15) || ((uintptr_t)Wp & 15)) {
+        padt_set_error("padt_gemm_packed_bf16: M <= 128, K % 8 == 0, K <= Kp, Kp % 32 == 0, 16-byte aligned A/Wp required");
         return -1;
     }
     const bool norm = norm_eps >= 0.f;

@@ -46,7 +46,7 @@ struct HeadArgs {
 
 // PACKED: text rows come from a fragment-packed copy of the table ([V/16][D/32][64 lanes][8], ops.pack_weight — every wave
 // load is 1 KiB contiguous) and the hidden rows from the 16-row fragment-packed activation layout; prototype rows (rebuilt
-// per batch) stay row-major.  Waves take groups of U consecutive K-steps; wave j (< MT) finishes sample block j.
+// per batch) stay row-major.  Waves take groups of U consecutive K-steps; wave w finishes sample blocks w, w + 4 (< MT).
 template <int MT, bool PACKED>
 __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
     __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
@@ -93,8 +93,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
     __syncthreads();
-    if (wave >= MT) return;
-    const int j = wave;                                       // sample block this wave finishes
+    for (int j = wave; j < MT; j += 4) {                      // sample blocks this wave finishes (two of them at MT = 8)
     f32x4 sum = *reinterpret_cast<f32x4*>(&red[0][j][lane][0]);
 #pragma unroll
     for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
@@ -129,6 +128,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
     if (fq == 0 && m < p.B) {
         p.part_val[(long)blockIdx.x * p.B + m] = best;
         p.part_idx[(long)blockIdx.x * p.B + m] = bidx;
+    }
     }
 }
 
@@ -205,7 +205,7 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
                              long batch, long D, int eos, const void* embed_table_packed, const void* gen_cfg,
                              const void* seen, long seen_words) {
     if (batch <= 0) return 0;
-    if (batch > 64 || (D & 7) || (ldh & 7)) { padt_set_error("padt_vrt_head: batch <= 64, D % 8 == 0 required"); return -1; }
+    if (batch > 128 || (D & 7) || (ldh & 7)) { padt_set_error("padt_vrt_head: batch <= 128, D % 8 == 0 required"); return -1; }
     if (embed_table_packed && ((D & 31) || (vocab & 15) || ((uintptr_t)embed_table_packed & 15) || ((uintptr_t)hidden & 15))) {
         padt_set_error("padt_vrt_head: the packed path needs D % 32 == 0, vocab % 16 == 0 and 16-byte aligned pointers");
         return -1;
@@ -219,10 +219,12 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
     if (embed_table_packed) {
         if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, true>), dim3(nblk), dim3(256), 0, s, a);
         else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, true>), dim3(nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((vrt_head_kernel<4, true>), dim3(nblk), dim3(256), 0, s, a);
+        else if (batch <= 64) hipLaunchKernelGGL((vrt_head_kernel<4, true>), dim3(nblk), dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((vrt_head_kernel<8, true>), dim3(nblk), dim3(256), 0, s, a);
     } else if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, false>), dim3(nblk), dim3(256), 0, s, a);
     else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, false>), dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((vrt_head_kernel<4, false>), dim3(nblk), dim3(256), 0, s, a);
+    else if (batch <= 64) hipLaunchKernelGGL((vrt_head_kernel<4, false>), dim3(nblk), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((vrt_head_kernel<8, false>), dim3(nblk), dim3(256), 0, s, a);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

@@ -155,7 +155,7 @@ def pack_rows(src, dst, M, to_packed=True):
 
 def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None,
                 a_packed=False, c_packed=False, rows=None):
-    """Decode-step projection over a pack_weight() image (rows <= 64): out = epi(rstd?(a) * (a @ w^T) + bias).
+    """Decode-step projection over a pack_weight() image (rows <= 128): out = epi(rstd?(a) * (a @ w^T) + bias).
     a_packed / c_packed: a / (out and residual) are fragment-packed activation buffers holding `rows` valid rows."""
     lib = _lib.load()
     _chk_bf16(a, wp, bias, residual)

@@ -161,16 +161,16 @@ def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
 @pytest.mark.parametrize("name,N,K,epi,split", [("qkv", 2560, 2048, 0, 1), ("o", 2048, 2048, 2, 1), ("gate/up", 22016, 2048, 3, 1),
                                                  ("down", 2048, 11008, 2, 2), ("down 7B", 3584, 18944, 2, 2)])
 def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi, split):
-    """In-flight batching must not change a sample: a row's output bits are the same whether 8, 16, 32 or 64 rows share the launch
+    """In-flight batching must not change a sample: a row's output bits are the same whether 8, 16, 32, 64 or 128 rows share the launch
     (the K-step-pair → wave map and the wave count of gemm_skinny_kernel do not depend on the row count; only the number of pairs in
     flight does).  Real PaDT_Pro_3B / 7B decode shapes — the small test config has too few K-steps to tell."""
     w = rnd(N, K, scale=0.02, seed=171)
     wp = ops.pack_weight(w)
-    x64 = rnd(64, K, seed=172)
+    x64 = rnd(128, K, seed=172)
     n_out = N // 2 if epi == 3 else N
-    res64 = rnd(64, n_out, seed=173)
+    res64 = rnd(128, n_out, seed=173)
     first = None
-    for B in (8, 16, 32, 64):
+    for B in (8, 16, 32, 64, 128):
         B16 = (B + 15) // 16 * 16
         xp = torch.zeros(B16, K, device="cuda", dtype=BF)
         ops.pack_rows(x64[:B].contiguous(), xp, B, to_packed=True)
@@ -186,6 +186,15 @@ def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi,
         if first is None:
             first = un[:8].clone()
         assert torch.equal(un[:8], first), f"{name}: rows 0..7 change when {B} rows share the launch"
+        if B == 128:                                             # and the 128-row launch is right on all of its rows
+            xf = x64.float()
+            lin = xf @ w.float().T
+            if epi == 2:
+                ref = lin + res64.float()
+            else:
+                lin = lin * torch.rsqrt(xf.pow(2).mean(-1, keepdim=True) + 1e-6)
+                ref = lin if epi == 0 else torch.nn.functional.silu(lin.view(128, -1, 2, 16)[:, :, 0]) .reshape(128, -1) * lin.view(128, -1, 2, 16)[:, :, 1].reshape(128, -1)
+            close_bf16(un, ref, f"{name} at 128 rows", ulps=2)
 
 
 @pytest.mark.parametrize("M,K", [(1000, 640), (40, 256), (2 * 256 + 24, 512), (300, 136)])

@@ -242,8 +242,8 @@ def test_vrt_head_real_vocabulary():
 
 
 def test_vrt_head_logits_do_not_depend_on_the_batch():
-    """A sample's logit row (real table, packed path of the decode step) is bit-identical whether 8, 32 or 64 rows share the launch
-    (vrt_head_kernel<1 / 2 / 4>): merged decode groups pick the same tokens as a batch decoding alone."""
+    """A sample's logit row (real table, packed path of the decode step) is bit-identical whether 8, 32, 64 or 128 rows share the launch
+    (vrt_head_kernel<1 / 2 / 4 / 8>): merged decode groups pick the same tokens as a batch decoding alone."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     from padt_amd import ops
@@ -251,11 +251,11 @@ def test_vrt_head_logits_do_not_depend_on_the_batch():
     g = torch.Generator(device="cuda").manual_seed(12)
     E = (torch.randn(V, D, device="cuda", generator=g) * 0.02).to(torch.bfloat16)
     Ep = ops.pack_weight(E)
-    h64 = torch.randn(64, D, device="cuda", generator=g).to(torch.bfloat16)
+    h64 = torch.randn(128, D, device="cuda", generator=g).to(torch.bfloat16)
     first = None
-    for B in (8, 32, 64):
+    for B in (8, 32, 64, 128):
         NP = B * 529
-        P = (torch.randn(64 * 529, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(13)) * 0.02).to(torch.bfloat16)[:NP]
+        P = (torch.randn(128 * 529, D, device="cuda", generator=torch.Generator(device="cuda").manual_seed(13)) * 0.02).to(torch.bfloat16)[:NP]
         off = torch.arange(0, NP + 1, 529, dtype=torch.int32, device="cuda")
         nblk = ops.vrt_head_nblk(V, NP)
         hp = torch.zeros((B + 15) // 16 * 16, D, device="cuda", dtype=torch.bfloat16)
