@@ -13,6 +13,12 @@ CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpadt_hip.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip", "decoder_hp.hip", "resize.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
+# Per-source extras (dropped with a warning if this hipcc does not know them).  -amdgpu-mfma-vgpr-form: MFMA results land in ordinary
+# VGPRs instead of AccVGPRs.  hipcc's default keeps the attention kernels' score / output tiles in AccVGPRs and moves every value to a
+# VGPR and back for the softmax (184 v_accvgpr_read/write per 44 MFMAs in the ViT full-attention loop) — with the LDS-DMA K / V staging
+# the full-attention kernel drops from 212 to 160 registers (three waves per SIMD instead of two): 373 → 323 us; the prompt kernel
+# (LDS-bound at two blocks per CU) loses 3 %, the decode kernels are unchanged (profiles/r02_pmc_attention.md).
+EXTRA_FLAGS = {"attention.hip": ["-mllvm", "-amdgpu-mfma-vgpr-form=1"]}
 
 
 def _hipcc():
@@ -39,8 +45,12 @@ def build(force=False, verbose=True):
 
     def compile_one(src):
         obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 and src in EXTRA_FLAGS:
+            print(f"[padt_amd.build] {src}: extra flags {EXTRA_FLAGS[src]} rejected, compiling without them", file=sys.stderr)
+            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         if verbose and r.stderr.strip():

@@ -45,6 +45,8 @@ template <int D> struct AttnCfg {
     static constexpr int K_BYTES = 64 * KROW * 2;
     static constexpr int V_BYTES = 64 * VROW * 2;
     static constexpr int LDS = K_BYTES + V_BYTES;
+    static constexpr int LDS2 = 2 * LDS;              // double-buffered (LDS-DMA path)
+    static constexpr int PIECES = (K_BYTES + 1023) / 1024;   // 1-KiB LDS-DMA pieces per K (or V) tile
 };
 
 // Everything is computed TRANSPOSED so that a lane owns ONE query column: S^T = K Q^T puts the 16 keys of a block on the
@@ -129,8 +131,35 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
         nkt = lim < nkt ? lim : nkt;
     }
 
-    // K/V tile kt+1 is fetched into registers while tile kt is multiplied
-    u32x4 kreg[C::NK], vreg[C::NK];
+    // DMA (every variant but the fused-RoPE one): K / V tile kt+1 goes global → LDS by LDS-DMA into the other half of a double
+    // buffer while tile kt is multiplied — no staging registers (24-32 VGPRs back: one more wave per SIMD), no ds_write pass, ONE block
+    // barrier per tile instead of two.  Lane l of piece pc owns LDS bytes pc*1024 + 16 l of the row-major tile (row stride KROW): it
+    // loads the matching 16 bytes of its key row, or nothing when those bytes are row padding.  Keys past Lk re-read the last key
+    // (their scores are masked, their probabilities 0).
+    constexpr bool DMA = !ROPE;
+    constexpr int PPW = (C::PIECES + 3) / 4;                      // pieces per wave
+    auto issue = [&](int kt, int buf) {
+        char* kb_ = smem + buf * C::LDS;
+        char* vb_ = kb_ + C::K_BYTES;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int pc = wave + 4 * i;
+            const int ob = pc * 1024 + lane * 16;                 // byte offset inside the tile
+            const int row = ob / (C::KROW * 2), cb = ob % (C::KROW * 2);
+            if (pc < C::PIECES && row < 64 && cb < D * 2) {
+                int key = kt * 64 + row;
+                key = key < Lk ? key : Lk - 1;
+                const char* ks = reinterpret_cast<const char*>(p.k + (long)(k_beg + key) * p.ldk + hk * D) + cb;
+                const char* vs = reinterpret_cast<const char*>(p.v + (long)(k_beg + key) * p.ldv + hk * D) + cb;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ks,
+                                                 (__attribute__((address_space(3))) void*)(kb_ + pc * 1024), 16, 0, 0);
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)vs,
+                                                 (__attribute__((address_space(3))) void*)(vb_ + pc * 1024), 16, 0, 0);
+            }
+        }
+    };
+    // (fused-RoPE variant) K/V tile kt+1 is fetched into registers while tile kt is multiplied
+    u32x4 kreg[DMA ? 1 : C::NK], vreg[DMA ? 1 : C::NK];
     constexpr int NR = ROPE ? (64 * (C::CPR / 2) + 255) / 256 : 1;  // (row, half-chunk) rotation items per thread per tile
     f32x4 rc[NR][2], rs[NR][2];
     auto fetch = [&](int kt) {
@@ -150,7 +179,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             }
         }
 #pragma unroll
-        for (int it = 0; it < C::NK; ++it) {
+        for (int it = 0; it < (DMA ? 0 : C::NK); ++it) {
             const int idx = it * 256 + tid;
             const int row = idx / C::CPR, c = idx % C::CPR;
             const int key = kt * 64 + row;
@@ -159,9 +188,16 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             vreg[it] = ok ? *reinterpret_cast<const u32x4*>(p.v + (long)(k_beg + key) * p.ldv + hk * D + c * 8) : u32x4{0u, 0u, 0u, 0u};
         }
     };
-    if (nkt > 0) fetch(0);
+    if (nkt > 0) { if (DMA) issue(0, 0); else fetch(0); }
 
     for (int kt = 0; kt < nkt; ++kt) {
+        if (DMA) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
+            __syncthreads();                                      // everyone's have; everyone is done with the other buffer (tile kt - 1)
+            if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
+            Ks = reinterpret_cast<bf16_t*>(smem + (kt & 1) * C::LDS);
+            Vt = reinterpret_cast<bf16_t*>(smem + (kt & 1) * C::LDS + C::K_BYTES);
+        } else {
         __syncthreads();                                          // previous tile fully consumed
 #pragma unroll
         for (int it = 0; it < C::NK; ++it) {
@@ -172,6 +208,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             }
         }
         __syncthreads();
+        }
         if (ROPE) {                                               // rotate the staged K tile in place (pairs d, d + D/2)
 #pragma unroll
             for (int it = 0; it < NR; ++it) {
@@ -194,7 +231,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             }
             __syncthreads();
         }
-        if (kt + 1 < nkt) fetch(kt + 1);
+        if (!DMA && kt + 1 < nkt) fetch(kt + 1);
         if (CAUSAL && kt * 64 > w_tok1 + shift) continue;         // tile entirely above this wave's diagonal
 
         // ---- S^T = K Q^T: lane holds S[query = frow][key = kt*64 + kb*16 + fq*4 + r]
@@ -658,23 +695,36 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
 // ---------------------------------------------------------------------------------------------------------------------
 extern "C" void padt_set_error(const char* msg);
 
+template <int D, bool CAUSAL, int QR, bool ROPE, bool GQA>
+static void launch_attn_k(const AttnArgs& a, dim3 grid, hipStream_t s) {
+    constexpr int lds = ROPE ? AttnCfg<D>::LDS : AttnCfg<D>::LDS2;             // the LDS-DMA path double-buffers the K / V tiles
+    if constexpr (lds > 64 * 1024) {
+        static bool done = false;
+        if (!done) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_varlen_kernel<D, CAUSAL, QR, ROPE, GQA>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            done = true;
+        }
+    }
+    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, ROPE, GQA>), grid, dim3(256), lds, s, a);
+}
+
 template <int D, bool CAUSAL, int QR>
 static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
     static const int gqa = getenv("PADT_ATTN_GQA") ? atoi(getenv("PADT_ATTN_GQA")) : 1;      // 0 off, 1 auto, (A/B knob)
     if (gqa && a.group > 1 && a.group <= 16 * QR && a.rcos == nullptr) {                      // q heads of a kv group share the block's K / V tiles
         const int tpb = 64 * QR / a.group;
-        hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, false, true>), dim3((max_seqlen_q + tpb - 1) / tpb, H / a.group, nseg), dim3(256),
-                           AttnCfg<D>::LDS, s, a);
+        launch_attn_k<D, CAUSAL, QR, false, true>(a, dim3((max_seqlen_q + tpb - 1) / tpb, H / a.group, nseg), s);
         return;
     }
     const int tiles = (max_seqlen_q + 64 * QR - 1) / (64 * QR);
     if constexpr (!CAUSAL && QR == 1 && D % 16 == 0) {
         if (a.rcos) {
-            hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, true>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+            launch_attn_k<D, CAUSAL, QR, true, false>(a, dim3(tiles, H, nseg), s);
             return;
         }
     }
-    hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, false>), dim3(tiles, H, nseg), dim3(256), AttnCfg<D>::LDS, s, a);
+    launch_attn_k<D, CAUSAL, QR, false, false>(a, dim3(tiles, H, nseg), s);
 }
 
 // long segments, d <= 80: 32 query rows per wave (each K / V^T fragment read from LDS feeds two MFMAs); at d = 128 the
