@@ -70,7 +70,8 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
-    const int seg = blockIdx.z, h = blockIdx.y, tile = blockIdx.x;
+    // causal: a block's work grows with its query position (it visits keys 0 .. its last token) — dispatch the late, long blocks first
+    const int seg = blockIdx.z, h = blockIdx.y, tile = CAUSAL ? (int)(gridDim.x - 1 - blockIdx.x) : (int)blockIdx.x;
     const int q_beg = p.cu_q[seg], Lq = p.cu_q[seg + 1] - q_beg;
     const int k_beg = p.cu_k[seg], Lk = p.cu_k[seg + 1] - k_beg;
     constexpr int TQ = 64 * QR;                                   // query rows per block
