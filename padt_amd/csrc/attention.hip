@@ -728,12 +728,14 @@ static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg,
     launch_attn_k<D, CAUSAL, QR, false, false>(a, dim3(tiles, H, nseg), s);
 }
 
-// long segments, d <= 80: 32 query rows per wave (each K / V^T fragment read from LDS feeds two MFMAs); at d = 128 the
-// second row block costs the second resident block per CU and loses (measured: prefill 36 vs 43 us)
+// long segments: 32 query rows per wave (each K / V^T fragment read from LDS feeds two MFMAs).  Round 1 restricted this to d <= 80
+// (at d = 128 the second row block cost the second resident block per CU: prefill 36 vs 43 us); with LDS-DMA staging and MFMA results
+// in VGPRs the d = 128 kernel is LDS-bound at two blocks per CU either way and the wider block wins (3B prompt 42.2 → 37.8 us, 7B
+// 69.3 → 55.9 us)
 template <int D, bool CAUSAL>
 static void launch_attn(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
     static const int force = getenv("PADT_ATTN_QR") ? atoi(getenv("PADT_ATTN_QR")) : 0;
-    if (force ? force == 2 : (max_seqlen_q >= 256 && D <= 80)) launch_attn_qr<D, CAUSAL, 2>(a, max_seqlen_q, H, nseg, s);
+    if (force ? force == 2 : (max_seqlen_q >= 256)) launch_attn_qr<D, CAUSAL, 2>(a, max_seqlen_q, H, nseg, s);
     else launch_attn_qr<D, CAUSAL, 1>(a, max_seqlen_q, H, nseg, s);
 }
 
