@@ -143,7 +143,9 @@ def roofline_leg(model, inp, args, cfg):
     log, ops.GEMM_LOG = ops.GEMM_LOG, None
     # launches that take a tile kernel (M > 64); "hp" entries are the split-precision decoder GEMMs (ops.gemm_hp: A = [hi | lo],
     # W = [W | W], K' = 2K): their ALGORITHMIC work is the reference's 2*M*N*K, half of what the MFMA pipe executes
-    tile = [c for c in log if (c[8] if isinstance(c[0], str) else c[0].shape[0]) > 64]
+    def rows_of(c):
+        return c[8] if c[0] == "hp" else (c[1].shape[0] if c[0] == "r32" else c[0].shape[0])
+    tile = [c for c in log if rows_of(c) > 64]
     vip, vi = model.W.vit_ipad, cfg.vision_config.intermediate_size
     lip, li = model.W.llm_ipad, cfg.intermediate_size
     dip, di = model.W.dec_ipad, cfg.vl_decoder["intermediate_size"]
@@ -158,6 +160,11 @@ def roofline_leg(model, inp, args, cfg):
     flops = 0.0
     alg_bytes = 0.0
     for c in tile:
+        if c[0] == "r32":                                               # fp32 residual stream: reads + writes fp32, writes the bf16 mirror
+            _, a, w, bias, x32, xb = c
+            flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(a.shape[1])
+            alg_bytes += 2.0 * (a.shape[0] * alg(a.shape[1]) + alg(w.shape[0]) * alg(a.shape[1])) + (8.0 + (2.0 if xb is not None else 0.0)) * a.shape[0] * w.shape[0]
+            continue
         if isinstance(c[0], str):
             _, a, w, bias, out, epi, res, out_mode, M = c
             n, k = alg(w.shape[0]), alg(w.shape[1] // 2)
@@ -178,7 +185,9 @@ def roofline_leg(model, inp, args, cfg):
 
     def replay():
         for c in tile:
-            if isinstance(c[0], str):
+            if c[0] == "r32":
+                ops.gemm_resid32(c[1], c[2], c[3], c[4], c[5])
+            elif isinstance(c[0], str):
                 ops.gemm_hp(c[1], c[2], c[3], out=c[4], epilogue=c[5], residual=c[6], out_mode=c[7], M=c[8])
             else:
                 (a, w, bias, out, epi, res, f32, K, rs) = c

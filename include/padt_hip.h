@@ -46,6 +46,17 @@ int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ld
 int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
                         long M, long N, long K, const void* row_scale, const void* rope_cos, const void* rope_sin, long ld_cs,
                         long rope_cols, int head_dim);
+/* fp32 RESIDUAL STREAM: X32[M,N] (fp32, in place) += A[M,K] · W[N,K]^T + bias, and Xb = bf16(X32) (row-major mirror, ldxb % 8 == 0; may be
+ * null).  The residual adds of a ViT block (HF:318-320: x + attn.proj(..), x + mlp.down_proj(..)) and of an LLM layer at prompt length
+ * (HF:741,757) with the stream carried in fp32 between kernels — what the reference's fp32 CPU path does — while the same epilogue emits the
+ * bf16 A operand of the next projection.  Every tile kernel of padt_gemm_bf16 serves it. */
+int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx, void* Xb,
+                      long ldxb, long M, long N, long K);
+/* Dispatch knobs of the 256-row tile kernel (tests force every tile variant; tools A/B them): mode256 0 off / 1 auto / 2 forced,
+ * mf 0 auto / 2..4 tile height in 64-row units, peel 0 never / 1 cost model / 2 always, colsplit 0 never / 1 cost model / n columns,
+ * group_m rasterisation patch height.  -1 keeps a field.  The defaults are read once from PADT_GEMM256 / PADT_GEMM_MF / PADT_GEMM_PEEL /
+ * PADT_GEMM_COLSPLIT / PADT_GEMM_GROUP_M when the library loads.  Process-wide, not thread-safe (a test / tuning surface). */
+int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m);
 /* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above). */
 int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 
@@ -82,6 +93,12 @@ int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long l
 int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias, void* C,
                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps, int split_k,
                          void* workspace, int act_packed);
+/* Decode-step residual projection over the fp32 residual stream (o_proj / down_proj, HF:741,757 at one token per row):
+ * X32[M,N] (fp32 row-major, in place) += scale?[n] * (A · W^T); Xb = bf16(X32) in the fragment-packed activation layout (required;
+ * ldxb % 8 == 0) = the A operand of the next projection.  Wp bf16 fragment-packed, or with scales != null the fp8 image.  a_packed: A is
+ * in the fragment-packed activation layout.  split_k / workspace as padt_gemm_packed_bf16. */
+int padt_gemm_packed_resid32(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* scales, void* X32, long ldx,
+                             void* Xb, long ldxb, long M, long N, long K, int split_k, void* workspace, int a_packed);
 
 /* ---- attention ------------------------------------------------------------------------------------------------------
  * Varlen flash attention, fp32 online softmax, non-causal or causal (bottom-right aligned), GQA by head index.
@@ -133,6 +150,11 @@ int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb
                   long D);
 /* fp32 → bf16 with zero-padded row tail (pixel_values.type(visual.dtype), padt.py:184). */
 int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad);
+/* bf16 → fp32 rows (token embeddings entering the fp32 residual stream; padt.py:212-219 feed HF:790-872). */
+int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D);
+/* y(bf16) = w * x * rsqrt(mean(x^2)+eps) for fp32 rows x: the norms that read the fp32 residual stream (ViT merger ln_q HF:141-148,
+ * LLM final norm HF:867). */
+int padt_rmsnorm_f32(void* stream, const void* x_f32, long ldx, const void* w, void* y, long ldy, long rows, long D, float eps);
 /* in-place fp32 sigmoid (bbox head, padt_decoder.py:164). */
 int padt_sigmoid_f32(void* stream, void* x, long n);
 /* inputs_embeds from the two-pointer table [E ‖ proto] + image-embed scatter.  padt.py:193-219, 226-229.

@@ -352,15 +352,73 @@ extern "C" int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y
     return 0;
 }
 
-__global__ void bf16_to_f32_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int D,
-                                   int sigmoid) {
-    const long total = rows * D;
+// bf16 → fp32 (16-byte loads): the token embeddings entering the fp32 residual stream of the LLM (padt_gemm_resid32).
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int vec) {
+    const long total = rows * vec;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long r = i / D;
-        const int c = (int)(i % D);
-        float v = bf2f(x[r * ldx + c]);
-        y[r * ldy + c] = sigmoid ? 1.0f / (1.0f + __expf(-v)) : v;
+        const long r = i / vec;
+        const int c = (int)(i % vec) * 8;
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(x + r * ldx + c), f);
+        float* yp = y + r * ldy + c;
+        *reinterpret_cast<f32x4*>(yp) = f32x4{f[0], f[1], f[2], f[3]};
+        *reinterpret_cast<f32x4*>(yp + 4) = f32x4{f[4], f[5], f[6], f[7]};
     }
+}
+
+extern "C" int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D) {
+    if (rows <= 0) return 0;
+    if ((D & 7) || (ldx & 7) || (ldy & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) {
+        padt_set_error("padt_cast_bf16_f32: D, ldx multiples of 8, ldy of 4, 16-byte aligned pointers");
+        return -1;
+    }
+    long blocks = (rows * (D / 8) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (float*)y, ldy,
+                       rows, (int)(D / 8));
+    PADT_CHECK_LAUNCH("cast_bf16_f32");
+    return 0;
+}
+
+// RMSNorm of fp32 rows → bf16 (the norms that read the fp32 residual stream: ViT merger ln_q HF:141-148, LLM final norm HF:867): one wave per
+// row, statistics and scaling in fp32, ONE rounding on the way out.
+__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+                                                          long ldy, int rows, int D, float eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    float ss = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        ss += v[0] * v[0] + v[1] * v[1] + v[2] * v[2] + v[3] * v[3];
+    }
+    ss = wave_sum(ss);
+    const float rstd = rsqrtf(ss / (float)D + eps);
+    bf16_t* yr = y + (long)row * ldy;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        float wv[4];
+        const u32x2 wr = *reinterpret_cast<const u32x2*>(w + c);
+        wv[0] = __builtin_bit_cast(float, wr[0] << 16);
+        wv[1] = __builtin_bit_cast(float, wr[0] & 0xffff0000u);
+        wv[2] = __builtin_bit_cast(float, wr[1] << 16);
+        wv[3] = __builtin_bit_cast(float, wr[1] & 0xffff0000u);
+        // HF:74-79 rounds the normalised value to the input dtype before the weight multiply; with an fp32 stream that rounding is fp32
+        *reinterpret_cast<u32x2*>(yr + c) = u32x2{pack2bf(v[0] * rstd * wv[0], v[1] * rstd * wv[1]), pack2bf(v[2] * rstd * wv[2], v[3] * rstd * wv[3])};
+    }
+}
+
+extern "C" int padt_rmsnorm_f32(void* stream, const void* x_f32, long ldx, const void* w, void* y, long ldy, long rows, long D, float eps) {
+    if (rows <= 0) return 0;
+    if ((D & 3) || (ldx & 3) || (ldy & 3) || ((uintptr_t)x_f32 & 15) || ((uintptr_t)y & 7) || ((uintptr_t)w & 7)) {
+        padt_set_error("padt_rmsnorm_f32: D and strides multiples of 4, x 16-byte / y, w 8-byte aligned");
+        return -1;
+    }
+    hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x_f32, ldx,
+                       (const bf16_t*)w, (bf16_t*)y, ldy, (int)rows, (int)D, eps);
+    PADT_CHECK_LAUNCH("rmsnorm_f32");
+    return 0;
 }
 
 // in-place fp32 sigmoid (bbox head's nn.Sigmoid, padt_decoder.py:164)

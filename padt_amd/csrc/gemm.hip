@@ -38,6 +38,8 @@ struct GemmArgs {
     const float* cs = nullptr;   // optional per-output-column scale applied to the accumulator before bias (fp8 weights: dequantisation scale of weight row n)
     int r_f32 = 0;               // EPI_RESID: R is fp32 [M][ldr] (fp32 residual stream; with OUT_F32)
     long lo_off = 0;             // bf16 output: also store lo = bf16(x - hi) at C + lo_off (split-precision pair, padt_gemm_bf16_ex)
+    bf16_t* C2 = nullptr;        // fp32 output: optional bf16 mirror of C (fp32 residual stream → the next projection's A operand), row-major
+    long ldc2 = 0;               //   or, with c_pack, in the fragment-packed activation layout (decode steps)
 };
 
 // bf16 split pair of 4 fp32 values: hi = bf16(x), lo = bf16(x - hi)  (hi + lo carries 16 mantissa bits)
@@ -106,7 +108,10 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) o[r] += p.r_f32 ? rf[r] : rv[r];
         }
-        if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+        if (OUT_F32) {
+            *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+            if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + act_index(m, n, p.ldc2, p.c_pack)) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        }
         else if (p.lo_off) {
             u32x2 hi, lo;
             split4(o, hi, lo);
@@ -122,8 +127,10 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         if (p.bias) x += bf2f(p.bias[n + r]);
         if (EPI == EPI_GELU) x = gelu_erf(x);
         if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
-        if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-        else {
+        if (OUT_F32) {
+            reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+            if (p.C2) p.C2[act_index(m, n + r, p.ldc2, p.c_pack)] = f2bf(x);
+        } else {
             const bf16_t h = f2bf(x);
             reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = h;
             if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(h));
@@ -245,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 
     // epilogue: acc[mi][ni][r] = C[m0 + wm*64 + mi*16 + (lane&15)][n0 + wn*64 + ni*16 + (lane>>4)*4 + r]
     const bool interior = (m0 + BM <= p.M) && (n0 + BN <= p.N);
-    if (interior && EPI != EPI_SWIGLU && !p.r_f32 && !p.lo_off && !p.cs) {
+    if (interior && EPI != EPI_SWIGLU && !p.r_f32 && !p.lo_off && !p.cs && !p.C2) {
         // block-uniform fast path: no per-fragment bounds checks; every bias / residual load is issued up front
         const int mb = m0 + wm * 64 + frow, nb = n0 + wn * 64 + fq * 4;
         u32x2 braw[4], rraw[4][4];
@@ -512,7 +519,8 @@ extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off);
+                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
+                                void* C2, long ldc2);
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -583,7 +591,7 @@ static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
 
 static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                           long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                          const void* row_scale, const RopeEpi& rope, int resid_f32 = 0, long lo_off = 0) {
+                          const void* row_scale, const RopeEpi& rope, int resid_f32 = 0, long lo_off = 0, void* C2 = nullptr, long ldc2 = 0) {
     if (M <= 0 || N <= 0) return 0;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         padt_set_error("padt_gemm_bf16: K, lda, ldw must be multiples of 8 and A, W 16-byte aligned");
@@ -607,7 +615,11 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         padt_set_error("padt_gemm_bf16_ex: a split (hi|lo) output needs bf16 output, lo_off % 4 == 0, lo_off >= N and ldc >= lo_off + N");
         return -1;
     }
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off) == 0) {
+    if (C2 && (!out_f32 || (ldc2 & 7) || ((uintptr_t)C2 & 15) || ldc2 < N)) {
+        padt_set_error("padt_gemm_resid32: the bf16 mirror needs fp32 output, ldxb % 8 == 0, ldxb >= N and a 16-byte aligned pointer");
+        return -1;
+    }
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -618,6 +630,7 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
         if (R) R = resid_f32 ? (const void*)((const float*)R + done * ldr) : (const void*)((const bf16_t*)R + done * ldr);
         if (rs) rs += done;
+        if (C2) C2 = (bf16_t*)C2 + done * ldc2;
         if (rp.cos) { rp.cos += done * rp.ld; rp.sin += done * rp.ld; }
         M -= done;
     }
@@ -627,6 +640,8 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
     a.rope = rp;
     a.r_f32 = resid_f32;
     a.lo_off = lo_off;
+    a.C2 = (bf16_t*)C2;
+    a.ldc2 = ldc2;
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: dispatch_m<EPI_NONE, false>(a, s); break;
@@ -658,6 +673,15 @@ extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const vo
                                  const void* row_scale, int resid_f32, long lo_off) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
                           RopeEpi{nullptr, nullptr, 0, 0, 0}, resid_f32, lo_off);
+}
+
+// fp32 residual stream: X32[m][n] += (A · W^T)[m][n] + bias[n] in place, and Xb = bf16(X32) (row-major mirror, may be null) — the residual
+// adds of the ViT block (HF:318-320) and the LLM layer (HF:741,757) with the stream kept in fp32 between kernels and the next projection's
+// bf16 A operand produced by the same epilogue.
+extern "C" int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx,
+                                 void* Xb, long ldxb, long M, long N, long K) {
+    return gemm_bf16_impl(stream, A, lda, W, ldw, bias, X32, ldx, X32, ldx, M, N, K, EPI_RESID, 1, nullptr,
+                          RopeEpi{nullptr, nullptr, 0, 0, 0}, 1, 0, Xb, ldxb);
 }
 
 // C = rope(row_scale[m] * (A · W^T) + bias): the rotate-half RoPE of the leading `rope_cols` output columns fused into the
@@ -700,12 +724,12 @@ extern "C" int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, flo
 }
 
 // Same kernel over the fragment-packed weight image (see include/padt_hip.h): the decode step's projections.
-template <int EPI, bool NORM, int WQ = 0>
+template <int EPI, bool NORM, int WQ = 0, bool F32 = false>
 static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
-    if (a.M <= 16) launch_skinny<1, EPI, false, NORM, true, WQ>(a, eps, s);
-    else if (a.M <= 32) launch_skinny<2, EPI, false, NORM, true, WQ>(a, eps, s);
-    else if (a.M <= 64) launch_skinny<4, EPI, false, NORM, true, WQ>(a, eps, s);
-    else launch_skinny<8, EPI, false, NORM, true, WQ>(a, eps, s);
+    if (a.M <= 16) launch_skinny<1, EPI, F32, NORM, true, WQ>(a, eps, s);
+    else if (a.M <= 32) launch_skinny<2, EPI, F32, NORM, true, WQ>(a, eps, s);
+    else if (a.M <= 64) launch_skinny<4, EPI, F32, NORM, true, WQ>(a, eps, s);
+    else launch_skinny<8, EPI, F32, NORM, true, WQ>(a, eps, s);
 }
 
 static long splitk_ticket_bytes(long N) { return (((N + 15) / 16 * 4 + 255) / 256) * 256; }
@@ -716,8 +740,13 @@ extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
 
 static int gemm_packed_impl(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
                             long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
-                            int split_k, void* workspace, int act_packed, const float* wscale) {
+                            int split_k, void* workspace, int act_packed, const float* wscale, void* Xb = nullptr, long ldxb = 0) {
     if (M <= 0 || N <= 0) return 0;
+    const bool resid32 = Xb != nullptr;          // padt_gemm_packed_resid32: C = R = fp32 row-major stream, Xb = its packed bf16 mirror
+    if (resid32 && (epilogue != EPI_RESID || (act_packed & 2) || (ldxb & 7) || ((uintptr_t)Xb & 15) || ((uintptr_t)R & 15) || R != C)) {
+        padt_set_error("padt_gemm_packed_resid32: in-place fp32 stream (16-byte aligned) and a 16-byte aligned packed mirror with ldxb % 8 == 0 required");
+        return -1;
+    }
     if (wscale && ((Kp & 63) || (N & 15) || ((uintptr_t)wscale & 15))) {
         padt_set_error("padt_gemm_packed_fp8: Kp % 64 == 0, N % 16 == 0 and 16-byte aligned scales required");
         return -1;
@@ -743,12 +772,21 @@ static int gemm_packed_impl(void* stream, const void* A, long lda, const void* W
     GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)Wp, Kp, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr, (int)M, (int)N, (int)K};
     a.a_pack = act_packed & 1;
     a.c_pack = (act_packed >> 1) & 1;
+    if (resid32) { a.r_f32 = 1; a.C2 = (bf16_t*)Xb; a.ldc2 = ldxb; a.c_pack = 1; }   // c_pack addresses the MIRROR here (R / C are fp32 row-major)
     if (split_k > 1) {
         a.ticket = reinterpret_cast<int*>(workspace);
         a.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + splitk_ticket_bytes(N));
         a.split = split_k;
     }
     hipStream_t s = (hipStream_t)stream;
+    if (resid32) {
+        a.cs = wscale;
+        if (wscale) dispatch_packed<EPI_RESID, false, 1, true>(a, 0.f, s);
+        else dispatch_packed<EPI_RESID, false, 0, true>(a, 0.f, s);
+        hipError_t e2 = hipGetLastError();
+        if (e2 != hipSuccess) { padt_set_error(hipGetErrorString(e2)); return -2; }
+        return 0;
+    }
     if (wscale) {
         a.cs = wscale;
         if (epilogue == EPI_SWIGLU) { if (norm) dispatch_packed<EPI_SWIGLU, true, 1>(a, norm_eps, s); else dispatch_packed<EPI_SWIGLU, false, 1>(a, 0.f, s); }
@@ -777,4 +815,14 @@ extern "C" int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const
     if (scales == nullptr) { padt_set_error("padt_gemm_packed_fp8: scales are required"); return -1; }
     return gemm_packed_impl(stream, A, lda, Wq, Kp, bias, C, ldc, R, ldr, M, N, K, epilogue, norm_eps, split_k, workspace, act_packed,
                             (const float*)scales);
+}
+
+// Decode-step residual projection (o_proj, down_proj: HF:741,757 at one token per row) over the fp32 residual stream:
+// X32[m][n] += scale?[n] * (A · W^T)[m][n]  in place (fp32 row-major), Xb = bf16(X32) in the fragment-packed activation layout — the A operand
+// of the next projection.  Wp: bf16 fragment-packed weights, or (scales != null) the fp8 image of padt_gemm_packed_fp8.
+extern "C" int padt_gemm_packed_resid32(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* scales, void* X32, long ldx,
+                                        void* Xb, long ldxb, long M, long N, long K, int split_k, void* workspace, int a_packed) {
+    if (Xb == nullptr) { padt_set_error("padt_gemm_packed_resid32: the packed mirror is required"); return -1; }
+    return gemm_packed_impl(stream, A, lda, Wp, Kp, nullptr, X32, ldx, X32, ldx, M, N, K, EPI_RESID, -1.0f, split_k, workspace, a_packed ? 1 : 0,
+                            (const float*)scales, Xb, ldxb);
 }

@@ -3,19 +3,18 @@
 //
 // Why a second tile kernel: the 128^2 two-barrier kernel drains its LDS-DMA at every K-step (s_waitcnt vmcnt(0) +
 // barrier) and tops out at ≈880 TFLOP/s (profiles/r01_gemm_tile_experiments.md).  This one never drains:
-//   * 8 waves (2 x 4), wave tile 128 x 64 → 64 MFMA 16x16x32 per wave per K-tile, issued as 4 PHASES of 16 (one
-//     64 x 32 quadrant each, order (m0,n0) (m0,n1) (m1,n1) (m1,n0) so one operand sub-tile stays in registers between
-//     neighbouring phases: 8 or 4 ds_read_b128 per phase instead of 12);
+//   * 8 waves (2 x 4), wave tile 128 x 64 → 64 MFMA 16x16x32 per wave per K-tile, issued as 2 PHASES of 32 (phase A: the m-half-0
+//     rows against both n-halves, phase B: the m-half-1 rows) — see the hazard table at the main loop;
 //   * LDS holds two K-tiles as 2 x 4 half-tiles of 16 KiB: A-half h = the m-half h rows of every wave, B-half h = the
 //     n-half h columns of every wave — so a half-tile is dead after the last phase that uses it and can be re-staged
 //     while the rest of its K-tile is still being multiplied;
-//   * every phase stages exactly one half-tile of a FUTURE K-tile (2 LDS-DMA pieces per wave):
-//         phase 0 → B1(t+1)   phase 1 → A1(t+1)   phase 2 → A0(t+2)   phase 3 → B0(t+2)
-//     and waits with a COUNTED s_waitcnt vmcnt(6): the three most recent half-tiles stay in flight across barriers,
-//     the data a phase reads was issued >= 5 phases (>= 1300 MFMA cycles) earlier;
-//   * a phase = load segment | raw s_barrier | 16-MFMA segment | raw s_barrier, and the two wave groups (wr = 0 / 1,
+//   * phase A stages one half-tile and phase B three half-tiles of FUTURE K-tiles (2 LDS-DMA pieces per wave per half-tile) and
+//     both wait with a COUNTED s_waitcnt (vmcnt(2) / vmcnt(6)): the youngest half-tiles stay in flight across barriers;
+//   * a phase = load segment | raw s_barrier | 32-MFMA segment | raw s_barrier, and the two wave groups (wr = 0 / 1,
 //     i.e. the two waves of every SIMD) run ONE BARRIER APART: while one multiplies, the other stages and reads LDS;
-//   * s_setprio(1) around each 16-MFMA cluster; same source-side XOR swizzle as gemm_tile_kernel (0 bank conflicts).
+//   * s_setprio(1) around each MFMA cluster; same source-side XOR swizzle as gemm_tile_kernel (0 bank conflicts).
+// (The round-1 schedule of four 16-MFMA phases and the DMA-placement variants measured against it are in the history and in
+//  profiles/r02_gemm256_experiments.md.)
 #include "common.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -34,6 +33,7 @@ struct Gemm256Args {
     int group_m;                    // tile rasterisation: ids walk down group_m tile rows, then to the next tile column
     int r_f32;                      // EPI_RESID: R is fp32 [M][ldr] (with OUT_F32)
     long lo_off;                    // bf16 output: also store lo = bf16(x - hi) at C + lo_off (padt_gemm_bf16_ex)
+    bf16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
@@ -69,18 +69,6 @@ PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, in
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off1),
                                      (__attribute__((address_space(3))) void*)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
 }
-
-PADT_DEV void dma1(const char* base, unsigned off, char* dst, int piece) {
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + off),
-                                     (__attribute__((address_space(3))) void*)(dst + piece * 1024), 16, 0, 0);
-}
-
-#ifndef PADT_PHASES2
-#define PADT_PHASES2 1     // 1 (default): two 32-MFMA phases per K-tile; 0: the round-1 schedule of four 16-MFMA phases (build-time A/B knob)
-#endif
-#ifndef PADT_DMAPOS
-#define PADT_DMAPOS 0      // where a phase issues its two LDS-DMA pieces: 0 load segment (after the ds_reads), 1 inside the MFMA
-#endif                     // segment (after the 8th MFMA), 2 one piece each.  Build-time A/B knob (profiles/r02_gemm256_experiments.md)
 
 PADT_DEV bf16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
 
@@ -135,12 +123,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         if (is_b) dma2(tileW + (long)t * (TK * 2), offB[h][0], offB[h][1], dst, wave);
         else dma2(tileA + (long)t * (TK * 2), offA[h][0], offA[h][1], dst, wave);
     };
-    auto stage_piece = [&](int t, int is_b, int h, char* dst, int i) {
-        if (is_b) dma1(tileW + (long)t * (TK * 2), offB[h][i], dst, wave * 2 + i);
-        else dma1(tileA + (long)t * (TK * 2), offA[h][i], dst, wave * 2 + i);
-    };
 
-#if PADT_PHASES2
     // ---- TWO phases of 32 MFMAs per K-tile instead of four of 16: a 16-MFMA segment is ≈270 cycles and every interval between two
     // barriers carries ≈150 cycles of synchronisation cost, so halving the barrier count is worth more than the finer DMA / ds_read
     // interleave (same-call A/B, profiles/r02_gemm256_experiments.md: 8192^3 1342 → 1437 TFLOP/s, prefill down +13 %, gate/up +5 %;
@@ -164,7 +147,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     }
     const int wr_u = __builtin_amdgcn_readfirstlane(wr);          // provably wave-uniform → scalar branch around s_barrier
     if (wr_u == 1) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(6)" ::: "memory");              // tile 0 complete (A0, B0, B1 of tile 1 may still fly)
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");  // tile 0 complete (A0, B0, B1 of tile 1 may still fly)
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");         // K == 64: only tile 0's eight pieces were issued
     __builtin_amdgcn_s_barrier();
     __builtin_amdgcn_s_barrier();                                 // both groups have waited before anyone reads tile 0
     auto phase2 = [&](int t, auto ph_tag, auto steady_tag) {
@@ -230,114 +214,6 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
             phase2(t, Q1{}, std::false_type{});
         }
     }
-#else
-    // ---- prologue: the issue order of the steady state: A0(0) B0(0) B1(0) A1(0) A0(1) B0(1)
-    stage_half(0, 0, 0, slot(smem, 0, 0, 0));
-    stage_half(0, 1, 0, slot(smem, 0, 1, 0));
-    stage_half(0, 1, 1, slot(smem, 0, 1, 1));
-    stage_half(0, 0, 1, slot(smem, 0, 0, 1));
-    if (nk > 1) {
-        stage_half(1, 0, 0, slot(smem, 1, 0, 0));
-        stage_half(1, 1, 0, slot(smem, 1, 1, 0));
-    }
-    // Stagger: the wr = 1 waves run one barrier (= half a phase) behind the wr = 0 waves, so on every SIMD (waves w and
-    // w + 4) one wave is in its 16-MFMA segment while the other stages / reads LDS.  They make up for it at the end.
-    const int wr_u = __builtin_amdgcn_readfirstlane(wr);          // provably wave-uniform → scalar branch around s_barrier
-    if (wr_u == 1) __builtin_amdgcn_s_barrier();
-    asm volatile("s_waitcnt vmcnt(4)" ::: "memory");              // tile 0 complete (A0(1), B0(1) may still fly)
-    __builtin_amdgcn_s_barrier();
-    __builtin_amdgcn_s_barrier();                                 // both groups have waited before anyone reads tile 0
-
-    // Phase PH of K-tile t = LOAD segment | barrier | 16-MFMA segment (+ counted wait) | barrier.
-    //   stage issued per phase:  0 → B1(t+1)   1 → A1(t+1)   2 → A0(t+2)   3 → B0(t+2)
-    //   (every slot is re-staged >= 2 phases after its last ds_read, every half-tile is read >= 5 phases after its issue:
-    //    both survive the half-phase lag between the two wave groups)
-    //   LDS reads per phase:     0 → A m-half 0 (8) + B n-half 0 (4)   1 → B n-half 1 (4)   2 → A m-half 1 (8)   3 → none
-    auto phase = [&](int t, auto ph_tag, auto steady_tag) {
-        constexpr int PH = decltype(ph_tag)::value;
-        constexpr bool STEADY = decltype(steady_tag)::value;
-        const int par = t & 1;
-        constexpr int MH = (PH >= 2) ? 1 : 0;                     // quadrant order (0,0) (0,1) (1,1) (1,0)
-        constexpr int NH = (PH == 1 || PH == 2) ? 1 : 0;
-        auto stage = [&]() {
-            if (PH == 0) { if (STEADY || t + 1 < nk) stage_half(t + 1, 1, 1, slot(smem, par ^ 1, 1, 1)); }
-            if (PH == 1) { if (STEADY || t + 1 < nk) stage_half(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1)); }
-            if (PH == 2) { if (STEADY || t + 2 < nk) stage_half(t + 2, 0, 0, slot(smem, par, 0, 0)); }
-            if (PH == 3) { if (STEADY || t + 2 < nk) stage_half(t + 2, 1, 0, slot(smem, par, 1, 0)); }
-        };
-        auto stage1 = [&](int i) {                                // one of the phase's two pieces
-            if (PH == 0) { if (STEADY || t + 1 < nk) stage_piece(t + 1, 1, 1, slot(smem, par ^ 1, 1, 1), i); }
-            if (PH == 1) { if (STEADY || t + 1 < nk) stage_piece(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1), i); }
-            if (PH == 2) { if (STEADY || t + 2 < nk) stage_piece(t + 2, 0, 0, slot(smem, par, 0, 0), i); }
-            if (PH == 3) { if (STEADY || t + 2 < nk) stage_piece(t + 2, 1, 0, slot(smem, par, 1, 0), i); }
-        };
-        if (PH == 0) {
-            const char* bh = slot(smem, par, 1, 0);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) b0[i][kk] = rd(bh, wc * 32 + i * 16 + frow, kk * 4 + fq);
-        }
-        if (PH == 1) {
-            const char* bh = slot(smem, par, 1, 1);
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) b1[i][kk] = rd(bh, wc * 32 + i * 16 + frow, kk * 4 + fq);
-        }
-        if (PH == 0 || PH == 2) {
-            const char* ah = slot(smem, par, 0, MH);
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, kk * 4 + fq);
-        }
-        __builtin_amdgcn_sched_barrier(0);                        // ds_reads are issued BEFORE the LDS-DMA pieces (measured +4-8 %:
-        if (PADT_DMAPOS == 0) stage();                            // the reads' latency hides behind the DMA issue cost)
-        if (PADT_DMAPOS == 2) stage1(0);
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        __builtin_amdgcn_sched_barrier(0);
-        __builtin_amdgcn_s_setprio(1);
-#pragma unroll
-        for (int kk = 0; kk < 2; ++kk) {
-#pragma unroll
-            for (int i = 0; i < MF; ++i)
-#pragma unroll
-                for (int j = 0; j < 2; ++j)
-                    acc[MH * MF + i][NH * 2 + j] = mfma16(NH ? b1[j][kk] : b0[j][kk], af[i][kk], acc[MH * MF + i][NH * 2 + j]);
-            if (kk == 0 && PADT_DMAPOS != 0) {                    // experiment: DMA issue in the shadow of the MFMA queue
-                __builtin_amdgcn_sched_barrier(0);
-                if (PADT_DMAPOS == 1) stage(); else stage1(1);
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        }
-        __builtin_amdgcn_s_setprio(0);
-        // retire this wave's DMA pieces of everything up to 4 stages back: the NEXT-BUT-ONE load segment reads them after
-        // two more barriers, by which time the lagging group has executed the same wait
-        if (STEADY) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        asm volatile("" ::: "memory");
-    };
-    using P0 = std::integral_constant<int, 0>;
-    using P1 = std::integral_constant<int, 1>;
-    using P2 = std::integral_constant<int, 2>;
-    using P3 = std::integral_constant<int, 3>;
-    int t = 0;
-    for (; t + 2 < nk; ++t) {                                     // steady state: every phase issues a stage
-        phase(t, P0{}, std::true_type{});
-        phase(t, P1{}, std::true_type{});
-        phase(t, P2{}, std::true_type{});
-        phase(t, P3{}, std::true_type{});
-    }
-    for (; t < nk; ++t) {                                         // last two K-tiles: stages run out → drain instead of count
-        phase(t, P0{}, std::false_type{});
-        phase(t, P1{}, std::false_type{});
-        phase(t, P2{}, std::false_type{});
-        phase(t, P3{}, std::false_type{});
-    }
-#endif
     if (wr_u == 0) __builtin_amdgcn_s_barrier();                  // matches the extra barrier of the lagging group
 
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
@@ -352,6 +228,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     if (n0 + TN <= p.N) {
         // bf16 tiles leave through LDS (free after the main loop) so that the global stores are whole 512-byte rows
         const bool wide = !OUT_F32 && EPI != EPI_SWIGLU && p.lo_off == 0 && (reinterpret_cast<unsigned long>(p.C) & 15) == 0 && (p.ldc & 7) == 0;
+        const bool mirror = OUT_F32 && p.C2 != nullptr;           // fp32 tile to C, its bf16 image through LDS to C2 (16-byte aligned, ldc2 % 8: checked by the host)
         const int nb = n0 + wc * 64 + fq * 4;                     // this lane's first column of fragment column ni: nb + 16 * ni
         const int mb = m0 + wr * (32 * MF) + frow;                // this lane's row of fragment row mi: mb + 16 * mi
         float bv[4][4];
@@ -439,6 +316,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         const long off = (long)m * p.ldc + nb + ni * 16;
                         if (OUT_F32) {
                             if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
+                            if (mirror) *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
+                                u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                         } else if (wide) {                        // bf16 tile → LDS in row-major order, written out as full rows below
                             *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
                                 u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
@@ -459,7 +338,9 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         if (EPI == EPI_NONE && p.rope.cos != nullptr) run(std::true_type{}, std::false_type{});
         else if (EPI == EPI_RESID && OUT_F32 && p.r_f32) run(std::false_type{}, std::true_type{});
         else run(std::false_type{}, std::false_type{});
-        if (wide) {
+        if (wide || mirror) {
+            bf16_t* cw = mirror ? p.C2 : reinterpret_cast<bf16_t*>(p.C);
+            const long ldw_out = mirror ? p.ldc2 : p.ldc;
             // 8-byte fragment stores put 16 x 32-byte pieces on the wire per instruction and cost 4-8 us per tile in the memory system
             // (same instruction count into one 512-byte region: 1.5 us); full 512-byte rows, 16 bytes per lane, do not.
             __syncthreads();
@@ -468,7 +349,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
             for (int it = 0; it < 4 * MF; ++it) {
                 const int row = wave * (8 * MF) + it * 2 + (lane >> 5);
                 const u32x4 v = *reinterpret_cast<const u32x4*>(smem + row * OUT_PITCH + c16 * 16);
-                if (m0 + row < p.M) *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(p.C) + (long)(m0 + row) * p.ldc + n0 + c16 * 8) = v;
+                if (m0 + row < p.M) *reinterpret_cast<u32x4*>(cw + (long)(m0 + row) * ldw_out + n0 + c16 * 8) = v;
             }
         }
         return;
@@ -503,8 +384,10 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         if (p.bias) x += bf2f(p.bias[n + r]);
                         if (EPI == EPI_GELU) x = gelu_erf(x);
                         if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
-                        if (OUT_F32) reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-                        else {
+                        if (OUT_F32) {
+                            reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
+                            if (p.C2) p.C2[(long)m * p.ldc2 + n + r] = f2bf(x);
+                        } else {
                             const bf16_t hb = f2bf(x);
                             reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = hb;
                             if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(hb));
@@ -534,8 +417,10 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
                     for (int r = 0; r < 4; ++r) o[r] += p.r_f32 ? rf[r] : rv[r];
                 }
-                if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
-                else {
+                if (OUT_F32) {
+                    *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
+                    if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + (long)m * p.ldc2 + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                } else {
                     const u32x2 hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                     bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
                     *reinterpret_cast<u32x2*>(cp) = hi;
@@ -590,6 +475,21 @@ static Plan256 plan256(long M, long N, long K, int force_mf, bool allow_peel, bo
     return best;
 }
 
+// Dispatch knobs (tests force every tile variant): read from the environment ONCE when the library is loaded; tests and tools that A/B a
+// variant inside one process call padt_gemm_knobs() instead.  -1 keeps a field.
+struct Knobs256 { int mode, mf, peel, colsplit, group_m; };
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+static Knobs256 g_knobs = {env_int("PADT_GEMM256", 1), env_int("PADT_GEMM_MF", 0), env_int("PADT_GEMM_PEEL", 1), env_int("PADT_GEMM_COLSPLIT", 1),
+                           env_int("PADT_GEMM_GROUP_M", 8)};
+extern "C" int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m) {
+    if (mode256 >= 0) g_knobs.mode = mode256;
+    if (mf >= 0) g_knobs.mf = mf;
+    if (peel >= 0) g_knobs.peel = peel;
+    if (colsplit >= 0) g_knobs.colsplit = colsplit;
+    if (group_m >= 1) g_knobs.group_m = group_m;
+    return 0;
+}
+
 template <int EPI, bool F32>
 static void run256(Gemm256Args a, int mf, hipStream_t s) {
     if (mf == 4) launch256_mf<EPI, F32, 4>(a, s);
@@ -602,13 +502,10 @@ static void run256(Gemm256Args a, int mf, hipStream_t s) {
 // tiles (222 of them) — two launches, 6 + 0.68 round-equivalents instead of 7.
 template <int EPI, bool F32>
 static long launch256(Gemm256Args a, hipStream_t s) {
-    const char* fe = getenv("PADT_GEMM_MF");                      // tuning / test knobs, read per call
-    const int force = fe ? atoi(fe) : 0;
-    const char* pe = getenv("PADT_GEMM_PEEL");
-    const bool allow_peel = pe ? atoi(pe) != 0 : true;            // 0 never, 1 cost model (default), 2 always when a tail exists (tests)
-    const bool force_peel = pe && atoi(pe) == 2;
-    const char* ce = getenv("PADT_GEMM_COLSPLIT");                // 0 never, 1 cost model (default), >= 2: always peel that many tile columns (tests)
-    const int colsplit = ce ? atoi(ce) : 1;
+    const int force = g_knobs.mf;
+    const bool allow_peel = g_knobs.peel != 0;                    // 0 never, 1 cost model (default), 2 always when a tail exists (tests)
+    const bool force_peel = g_knobs.peel == 2;
+    const int colsplit = g_knobs.colsplit;                        // 0 never, 1 cost model (default), >= 2: always peel that many tile columns (tests)
     const long ntn = (a.N + TN - 1) / TN;
     const Plan256 whole = plan256(a.M, a.N, a.K, force, allow_peel, force_peel);
     long split_cols = 0;
@@ -637,6 +534,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     if (a.bias) a2.bias = a.bias + n1;
     a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((bf16_t*)a.C + c1);
     if (a.R) a2.R = a.r_f32 ? (const bf16_t*)((const float*)a.R + c1) : a.R + c1;
+    if (a.C2) a2.C2 = a.C2 + c1;
     run256<EPI, F32>(a1, pm.mf, s);
     run256<EPI, F32>(a2, pr.mf, s);
     return a.M;
@@ -647,8 +545,9 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 // *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off) {
-    static const int mode = getenv("PADT_GEMM256") ? atoi(getenv("PADT_GEMM256")) : 1;      // 0 off, 1 auto, 2 force
+                                const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
+                                void* C2, long ldc2) {
+    const int mode = g_knobs.mode;                                // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
         // auto: measured on MI355X (profiles/r01_gemm_tile_experiments.md) the phase-pipelined kernel wins or ties on every
@@ -657,9 +556,9 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
         if (M < 512 || N < 512 || K < 512) return 1;
     }
     if (K % TK) return 1;                                         // no K-tail path in this kernel
-    static const int group_m = getenv("PADT_GEMM_GROUP_M") ? atoi(getenv("PADT_GEMM_GROUP_M")) : 8;   // tuning knob
+    const int group_m = g_knobs.group_m;
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;

@@ -160,6 +160,7 @@ class DecodeSession:
         B16 = (B + 15) // 16 * 16
         self.x = z(B16, D)
         self.x_rm = z(B, D)
+        self.x32 = z(B, D, dt=torch.float32) if W.resid_f32 else None     # fp32 residual stream of the decode step (x is its packed bf16 mirror)
         self.n = z(B, D)
         self.qkv = z(B, (cfg.num_attention_heads + 2 * Hkv) * hd)
         self.q = z(B, cfg.num_attention_heads * hd)
@@ -186,6 +187,9 @@ class DecodeSession:
         B = self.B
         ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x_rm, err_flag=self.err)
         ops.pack_rows(self.x_rm, self.x, B, to_packed=True)
+        f32 = self.x32 is not None
+        if f32:
+            ops.cast_bf16_f32(self.x_rm, out=self.x32)
         ops.rope_table(self.pos3, self.inv_freq, self.rope_cs, hd, cfg.mrope_section)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
@@ -195,25 +199,42 @@ class DecodeSession:
                                     norm_eps=cfg.rms_norm_eps, a_packed=True, rows=B)
                 ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
                                      hd, self.s_max, self.s_max, out_packed=True)
-                ops.gemm_packed_fp8(self.att, W[p + "o.wq"], W[p + "o.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                                    split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+                if f32:
+                    ops.gemm_packed_resid32(self.att, W[p + "o.wq"], D, self.x32, self.x, scales=W[p + "o.ws"], split_k=self.o_split,
+                                            workspace=self.splitk_ws, rows=B)
+                else:
+                    ops.gemm_packed_fp8(self.att, W[p + "o.wq"], W[p + "o.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                        split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
                 ops.gemm_packed_fp8(self.x, W[p + "gu.wq"], W[p + "gu.ws"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU,
                                     norm_eps=cfg.rms_norm_eps, a_packed=True, c_packed=True, rows=B)
-                ops.gemm_packed_fp8(self.h, W[p + "down.wq"], W[p + "down.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                                    split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+                if f32:
+                    ops.gemm_packed_resid32(self.h, W[p + "down.wq"], D, self.x32, self.x, scales=W[p + "down.ws"], split_k=self.down_split,
+                                            workspace=self.splitk_ws, rows=B)
+                else:
+                    ops.gemm_packed_fp8(self.h, W[p + "down.wq"], W[p + "down.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                        split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
                 continue
             ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps,
                             a_packed=True, rows=B)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
                                  hd, self.s_max, self.s_max, out_packed=True)
-            ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                            split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+            if f32:
+                ops.gemm_packed_resid32(self.att, W[p + "o.wp"], D, self.x32, self.x, split_k=self.o_split, workspace=self.splitk_ws, rows=B)
+            else:
+                ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
             ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps,
                             a_packed=True, c_packed=True, rows=B)
-            ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
-                            split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
-        ops.pack_rows(self.x, self.x_rm, B, to_packed=False)
-        ops.rmsnorm(self.x_rm, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
+            if f32:
+                ops.gemm_packed_resid32(self.h, W[p + "down.wp"], D, self.x32, self.x, split_k=self.down_split, workspace=self.splitk_ws, rows=B)
+            else:
+                ops.gemm_packed(self.h, W[p + "down.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
+                                split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
+        if f32:
+            ops.rmsnorm_f32(self.x32, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
+        else:
+            ops.pack_rows(self.x, self.x_rm, B, to_packed=False)
+            ops.rmsnorm(self.x_rm, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
         self.head_and_select(self.hn, advance=True)
 
     def head_and_select(self, hn, advance: bool):
@@ -297,6 +318,7 @@ class LanguageModel:
         dev = image_embeds.device
         bf = torch.bfloat16
         x = ops.embed_tokens(plan.ids, plan.img_index, W["llm.embed"], sess.proto, image_embeds, err_flag=sess.err)
+        x32 = ops.cast_bf16_f32(x) if W.resid_f32 else None      # fp32 residual stream; x stays its bf16 mirror
         n = torch.empty_like(x)
         rstd = torch.empty((T,), device=dev, dtype=torch.float32)
         qkv = torch.empty((T, (Hq + 2 * Hkv) * hd), device=dev, dtype=bf)
@@ -312,8 +334,16 @@ class LanguageModel:
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
-            ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
+            if x32 is not None:
+                ops.gemm_resid32(att, W[p + "o.w"], None, x32, x)
+            else:
+                ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
             ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)                # norm weight is folded into gu.w
             ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
-            ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
+            if x32 is not None:
+                ops.gemm_resid32(h, W[p + "down.w"], None, x32, x)
+            else:
+                ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
+        if x32 is not None:
+            return ops.rmsnorm_f32(x32, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)
         return ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)

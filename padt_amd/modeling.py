@@ -391,6 +391,8 @@ class PaDTForConditionalGeneration:
                 obj_sample.append(si)
                 n_vp.append(int(f.shape[0]))
         feats_cat = torch.cat([f.to(dev, torch.bfloat16) for f in flat], dim=0).contiguous()
+        if not self.W.dec_hp and high_res_image_embeds.dtype == torch.float32:      # the bf16-storage decoder (PADT_DECODER_HP=0) reads bf16 rows
+            high_res_image_embeds = ops.cast_f32_bf16(high_res_image_embeds.contiguous())
         bbox, score, masks, hw = self.vl_decoder.forward_objects(
             feats_cat, n_vp, low_res_image_embeds, high_res_image_embeds, visual_pes, obj_sample, patch_off, patch_num, grids)
         return {"pred_boxes": bbox, "pred_score": score, "pred_mask": masks, "pred_mask_valid_hw": hw,

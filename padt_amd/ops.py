@@ -56,6 +56,25 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     return out
 
 
+def gemm_resid32(a, w, bias, x32, xb=None):
+    """fp32 residual stream: x32[M,N] += a @ w^T + bias (in place); xb = bf16(x32) is the next projection's A operand."""
+    lib = _lib.load()
+    _chk_bf16(a, w, bias, xb)
+    M, K = a.shape
+    N = w.shape[0]
+    assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and x32.shape[0] >= M and x32.shape[1] >= N
+    if GEMM_LOG is not None:
+        GEMM_LOG.append(("r32", a, w, bias, x32, xb))
+    _lib.check(lib.padt_gemm_resid32(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
+                                     xb.stride(0) if xb is not None else 0, M, N, K), "padt_gemm_resid32")
+    return x32
+
+
+def gemm_knobs(mode256=-1, mf=-1, peel=-1, colsplit=-1, group_m=-1):
+    """Dispatch knobs of the 256-row tile kernel (tests / tuning tools); -1 keeps a field.  Defaults: (1, 0, 1, 1, 8)."""
+    _lib.check(_lib.load().padt_gemm_knobs(int(mode256), int(mf), int(peel), int(colsplit), int(group_m)), "padt_gemm_knobs")
+
+
 def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
     """out = rope(row_scale[m] * (a @ w^T) + bias) with the leading rope_cols columns pair-interleaved per head (see
     weights.interleave_rope_rows): the ViT qkv projection with RoPE fused into the epilogue."""
@@ -170,6 +189,21 @@ def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None,
                                          -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace),
                                          (1 if a_packed else 0) | (2 if c_packed else 0)), "padt_gemm_packed_bf16")
     return out
+
+
+def gemm_packed_resid32(a, wp, n, x32, xb_packed, scales=None, split_k=1, workspace=None, a_packed=True, rows=None):
+    """Decode-step residual projection over the fp32 stream: x32[rows, n] += scales?[n] * (a @ w^T) in place, xb_packed = bf16(x32) in the
+    fragment-packed activation layout.  wp: pack_weight() image, or with scales the fp8 image."""
+    lib = _lib.load()
+    _chk_bf16(a, xb_packed)
+    M, K = a.shape
+    if rows is not None:
+        M = rows
+    assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and (scales is None or scales.dtype == torch.float32)
+    _lib.check(lib.padt_gemm_packed_resid32(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(scales), _p(x32), x32.stride(0),
+                                            _p(xb_packed), xb_packed.stride(0), M, n, K, int(split_k), _p(workspace), 1 if a_packed else 0),
+               "padt_gemm_packed_resid32")
+    return x32
 
 
 def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None, rope=None):
@@ -293,6 +327,27 @@ def cast_f32_bf16(x, D_pad=None, out=None):
         out = torch.empty((x.shape[0], D_pad), device=x.device, dtype=BF16)
     _lib.check(lib.padt_cast_f32_bf16(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], D, D_pad),
                "padt_cast_f32_bf16")
+    return out
+
+
+def cast_bf16_f32(x, out=None):
+    lib = _lib.load()
+    _chk_bf16(x)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
+    _lib.check(lib.padt_cast_bf16_f32(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1]), "padt_cast_bf16_f32")
+    return out
+
+
+def rmsnorm_f32(x32, w, out=None, eps=1e-6):
+    """bf16 RMSNorm of fp32 rows (the norms that read the fp32 residual stream)."""
+    lib = _lib.load()
+    _chk_bf16(w)
+    assert x32.dtype == torch.float32 and x32.stride(-1) == 1
+    if out is None:
+        out = torch.empty(x32.shape, device=x32.device, dtype=BF16)
+    _lib.check(lib.padt_rmsnorm_f32(_stream(), _p(x32), x32.stride(0), _p(w), _p(out), out.stride(0), x32.shape[0], x32.shape[1], float(eps)),
+               "padt_rmsnorm_f32")
     return out
 
 

@@ -92,9 +92,11 @@ class VisionEncoder:
             torch.cuda.current_stream().synchronize()        # tables are shared by every stream that runs this grid later
         return self._plans[key]
 
-    def block(self, i: int, x, plan: VisionPlan, rstd, qkv, att, hbuf, force_full=None):
+    def block(self, i: int, x, plan: VisionPlan, rstd, qkv, att, hbuf, force_full=None, x32=None):
         """One ViT block in place on x (P, vh): x += proj(attn(rope(qkv(RMSNorm(x))))); x += down(SwiGLU(RMSNorm(x)))
-        (HF:297-321).  Window segments except for the full-attention layers (padt.py:89-93)."""
+        (HF:297-321).  Window segments except for the full-attention layers (padt.py:89-93).
+        x32 given: the residual stream is the fp32 tensor x32, updated in place by the residual GEMMs' epilogues, and x is its bf16
+        mirror (the A operand of the qkv / gate-up GEMMs), rewritten by the same epilogues."""
         cfg, W = self.cfg, self.W
         v = cfg.vision_config
         vh, H = v.hidden_size, v.num_heads
@@ -111,10 +113,16 @@ class VisionEncoder:
             ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)
         ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
-        ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
+        if x32 is not None:
+            ops.gemm_resid32(att, W[p + "proj.w"], W[p + "proj.b"], x32, x)
+        else:
+            ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
         ops.row_rstd(x, out=rstd)
         ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
-        ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
+        if x32 is not None:
+            ops.gemm_resid32(hbuf, W[p + "down.w"], W[p + "down.b"], x32, x)
+        else:
+            ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
 
     def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):
         """pixel_values (P, C*T*p*p) fp32 or bf16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
@@ -126,17 +134,26 @@ class VisionEncoder:
         if pixel_values.shape[0] != P:
             raise ValueError(f"pixel_values has {pixel_values.shape[0]} rows, image_grid_thw implies {P}")
         pix = pixel_values if pixel_values.dtype == torch.bfloat16 else ops.cast_f32_bf16(pixel_values.float().contiguous())
-        x0 = ops.gemm(pix, W["vit.patch_embed"])                               # conv3d-as-GEMM (HF:116-122)
-        x = ops.gather_rows(x0, plan.patch_perm)                               # window order
+        f32 = W.resid_f32
+        x0 = ops.gemm(pix, W["vit.patch_embed"], out_f32=f32)                  # conv3d-as-GEMM (HF:116-122)
+        x32 = None
+        if f32:                                                                # fp32 residual stream + its bf16 mirror
+            x32 = ops.gather_rows(x0, plan.patch_perm)                         # window order
+            x = ops.cast_f32_bf16(x32)
+        else:
+            x = ops.gather_rows(x0, plan.patch_perm)
         n = torch.empty_like(x)
         rstd = torch.empty((P,), device=x.device, dtype=torch.float32)
         qkv = torch.empty((P, 3 * vh), device=x.device, dtype=x.dtype)
         att = torch.empty_like(x)
         hbuf = torch.empty((P, W.vit_ipad), device=x.device, dtype=x.dtype)
         for i in range(v.depth):
-            self.block(i, x, plan, rstd, qkv, att, hbuf)
-        high = x
-        ops.rmsnorm(x, W["vit.merger.ln_q"], out=n)
+            self.block(i, x, plan, rstd, qkv, att, hbuf, x32=x32)
+        high = x32 if f32 else x                                               # the PaDT decoder reads fp32 or bf16 rows
+        if f32:
+            ops.rmsnorm_f32(x32, W["vit.merger.ln_q"], out=n)
+        else:
+            ops.rmsnorm(x, W["vit.merger.ln_q"], out=n)
         m = ops.gemm(n.view(plan.N, vh * cfg.merge_unit), W["vit.merger.0.w"], W["vit.merger.0.b"], epilogue=ops.EPI_GELU)
         low_win = ops.gemm(m, W["vit.merger.2.w"], W["vit.merger.2.b"])
         low = ops.gather_rows(low_win, plan.reverse)                           # raster order (padt.py:103-104)

@@ -204,6 +204,7 @@ class PreparedWeights(dict):
     dec_ipad: int
     dec_hp: bool = False
     llm_weights: str = "bf16"
+    resid_f32: bool = True
 
 
 def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16") -> PreparedWeights:
@@ -215,6 +216,9 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
     dev = torch.device(device)
     W = PreparedWeights()
     W.llm_weights = llm_weights
+    # fp32 residual streams in the ViT and the LLM (default; PADT_RESID_F32=0 keeps the round-2 bf16 streams for A/B runs): the
+    # residual GEMMs' epilogues update an fp32 stream in place and emit its bf16 mirror for the next projection
+    W.resid_f32 = os.environ.get("PADT_RESID_F32", "1") != "0"
 
     def put(name, t):
         W[name] = t.to(device=dev, dtype=BF16).contiguous()

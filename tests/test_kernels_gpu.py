@@ -25,6 +25,13 @@ def ops():
     return _ops
 
 
+@pytest.fixture
+def knobs(ops):
+    """Force a dispatch variant of the 256-row tile kernel for one test (padt_gemm_knobs), defaults restored afterwards."""
+    yield ops.gemm_knobs
+    ops.gemm_knobs(mode256=1, mf=0, peel=1, colsplit=1, group_m=8)
+
+
 def rnd(*shape, scale=1.0, seed=0):
     g = torch.Generator(device="cpu").manual_seed(seed + sum(shape))
     return (torch.randn(*shape, generator=g) * scale).to(BF).cuda()
@@ -71,10 +78,10 @@ def test_gemm_plain_bias(ops, M, N, K):
 
 @pytest.mark.parametrize("mf", [2, 3, 4])
 @pytest.mark.parametrize("M,N,K", [(1000, 1280, 1280), (577, 768, 512), (2116, 512, 3456)])
-def test_gemm_tile256_heights(ops, mf, M, N, K, monkeypatch):
+def test_gemm_tile256_heights(ops, mf, M, N, K, knobs):
     """The phase-pipelined kernel at every tile height (128 / 192 / 256 rows x 256 columns): ragged M and N tails, all
     epilogues, f32 output."""
-    monkeypatch.setenv("PADT_GEMM_MF", str(mf))
+    knobs(mf=mf)
     a, w, b, r = rnd(M, K, seed=41), rnd(N, K, scale=0.05, seed=42), rnd(N, seed=43), rnd(M, N, seed=44)
     lin = a.float() @ w.float().T + b.float()
     close_bf16(ops.gemm(a, w, b), lin, f"mf{mf} plain {M}x{N}x{K}")
@@ -94,15 +101,15 @@ def test_gemm_tile256_heights(ops, mf, M, N, K, monkeypatch):
 
 
 @pytest.mark.parametrize("mf", [3, 4])
-def test_gemm_tile256_peeled_tail(ops, mf, monkeypatch):
+def test_gemm_tile256_peeled_tail(ops, mf, knobs):
     """Ragged last tile row (<= 64 rows) peeled off to the skinny kernel: same results as the un-peeled launch."""
-    monkeypatch.setenv("PADT_GEMM_MF", str(mf))
+    knobs(mf=mf)
     M, N, K = 2 * 64 * mf + 24, 1024, 640
     a, w, b, r = rnd(M, K, seed=45), rnd(N, K, scale=0.05, seed=46), rnd(N, seed=47), rnd(M, N, seed=48)
     wi = interleave_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous())
     outs = {}
     for peel in ("0", "2"):
-        monkeypatch.setenv("PADT_GEMM_PEEL", peel)
+        knobs(peel=int(peel))
         o1 = r.clone()
         ops.gemm(a, w, b, out=o1, epilogue=ops.EPI_RESID, residual=o1)
         o32 = torch.zeros((M, N), device="cuda", dtype=torch.float32)
@@ -138,7 +145,7 @@ def test_gemm_row_scale_is_folded_rmsnorm(ops, M, N, K):
         close_bf16(ops.gemm(x, wi, bi, epilogue=ops.EPI_SWIGLU, row_scale=rstd), ref, f"row_scale swiglu {M}x{N}x{K}")
 
 
-def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
+def test_gemm_tile256_column_split_is_bit_identical(ops, knobs):
     """Column-split dispatch (last tile columns as a second launch with its own tile height) == the single launch."""
     M, N, K = 1100, 1536, 640
     a, w, b, r = rnd(M, K, seed=55), rnd(N, K, scale=0.05, seed=56), rnd(N, seed=57), rnd(M, N, seed=58)
@@ -146,7 +153,7 @@ def test_gemm_tile256_column_split_is_bit_identical(ops, monkeypatch):
     rstd = ops.row_rstd(a)
     outs = {}
     for cs in ("0", "2", "3"):
-        monkeypatch.setenv("PADT_GEMM_COLSPLIT", cs)
+        knobs(colsplit=int(cs))
         o1 = r.clone()
         ops.gemm(a, w, b, out=o1, epilogue=ops.EPI_RESID, residual=o1)
         o32 = torch.zeros((M, N), device="cuda", dtype=torch.float32)
@@ -198,7 +205,7 @@ def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi,
 
 
 @pytest.mark.parametrize("M,K", [(1000, 640), (40, 256), (2 * 256 + 24, 512), (300, 136)])
-def test_gemm_rope_epilogue(ops, M, K, monkeypatch):
+def test_gemm_rope_epilogue(ops, M, K, knobs):
     """qkv projection with RoPE fused into the epilogue (pair-interleaved q/k rows) vs Linear → rotate-half RoPE in fp32 on the
     ORIGINAL layout, compared after undoing the permutation; every kernel family (phase kernel, 128^2, skinny, peeled tail)."""
     from padt_amd.weights import interleave_rope_rows
@@ -216,8 +223,8 @@ def test_gemm_rope_epilogue(ops, M, K, monkeypatch):
     ref[:, : 2 * H * D] = (qk * cos[:, None] + rot * sin[:, None]).reshape(M, -1)
     wi, bi = interleave_rope_rows(w, 2 * H, D), interleave_rope_rows(b, 2 * H, D)
     if M == 2 * 256 + 24:
-        monkeypatch.setenv("PADT_GEMM_PEEL", "2")
-        monkeypatch.setenv("PADT_GEMM_MF", "4")
+        knobs(peel=2)
+        knobs(mf=4)
     out = torch.zeros(M, N, device="cuda", dtype=BF)
     ops.gemm_rope(x, wi, bi, out, cos, sin, 2 * H * D, D, row_scale=rstd)
     # undo the pair interleave of the q / k columns: column 2i <- d = i, column 2i + 1 <- d = i + D/2
@@ -912,3 +919,67 @@ def test_gemm_packed_fp8_weights(ops, M, N, K):
         ops.pack_rows(hp, un, M, to_packed=False)
         y = (lin * rstd + b.float()).view(M, N // 32, 2, 16)
         close_bf16(un, (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, N // 2), f"fp8 SwiGLU {M}x{N}x{K}")
+
+
+# ------------------------------------------------------------------------------------------------ fp32 residual stream
+@pytest.mark.parametrize("M,N,K", [(1000, 1280, 1280), (16928 // 8, 1280, 3456), (577, 2048, 2048), (300, 200, 136), (40, 640, 512), (2 * 256 + 24, 768, 640)])
+def test_gemm_resid32_stream_and_mirror(ops, M, N, K, knobs):
+    """padt_gemm_resid32 on every kernel family (256-row phase kernel incl. the wide mirror write-out, 128^2 kernel with ragged tiles,
+    skinny kernel, peeled tail): x32 += a w^T + b within fp32 accumulation noise, the mirror is EXACTLY bf16(x32) (one rounding)."""
+    if M == 2 * 256 + 24:
+        knobs(peel=2, mf=4)
+    a, w, b = rnd(M, K, seed=91), rnd(N, K, scale=0.05, seed=92), rnd(N, seed=93)
+    x0 = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(94)) * 3
+    ld = (N + 7) // 8 * 8
+    x32 = torch.zeros(M, ld, device="cuda")
+    x32[:, :N] = x0
+    xb = torch.full((M, ld), 7.0, device="cuda", dtype=BF)
+    ops.gemm_resid32(a, w, b, x32[:, :N], xb[:, :N])
+    ref = x0 + a.float() @ w.float().T + b.float()
+    close_f32(x32[:, :N], ref, f"resid32 {M}x{N}x{K}", rel=3e-5)
+    assert torch.equal(xb[:, :N], x32[:, :N].to(BF)), "mirror != bf16(stream)"
+    if ld != N:
+        assert (xb[:, N:] == 7.0).all() and (x32[:, N:] == 0).all(), "wrote outside N"
+    y = x32.clone()
+    ops.gemm_resid32(a, w, None, y[:, :N], None)                       # no mirror, no bias
+    close_f32(y[:, :N], x32[:, :N] + a.float() @ w.float().T, "resid32 without mirror", rel=3e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(8, 2048, 2048), (64, 2048, 11008), (21, 704, 512), (128, 3584, 3584)])
+def test_gemm_packed_resid32(ops, M, N, K):
+    """Decode-step residual projection over the fp32 stream: same accumulator bits as the bf16-stream kernel (the fp32 result rounds to
+    what that kernel stores when the residual is bf16-representable), packed mirror == bf16(stream), bf16 and fp8 weights, split-K."""
+    x = rnd(M, K, seed=95)
+    w, r = rnd(N, K, scale=0.05, seed=96), rnd(M, N, seed=97)
+    wp = ops.pack_weight(w)
+    M16 = (M + 15) // 16 * 16
+    xp = torch.zeros(M16, K, device="cuda", dtype=BF)
+    ops.pack_rows(x, xp, M, to_packed=True)
+    ws = ops.new_splitk_workspace(N, 2, "cuda")
+    old = r.clone()
+    ops.gemm_packed(x, wp, N, out=old, epilogue=ops.EPI_RESID, residual=old)
+    for split in (1, 2):
+        x32 = r.float().contiguous()
+        mir = torch.zeros(M16, N, device="cuda", dtype=BF)
+        ops.gemm_packed_resid32(xp, wp, N, x32, mir, split_k=split, workspace=ws, rows=M)
+        close_f32(x32, r.float() + x.float() @ w.float().T, f"packed resid32 split {split}", rel=3e-5)
+        un = torch.zeros(M, N, device="cuda", dtype=BF)
+        ops.pack_rows(mir, un, M, to_packed=False)
+        assert torch.equal(un, x32.to(BF)), "packed mirror != bf16(stream)"
+        if split == 1:
+            assert torch.equal(un, old), "fp32-stream kernel and bf16-stream kernel disagree on the same operands"
+    q, sc, deq = ops.quantize_fp8_rows(w)
+    if N % 16 == 0 and K % 8 == 0:
+        x32 = r.float().contiguous()
+        mir = torch.zeros(M16, N, device="cuda", dtype=BF)
+        ops.gemm_packed_resid32(xp, ops.pack_weight_fp8(q), N, x32, mir, scales=sc, rows=M)
+        close_f32(x32, r.float() + x.float() @ deq.float().T, "packed resid32 fp8", rel=3e-5)
+
+
+def test_cast_bf16_f32_and_rmsnorm_f32(ops):
+    x = rnd(77, 2048, seed=98)
+    assert torch.equal(ops.cast_bf16_f32(x), x.float())
+    x32 = torch.randn(77, 1280, device="cuda") * 2
+    w = rnd(1280, seed=99) * 0.1 + 1
+    ref = x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()
+    close_bf16(ops.rmsnorm_f32(x32, w), ref, "rmsnorm_f32")

@@ -13,6 +13,6 @@ def t(M, N, K, epi, reps=30):
     e1.record(); torch.cuda.synchronize()
     return e0.elapsed_time(e1) / reps * 1e3
 t(8192, 8192, 8192, 0, 10)
-os.environ["PADT_GEMM_MF"] = "4"; os.environ["PADT_GEMM_PEEL"] = "0"; os.environ["PADT_GEMM_COLSPLIT"] = "0"; os.environ["PADT_GEMM256"] = "2"
+ops.gemm_knobs(mode256=2, mf=4, peel=0, colsplit=0)
 for tiles, (M, N) in [(8, (512, 1024)), (32, (1024, 2048)), (64, (2048, 2048)), (128, (2048, 4096)), (256, (4096, 4096))]:
     print(f"{tiles:4d} tiles: K=1280 {t(M, N, 1280, 0):6.1f} us   K=2560 {t(M, N, 2560, 0):6.1f} us", flush=True)

@@ -15,7 +15,7 @@ def t(M, N, K, epi, reps=20):
     return e0.elapsed_time(e1) / reps * 1e3
 # warm clocks
 t(8192, 8192, 8192, 0, 10)
-os.environ["PADT_GEMM_MF"] = "4"; os.environ["PADT_GEMM_PEEL"] = "0"; os.environ["PADT_GEMM_COLSPLIT"] = "0"
+ops.gemm_knobs(mf=4, peel=0, colsplit=0)
 for (M, N, epi, name) in [(16896, 6912, 3, "vit gate/up 66x27=1782 tiles (6.96 rounds)"), (16896, 3840, 0, "vit qkv 66x15=990 (3.87)"), (4096, 4096, 0, "exactly 256 tiles (1 round)"), (8192, 8192, 0, "1024 tiles (4 rounds)")]:
     line = name + ": "
     ts = []
