@@ -700,12 +700,9 @@ template <int D, bool CAUSAL, int QR, bool ROPE, bool GQA>
 static void launch_attn_k(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int lds = ROPE ? AttnCfg<D>::LDS : AttnCfg<D>::LDS2;             // the LDS-DMA path double-buffers the K / V tiles
     if constexpr (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_varlen_kernel<D, CAUSAL, QR, ROPE, GQA>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_varlen_kernel<D, CAUSAL, QR, ROPE, GQA>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     }
     hipLaunchKernelGGL((attn_varlen_kernel<D, CAUSAL, QR, ROPE, GQA>), grid, dim3(256), lds, s, a);
 }

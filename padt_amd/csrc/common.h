@@ -12,6 +12,21 @@ typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;  // 8 bytes
 
 #define PADT_DEV __device__ __forceinline__
 
+// Host side: hipFuncSetAttribute(MaxDynamicSharedMemorySize) is PER DEVICE — a process that drives several GPUs must raise the limit
+// on each of them.  One bit per device ordinal; the attribute is set BEFORE the bit (two threads may both set it, none launches early).
+#include <atomic>
+struct PerDeviceOnce {
+    std::atomic<unsigned long long> mask{0};
+    template <class F> void run(F&& set_attribute) {
+        int d = 0;
+        (void)hipGetDevice(&d);
+        const unsigned long long bit = 1ull << (d & 63);
+        if (mask.load(std::memory_order_acquire) & bit) return;
+        set_attribute();
+        mask.fetch_or(bit, std::memory_order_release);
+    }
+};
+
 PADT_DEV float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 
 // round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32); NaN stays NaN, +-inf stays +-inf

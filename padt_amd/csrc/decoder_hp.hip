@@ -236,7 +236,7 @@ __global__ __launch_bounds__(256) void attn_f32_qfew_kernel(AttnF32Args p) {
     __syncthreads();
     for (int i = tid; i < nq * (D / 4); i += 256) {
         const int qi = i / (D / 4), c = (i % (D / 4)) * 4;
-        const float inv = 1.f / l_s[qi];
+        const float inv = l_s[qi] > 0.f ? 1.f / l_s[qi] : 0.f;   // a segment without keys yields zero rows (as attn_varlen_kernel), not NaN
         float v4[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
         m = m_new;
     }
     if (!valid) return;
-    const float inv = 1.f / l;
+    const float inv = l > 0.f ? 1.f / l : 0.f;
 #pragma unroll
     for (int c = 0; c < D; c += 4) {
         const float v4[4] = {o[c] * inv, o[c + 1] * inv, o[c + 2] * inv, o[c + 3] * inv};

@@ -524,12 +524,9 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
-    static bool attr_done = false;
-    if (!attr_done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<EPI, F32, BK>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<BK>::LDS);
-        attr_done = true;
-    }
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile_kernel<EPI, F32, BK>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, TileCfg<BK>::LDS); });
     const int ntm = (a.M + BM - 1) / BM, ntn = (a.N + BN - 1) / BN;
     hipLaunchKernelGGL((gemm_tile_kernel<EPI, F32, BK>), dim3(ntm * ntn), dim3(256), TileCfg<BK>::LDS, s, a);
 }
@@ -548,12 +545,9 @@ static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
     const int split = (a.ws && !NORM) ? a.split : 1;
     constexpr int lds = NW * NT * MT * 64 * 16 + NW * MT * 16 * 4;      // red + ssq (gemm_skinny_kernel)
     if constexpr (lds > 64 * 1024) {
-        static bool done = false;
-        if (!done) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-            done = true;
-        }
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     }
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>), dim3(nb, split), dim3(NW * 64), lds, s, a, eps);
 }

@@ -437,12 +437,9 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 
 template <int EPI, bool F32, int MF>
 static void launch256_mf(const Gemm256Args& a, hipStream_t s) {
-    static bool done = false;
-    if (!done) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32, MF>),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-        done = true;
-    }
+    static PerDeviceOnce once;
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32, MF>),
+                                            hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
     const int ntm = (a.M + 64 * MF - 1) / (64 * MF), ntn = (a.N + TN - 1) / TN;
     hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32, MF>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
 }

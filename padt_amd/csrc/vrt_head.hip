@@ -265,7 +265,9 @@ PADT_DEV unsigned hash32(unsigned x) {
 PADT_DEV float gumbel_noise(unsigned seed, unsigned step, unsigned row, unsigned idx) {
     unsigned x = hash32(idx * 0x9E3779B1u + seed);
     x = hash32(x ^ (row * 0x85EBCA77u + step * 0xC2B2AE3Du + 0x68bc21ebu));
-    const float u = ((float)(x >> 8) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1)
+    // 23 random bits: (x >> 9) + 0.5 is exact in fp32 (24 would round 2^24 - 0.5 up to 2^24 → u = 1 → g = +inf, a uniformly random
+    // token once per 2^24 candidates: 0.9 % per step over a 152k-row table with top_k = 0) → u in [2^-24, 1 - 2^-24], g finite
+    const float u = ((float)(x >> 9) + 0.5f) * (1.0f / 8388608.0f);
     return -logf(-logf(u));
 }
 PADT_DEV unsigned float_key(float f) {                                    // order-preserving float → uint

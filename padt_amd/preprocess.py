@@ -128,7 +128,10 @@ class ImageFrontEnd:
                  max_pixels: int = 14 * 14 * 4 * 1280, dtype=torch.bfloat16, resize: str = "gpu", pre_resize=None):
         """resize: "gpu" (default: Pillow's resampler on the device, bit-exact) or "pil" (host PIL, the reference's own call).
         pre_resize: None, "demo644" (eval/test_demo.py:67-73) or "min28" (eval/evaluation_scripts/utils.py:205-218) — the callers'
-        LANCZOS pass in front of the processor."""
+        LANCZOS pass in front of the processor, applied to the image as handed to this class.  NOT covered: in the demo the file first
+        goes through qwen_vl_utils.process_vision_info (test_demo.py:61-62; that package is not in the build container, so its
+        fetch_image step — which may itself smart-resize with BICUBIC — is unpinned); a caller who wants the demo's exact pixels for
+        images whose sides are not multiples of 28 applies that step before handing the image over."""
         self.device, self.patch, self.merge, self.temporal = device, patch, merge, temporal
         self.min_pixels, self.max_pixels, self.dtype = min_pixels, max_pixels, dtype
         self.resize, self.pre_resize = resize, pre_resize

@@ -64,3 +64,76 @@ def effective_llm_weights(model, w):
         out[s + "input_layernorm.weight"] = torch.ones_like(w[s + "input_layernorm.weight"])
         out[s + "post_attention_layernorm.weight"] = torch.ones_like(w[s + "post_attention_layernorm.weight"])
     return out
+
+
+# ------------------------------------------------------------------------------------------------ bf16-operand floor
+class bf16_operand_floor:
+    """Context manager: inside it the ORACLE's ViT / LLM arithmetic rounds every matrix-multiply operand on the activation side to
+    bf16 — the normalised rows entering qkv / gate-up, q / k / v (and with them the KV cache), the un-normalised probabilities P, the
+    attention output entering proj / o_proj, the SwiGLU hidden entering down_proj, pixel rows, merger / prototype / head inputs — and
+    keeps EVERYTHING else in fp32 (residual streams, accumulators, softmax statistics, norms, weights as given).  That is the smallest
+    distance to the fp32 reference any implementation on bf16 MFMA operands can have, whatever it stores between kernels; the full-depth
+    parity test measures it on its own inputs and bounds the HIP path by a multiple of it (tests/studies/e2e_precision_floor.py prints
+    the numbers).  The PaDT decoder is left alone (the HIP decoder runs split-precision operands)."""
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        self._saved = {k: getattr(O, k) for k in ("vit_block", "llm_layer", "linear", "vrt_logits")}
+
+        def linear(x, w, b=None):
+            return F.linear(bf(x), w, b)
+
+        def vit_block(w, pfx, cfg, x, cu, cos, sin):
+            H, T = cfg.vit_heads, x.shape[0]
+            n = O.rms_norm(x, w[pfx + "norm1.weight"], 1e-6)
+            qkv = linear(n, w[pfx + "attn.qkv.weight"], w[pfx + "attn.qkv.bias"]).reshape(T, 3, H, -1)
+            q, k, v = qkv.permute(1, 0, 2, 3).unbind(0)
+            c, s = cos.unsqueeze(-2).float(), sin.unsqueeze(-2).float()
+            q, k, v = bf(q * c + O.rotate_half(q) * s), bf(k * c + O.rotate_half(k) * s), bf(v)
+            a = torch.empty_like(q)
+            for i in range(len(cu) - 1):
+                a0, a1 = int(cu[i]), int(cu[i + 1])
+                qs, ks, vs = (t[a0:a1].transpose(0, 1) for t in (q, k, v))
+                sc = torch.matmul(qs, ks.transpose(1, 2)) * (q.shape[-1] ** -0.5)
+                e = torch.exp(sc - sc.max(-1, keepdim=True).values)
+                a[a0:a1] = (torch.matmul(bf(e), vs) / e.sum(-1, keepdim=True)).transpose(0, 1)
+            x = x + linear(a.reshape(T, -1), w[pfx + "attn.proj.weight"], w[pfx + "attn.proj.bias"])
+            n = O.rms_norm(x, w[pfx + "norm2.weight"], 1e-6)
+            g = linear(n, w[pfx + "mlp.gate_proj.weight"], w[pfx + "mlp.gate_proj.bias"])
+            u = linear(n, w[pfx + "mlp.up_proj.weight"], w[pfx + "mlp.up_proj.bias"])
+            return x + linear(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"], w[pfx + "mlp.down_proj.bias"])
+
+        def llm_layer(w, pfx, cfg, h, cos, sin, attn_bias, cache, li):
+            B, Lq, _ = h.shape
+            n = O.rms_norm(h, w[pfx + "input_layernorm.weight"], cfg.rms_eps)
+            q = linear(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"]).view(B, Lq, cfg.num_heads, cfg.head_dim)
+            k = linear(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            v = linear(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            c, s = cos.unsqueeze(2), sin.unsqueeze(2)
+            q, k, v = bf(q * c + O.rotate_half(q) * s), bf(k * c + O.rotate_half(k) * s), bf(v)
+            if cache is not None:
+                k, v = cache.update(li, k, v)
+            rep = cfg.num_heads // cfg.num_kv_heads
+            qh = q.transpose(1, 2)
+            kh = k.transpose(1, 2).repeat_interleave(rep, 1)
+            vh = v.transpose(1, 2).repeat_interleave(rep, 1)
+            sc = torch.matmul(qh, kh.transpose(2, 3)) * (cfg.head_dim ** -0.5) + attn_bias
+            e = torch.exp(sc - sc.max(-1, keepdim=True).values)
+            a = (torch.matmul(bf(e), vh) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, Lq, -1)
+            h = h + linear(a, w[pfx + "self_attn.o_proj.weight"])
+            n = O.rms_norm(h, w[pfx + "post_attention_layernorm.weight"], cfg.rms_eps)
+            g = linear(n, w[pfx + "mlp.gate_proj.weight"])
+            u = linear(n, w[pfx + "mlp.up_proj.weight"])
+            return h + linear(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"])
+
+        def vrt_logits(w, cfg, hidden, proto, lmask):
+            return self._saved["vrt_logits"](w, cfg, bf(hidden), bf(proto), lmask)
+
+        O.linear, O.vit_block, O.llm_layer, O.vrt_logits = linear, vit_block, llm_layer, vrt_logits
+        return self
+
+    def __exit__(self, *exc):
+        for k, v in self._saved.items():
+            setattr(O, k, v)
+        return False

@@ -233,3 +233,16 @@ def test_rope_index_left_padded_rows_against_installed_transformers():
     L = ids.shape[1]
     for b in range(len(grids)):
         assert L + int(deltas[b, 0]) == int(hf_pos[:, b, am[b] == 1].max()) + 1 == plan.next_pos[b]
+
+
+def test_gumbel_uniform_is_strictly_inside_the_unit_interval():
+    """csrc/vrt_head.hip gumbel_noise builds u = ((x >> 9) + 0.5) * 2^-23 in fp32 from a 32-bit hash x: both extremes must stay strictly
+    inside (0, 1) so that -log(-log u) is finite (the 24-bit form ((x >> 8) + 0.5) * 2^-24 rounds to exactly 1.0 for x = 0xFFFFFFFF)."""
+    import numpy as np
+    f = np.float32
+    for x in (0, 1, 0x7FFFFFFF, 0xFFFFFFFF):
+        u = f(f(f(x >> 9) + f(0.5)) * f(1.0 / 8388608.0))
+        assert f(0) < u < f(1), (x, u)
+        assert np.isfinite(-np.log(-np.log(u)))
+    bad = f(f(f(0xFFFFFFFF >> 8) + f(0.5)) * f(1.0 / 16777216.0))
+    assert bad == f(1.0)                                            # what the old expression did

@@ -273,11 +273,14 @@ def test_vrt_head_logits_do_not_depend_on_the_batch():
 def test_full_depth_3b_teacher_forced_against_oracle():
     """The WHOLE PaDT_Pro_3B geometry (32 ViT blocks at 2116 x 1280, 36 LLM layers at D = 2048 / 16:2 heads / MLP 11008,
     151 936 + 529 table rows, 98 M-parameter decoder) for one 46 x 46 image, seeded random weights (bf16-representable, biases
-    and norm jitter on), against the fp32 CPU oracle teacher-forced on the HIP tokens (≈30-60 s of host CPU):
-      * generated ids: margin rule (every HIP token is the oracle's arg-max unless the oracle's own top-2 margin is inside the
-        bf16 noise floor; then it must be within that floor of the max);
-      * ViT outputs, per-step last-layer hidden rows: relative rms, bounds = 2x what 32 / 36 layers of bf16 storage measured;
-      * boxes / scores / mask logits end to end, and the decoder alone on identical inputs at the north star's 1e-3."""
+    and norm jitter on), against the fp32 CPU oracle teacher-forced on the HIP tokens.  The tolerance is DERIVED, not chosen: the
+    oracle is run a second time inside parity_util.bf16_operand_floor() (every matmul operand on the activation side rounded to
+    bf16, everything else fp32 — the distance ANY bf16-MFMA implementation has) and every float quantity of the HIP path must be
+    within 2x that floor on the same inputs; box coordinates additionally within the north star's flat 1e-3.  (≈1 min of host CPU.)
+      * generated ids: margin rule — a HIP token must be the oracle's arg-max unless the oracle's own top-2 margin is inside the
+        logit noise the floor run shows at that step (2 x max |logit_floor - logit_fp32|); then it must be within that noise of the max;
+      * ViT outputs, prototypes, per-step last-layer hidden rows: relative rms <= 2 x floor;
+      * boxes <= 1e-3 and <= 2 x floor + 2e-4, score / mask logits <= 2 x floor end to end; the decoder alone on identical inputs 1e-3."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
@@ -307,43 +310,47 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        with U.bf16_operand_floor():
+            fres = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
     t_or = time.perf_counter() - t0
     assert torch.equal(ores["sequences"], seq)
-    st = ores["state"]
+    st, fst = ores["state"], fres["state"]
+    stream = "fp32" if model.W.resid_f32 else "bf16"
+    K = 2.0 if model.W.resid_f32 else 6.0                           # PADT_RESID_F32=0 (round-2 arithmetic, kept for A/B runs) sits 2.2-3x above the floor
     # ---- ViT (32 blocks) and prototypes
     mx, rms_h = rel(out.past_high_res_image_embeds, st.high_res)
     mxp, rms_p = rel(out.past_image_embeds, st.proto)
-    print(f"\n[full 3B] oracle {t_or:.1f} s on {torch.get_num_threads()} threads; ViT high_res rel max {mx:.3e} rms {rms_h:.3e}; prototypes rel max {mxp:.3e} rms {rms_p:.3e}")
-    assert rms_h < 4e-2 and rms_p < 4e-2
-    # ---- ids: margin rule
-    n_tie, noise = 0, 0.0
+    _, frms_h = rel(fst.high_res, st.high_res)
+    _, frms_p = rel(fst.proto, st.proto)
+    print(f"\n[full 3B, {stream} residual streams] oracle fp32 + bf16-operand floor {t_or:.1f} s on {torch.get_num_threads()} threads")
+    print(f"[full 3B] ViT high_res rel rms {rms_h:.3e} (floor {frms_h:.3e}, x{rms_h / frms_h:.2f}); prototypes rel rms {rms_p:.3e} (floor {frms_p:.3e}, x{rms_p / frms_p:.2f})")
+    assert rms_h < K * frms_h and rms_p < K * frms_p
+    # ---- ids: margin rule with the measured logit noise
+    n_tie = 0
     for t in range(T):
-        lg = ores["logits"][t][0]
+        lg, lf = ores["logits"][t][0], fres["logits"][t][0]
+        fin = torch.isfinite(lg)
+        noise = K * (lf[fin] - lg[fin]).abs().max().item()
         top2 = lg.topk(2).values
         chosen = lg[toks[0, t]].item()
-        floor = 2e-2 * lg[torch.isfinite(lg)].abs().max().item()
         margin = (top2[0] - (top2[1] if torch.isfinite(top2[1]) else top2[0] - 1)).item()
         gap = top2[0].item() - chosen
-        print(f"[full 3B] step {t} mode {sched[t]}: token {int(toks[0, t])}  oracle top-2 margin {margin:.3e}  floor {floor:.3e}  gap to oracle max {gap:.3e}")
-        if margin > floor:
-            assert gap == 0.0, f"step {t}: HIP token is not the oracle argmax (margin {margin:.3e} > floor {floor:.3e})"
+        print(f"[full 3B] step {t} mode {sched[t]}: token {int(toks[0, t])}  oracle top-2 margin {margin:.3e}  logit noise bound (2 x floor) {noise:.3e} "
+              f"= {noise / (lg[fin].abs().max().item() + 1e-30):.2%} of |logit|max  gap to oracle max {gap:.3e}")
+        if margin > noise:
+            assert gap == 0.0, f"step {t}: HIP token is not the oracle argmax (margin {margin:.3e} > noise {noise:.3e})"
         else:
             n_tie += 1
-            assert gap <= floor
-        noise = max(noise, gap)
+            assert gap <= noise
         if sched[t] == "v":
             assert V <= toks[0, t] < V + 529
     # ---- last-layer hidden rows (36 layers deep) that predicted each token
     hid = out.hidden_states.last_layer_rows().cpu().float()          # (T, 1, D)
-    worst = 0.0
     for t in range(T):
         mx, rms = rel(hid[t], ores["hidden"][t][:, -1])
-        worst = max(worst, rms)
-        print(f"[full 3B] hidden step {t}: rel max {mx:.3e} rms {rms:.3e}")
-        # measured: 3.5-3.8e-2 for steps fed a text token (36 layers x ~4.8e-3 per layer, the single-layer figure above, adding in
-        # quadrature plus the ViT's 2e-2 through the 529 image rows of the prompt), 7.6-7.9e-2 for steps fed a VRT token (its
-        # embedding IS a prototype = a ViT output, 2e-2 off at the input).  Bounds = 2x measured.
-        assert rms < (1.6e-1 if t > 0 and sched[t - 1] == "v" else 8e-2), f"hidden step {t}: rel rms {rms:.3e}"
+        _, frms = rel(fres["hidden"][t][:, -1], ores["hidden"][t][:, -1])
+        print(f"[full 3B] hidden step {t}: rel rms {rms:.3e} (floor {frms:.3e}, x{rms / frms:.2f})")
+        assert rms < K * frms, f"hidden step {t}: rel rms {rms:.3e} vs floor {frms:.3e}"
     # ---- parse + decoder
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
     proc.model_embed_token_size = V
@@ -352,22 +359,114 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     assert len(feats[0]) == 1 and feats[0][0].shape == (4, cfg.hidden_size)
     dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
     with torch.no_grad():
-        ofeats = [[torch.cat([ores["hidden"][t][0:1, -1] for t in range(2, 6)], 0)]]
-        odec = O.vl_decode(w, oc, ofeats, st.proto, st.high_res, grid, st.visual_pe)
+        vf = lambda r: [[torch.cat([r["hidden"][t][0:1, -1] for t in range(2, 6)], 0)]]
+        odec = O.vl_decode(w, oc, vf(ores), st.proto, st.high_res, grid, st.visual_pe)
+        fdec = O.vl_decode(w, oc, vf(fres), fst.proto, fst.high_res, grid, fst.visual_pe)
         odec2 = O.vl_decode(w, oc, [[feats[0][0].cpu().float()]], out.past_image_embeds.cpu().float(),
                             out.past_high_res_image_embeds.cpu().float(), grid,
                             (out.past_visual_pe[0].cpu(), out.past_visual_pe[1].cpu()))
     db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
     ds = (dec["pred_score"].cpu().float() - odec["pred_score"]).abs().max().item()
     mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
+    fdb = (fdec["pred_boxes"] - odec["pred_boxes"]).abs().max().item()
+    fds = (fdec["pred_score"] - odec["pred_score"]).abs().max().item()
+    fmx, frms = rel(fdec["pred_mask"], odec["pred_mask"])
     db2 = (dec["pred_boxes"].cpu().float() - odec2["pred_boxes"]).abs().max().item()
     mx2, rms2 = rel(dec["pred_mask"], odec2["pred_mask"])
     iou = O.box_iou_xywh(*[[float(b[0] - b[2] / 2), float(b[1] - b[3] / 2), float(b[2]), float(b[3])]
                            for b in (dec["pred_boxes"][0].cpu(), odec["pred_boxes"][0])])
-    print(f"[full 3B] end to end: box |d|max {db:.3e} (IoU vs oracle {iou:.4f}) score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}; "
-          f"decoder alone on identical inputs: box |d|max {db2:.3e} mask rel max {mx2:.3e} rms {rms2:.3e}; ties {n_tie}/{T}, token noise {noise:.3e}")
+    print(f"[full 3B] end to end: box |d|max {db:.3e} (floor {fdb:.3e}; IoU vs oracle {iou:.4f}) score |d|max {ds:.3e} (floor {fds:.3e}) "
+          f"mask logits rel max {mx:.3e} (floor {fmx:.3e}, x{mx / fmx:.2f}) rms {rms:.3e} (floor {frms:.3e}); "
+          f"decoder alone on identical inputs: box |d|max {db2:.3e} mask rel max {mx2:.3e} rms {rms2:.3e}; ties {n_tie}/{T}")
     assert db2 < 1e-3 and mx2 < 1e-3                                 # north star: decoder kernels on the same inputs
-    assert iou > 0.9 and db < 5e-2                                   # 32 + 36 bf16 layers upstream of the decoder's inputs
+    assert db < K * fdb + 2e-4 and ds < K * fds + 1e-3 and mx < K * fmx and rms < K * frms
+    if model.W.resid_f32:
+        assert db < 1e-3 and iou > 0.99                              # north star on the box coordinates, end to end at full depth
+
+
+def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
+    """What bench.py times, asserted: PaDT_Pro_3B, batches of 8 different 46 x 46 images through PipelinedRunner(depth=2, merge=8)
+    — 64-row decode steps, 8 x 529 prototypes per batch in one table, 16 REC tokens per image (VRT run of 5) — against
+      (a) the un-merged path (rec_batch, one batch at a time): tokens, boxes, scores, mask logits BIT-identical for every batch;
+      (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch (≈2-3 min of host CPU): every token by
+          the margin rule with the logit-noise bound the single-image full-depth test derives (bf16-operand floor ≈1.8 % of the
+          largest |logit| at text steps, x2), every box within 2.5e-3 (floor 4.7e-4 for one image, the north star's 1e-3 is
+          asserted where the floor is measured alongside: test_full_depth_3b_teacher_forced_against_oracle) and IoU > 0.98."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import padt_amd
+    import parity_util as U
+    from padt_amd import pipeline
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    O = U.O
+    cfg = padt_amd.padt_pro_3b()
+    sd = synthetic_state_dict(cfg, seed=3, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    oc = U.oracle_config(cfg)
+    B, T, NB = 8, 16, 10                                            # 10 batches: one full decode group of 8 + a partially filled one
+    sched = U.rec_schedule(T, vrt_at=range(6, 11))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = [U.synthetic_batch(cfg, [[1, 46, 46]] * B, n_pre=15, n_post=33, seed=500 + i) for i in range(NB)]
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=8)
+    res = []
+    for grid, pix, ids, am in batches:
+        res += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda().to(torch.bfloat16), grid, max_new_tokens=T, schedule=sched)
+    res += runner.flush()
+    assert len(res) == NB
+    # ---- (a) merged == un-merged, bit for bit
+    for i in (0, 3, 7, 9):
+        grid, pix, ids, am = batches[i]
+        dec1, comp1, lab1, vrt1 = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda().to(torch.bfloat16), grid,
+                                                     max_new_tokens=T, schedule=sched)
+        decm, compm, labm, vrtm = res[i]
+        assert compm == comp1 and vrtm == vrt1, f"batch {i}: tokens differ between merged and un-merged decode"
+        for k in ("pred_boxes", "pred_score", "pred_mask"):
+            assert torch.equal(decm[k], dec1[k]), f"batch {i}: {k} differs between merged and un-merged decode"
+    # ---- (b) one batch, all 8 samples, against the oracle
+    grid, pix, ids, am = batches[0]
+    out = model.generate(input_ids=proc.assign_to_global_vrt_id(ids.clone(), grid).cuda(), attention_mask=am.cuda(),
+                         pixel_values=pix.cuda().to(torch.bfloat16), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    toks = out.sequences[:, L:].cpu()
+    decm = res[0][0]
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ores = O.generate(w, oc, ids, am, pix.to(torch.bfloat16).float(), grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        feats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(B)]
+        ost = ores["state"]
+        odec = O.vl_decode(w, oc, feats, ost.proto, ost.high_res, grid, ost.visual_pe)
+    print(f"\n[3B batch 8] oracle on 8 images x {T} tokens: {time.perf_counter() - t0:.1f} s")
+    n_arg, n_tie = 0, 0
+    for b in range(B):
+        for t in range(T):
+            lg = ores["logits"][t][b]
+            fin = torch.isfinite(lg)
+            noise = 2 * 0.025 * lg[fin].abs().max().item()        # 2 x the bf16-operand floor of the logit noise (1.8-2.5 % of |logit|max, full-depth test)
+            top2 = lg.topk(2).values
+            margin = (top2[0] - (top2[1] if torch.isfinite(top2[1]) else top2[0] - 1)).item()
+            gap = top2[0].item() - lg[toks[b, t]].item()
+            if gap == 0.0:
+                n_arg += 1
+            elif margin <= noise:
+                n_tie += 1
+                assert gap <= noise, f"sample {b} step {t}: gap {gap:.3e} beyond the noise bound {noise:.3e}"
+            else:
+                raise AssertionError(f"sample {b} step {t}: HIP token is not the oracle arg-max (margin {margin:.3e} > noise {noise:.3e})")
+    db = (decm["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().amax(dim=1)
+    ious = [O.box_iou_xywh(*[[float(x[0] - x[2] / 2), float(x[1] - x[3] / 2), float(x[2]), float(x[3])] for x in (decm["pred_boxes"][b].cpu(), odec["pred_boxes"][b])])
+            for b in range(B)]
+    mx, rms = rel(decm["pred_mask"], odec["pred_mask"])
+    print(f"[3B batch 8] tokens: {n_arg}/{B * T} the oracle's arg-max, {n_tie} inside the logit noise; box |d|max per sample "
+          f"{[f'{x:.1e}' for x in db.tolist()]} ({int((db < 1e-3).sum())}/8 within 1e-3); IoU min {min(ious):.4f}; mask logits rel max {mx:.3e} rms {rms:.3e}")
+    assert n_arg >= int(0.85 * B * T)
+    assert float(db.max()) < 2.5e-3 and min(ious) > 0.98 and mx < 5e-2
 
 
 def test_padt_decoder_ovd_shape_seven_objects_per_image():
