@@ -4,13 +4,15 @@ the best mask IoU — including the reference's conventions (keys "%d_%s" % (id,
 round(); the cIoU mean runs over the expressions that received at least one prediction, eval_refcoco.py:104-116).
 
 COCO RLE is decoded here (rleFrString + decode of the COCO maskApi, the inverse of postprocess.rle_string / rle_counts): pycocotools is
-not in the image.  COCOeval itself (eval_coco.py:78-93, OVD mAP) is pycocotools' and is not rebuilt.
+not in the image.  The OVD score — COCO bbox mAP, eval_coco.py:21-93 — is `score_coco` (padt_amd/coco_eval.py, COCOeval's bbox protocol
+written from its published definition, re-exported here).
 """
 from collections import defaultdict
 from typing import Dict, Iterable, List, Sequence
 
 import numpy as np
 
+from .coco_eval import coco_eval_bbox, score_coco  # noqa: F401  (OVD: eval_coco.py)
 from .postprocess import box_iou_xywh
 
 
