@@ -388,10 +388,11 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     """What bench.py times, asserted: PaDT_Pro_3B, batches of 8 different 46 x 46 images through PipelinedRunner(depth=2, merge=8)
     — 64-row decode steps, 8 x 529 prototypes per batch in one table, 16 REC tokens per image (VRT run of 5) — against
       (a) the un-merged path (rec_batch, one batch at a time): tokens, boxes, scores, mask logits BIT-identical for every batch;
-      (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch (≈2-3 min of host CPU): every token by
-          the margin rule with the logit-noise bound the single-image full-depth test derives (bf16-operand floor ≈1.8 % of the
-          largest |logit| at text steps, x2), every box within 2.5e-3 (floor 4.7e-4 for one image, the north star's 1e-3 is
-          asserted where the floor is measured alongside: test_full_depth_3b_teacher_forced_against_oracle) and IoU > 0.98."""
+      (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch, and the oracle's bf16-operand floor run
+          on the same inputs (parity_util.bf16_operand_floor; ≈4 min of host CPU together): every token by the margin rule with the
+          logit noise the floor run shows for that sample and step (x2); the batch's largest box error within 2x the floor run's
+          largest (+2e-4), every IoU > 0.98, mask logits within 2x the floor's.  (The north star's flat 1e-3 on box coordinates
+          is below what bf16 MFMA operands alone allow on several of these 8 images — the floor run's own errors are printed.)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
@@ -438,17 +439,20 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     t0 = time.perf_counter()
     with torch.no_grad():
-        ores = O.generate(w, oc, ids, am, pix.to(torch.bfloat16).float(), grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
-        feats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(B)]
-        ost = ores["state"]
-        odec = O.vl_decode(w, oc, feats, ost.proto, ost.high_res, grid, ost.visual_pe)
-    print(f"\n[3B batch 8] oracle on 8 images x {T} tokens: {time.perf_counter() - t0:.1f} s")
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        with U.bf16_operand_floor():
+            fres = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        vf = lambda r: [[torch.cat([r["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(B)]
+        ost, fst = ores["state"], fres["state"]
+        odec = O.vl_decode(w, oc, vf(ores), ost.proto, ost.high_res, grid, ost.visual_pe)
+        fdec = O.vl_decode(w, oc, vf(fres), fst.proto, fst.high_res, grid, fst.visual_pe)
+    print(f"\n[3B batch 8] oracle (fp32 + bf16-operand floor) on 8 images x {T} tokens: {time.perf_counter() - t0:.1f} s")
     n_arg, n_tie = 0, 0
     for b in range(B):
         for t in range(T):
-            lg = ores["logits"][t][b]
+            lg, lf = ores["logits"][t][b], fres["logits"][t][b]
             fin = torch.isfinite(lg)
-            noise = 2 * 0.025 * lg[fin].abs().max().item()        # 2 x the bf16-operand floor of the logit noise (1.8-2.5 % of |logit|max, full-depth test)
+            noise = 2 * (lf[fin] - lg[fin]).abs().max().item()     # 2 x the logit noise bf16 operands alone cause for this sample and step
             top2 = lg.topk(2).values
             margin = (top2[0] - (top2[1] if torch.isfinite(top2[1]) else top2[0] - 1)).item()
             gap = top2[0].item() - lg[toks[b, t]].item()
@@ -462,11 +466,14 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     db = (decm["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().amax(dim=1)
     ious = [O.box_iou_xywh(*[[float(x[0] - x[2] / 2), float(x[1] - x[3] / 2), float(x[2]), float(x[3])] for x in (decm["pred_boxes"][b].cpu(), odec["pred_boxes"][b])])
             for b in range(B)]
+    fdb = (fdec["pred_boxes"] - odec["pred_boxes"]).abs().amax(dim=1)
     mx, rms = rel(decm["pred_mask"], odec["pred_mask"])
+    fmx, frms = rel(fdec["pred_mask"], odec["pred_mask"])
     print(f"[3B batch 8] tokens: {n_arg}/{B * T} the oracle's arg-max, {n_tie} inside the logit noise; box |d|max per sample "
-          f"{[f'{x:.1e}' for x in db.tolist()]} ({int((db < 1e-3).sum())}/8 within 1e-3); IoU min {min(ious):.4f}; mask logits rel max {mx:.3e} rms {rms:.3e}")
+          f"{[f'{x:.1e}' for x in db.tolist()]} (bf16-operand floor {[f'{x:.1e}' for x in fdb.tolist()]}); IoU min {min(ious):.4f}; "
+          f"mask logits rel max {mx:.3e} (floor {fmx:.3e}) rms {rms:.3e} (floor {frms:.3e})")
     assert n_arg >= int(0.85 * B * T)
-    assert float(db.max()) < 2.5e-3 and min(ious) > 0.98 and mx < 5e-2
+    assert float(db.max()) < 2 * float(fdb.max()) + 2e-4 and min(ious) > 0.98 and mx < 2 * fmx and rms < 2 * frms
 
 
 def test_padt_decoder_ovd_shape_seven_objects_per_image():
