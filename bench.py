@@ -8,8 +8,10 @@ A "step" = one batch of `--batch` (default 8) synthetic 640x640-equivalent image
   ViT → prototypes → packed prefill → 27 hipGraph decode steps over text‖VRT (scripted 28-token REC completion: one run
   of 5 VRTs, forced EOS) → parseVRTintoCompletion → PaDT decoder (boxes + 184x184 mask logits) [→ RCCL all-gather].
 Weights: random-init PaDT_Pro_3B architecture (3.85 B parameters, bf16).  Rank 0 prints ONE JSON line.
-Extra objects on that line: "roofline" (bf16 MFMA tile-GEMM family, measured live with HIP events by replaying the
-step's own GEMM launch list on the stream) and "cpu_baseline" (the fp32 CPU oracle timed on this host, N=1 only).
+Extra objects on that line (N=1): "roofline" (bf16 MFMA tile-GEMM family, HIP-event brackets around every tile-GEMM launch INSIDE the
+running pipeline; frac_replay = the same launches replayed alone), "roofline_decode" (HBM bytes of a decode step / its in-situ and stand-alone
+duration), "from_images" (the same pipeline fed from uint8 host images), "cpu_baseline" (the fp32 CPU oracle timed on this host, with the
+parity read-out), "extra_workloads" (BASELINE configs[3] OVD and configs[4] 7B RIC fp8 per-GPU shapes, short runs).
 """
 import argparse
 import json
@@ -78,7 +80,13 @@ def parse_args():
     ap.add_argument("--timeline-steps", type=int, default=4)
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
     ap.add_argument("--depth", type=int, default=2, help="batches in flight on separate HIP streams (1 = no overlap)")
-    return ap.parse_args()
+    ap.add_argument("--no-from-images", dest="from_images", action="store_false", help="skip the leg that feeds the pipeline from uint8 host images")
+    ap.add_argument("--no-extras", dest="extras", action="store_false", help="skip the OVD (configs[3]) and 7B RIC fp8 (configs[4]) short runs")
+    ap.add_argument("--dump-exchange", default="", help="directory: every rank saves its local results and what the all-gathers delivered (tests)")
+    a = ap.parse_args()
+    if a.model != "3b" or a.task != "rec" or a.weights != "bf16":
+        a.extras = False                                               # the extra keys belong to the headline line only
+    return a
 
 
 def build_model(args, device):
@@ -133,106 +141,170 @@ def run_step(model, inp, args, world):
     return decoded
 
 
-# ------------------------------------------------------------------------------------------------ roofline leg
-def roofline_leg(model, inp, args, cfg):
+# ------------------------------------------------------------------------------------------------ roofline legs
+def _alg_dims(model, cfg):
+    """Undo the zero padding of MLP intermediates: padded size → the model's own."""
+    pads = ((model.W.vit_ipad, cfg.vision_config.intermediate_size), (model.W.llm_ipad, cfg.intermediate_size),
+            (model.W.dec_ipad, cfg.vl_decoder["intermediate_size"]))
+
+    def alg(n):
+        for pad, true in pads:
+            if n == pad:
+                return true
+            if n == 2 * pad:
+                return 2 * true
+        return n
+    return alg
+
+
+def insitu_leg(model, inp, args, cfg, run_steps, steps):
+    """The two rooflines measured IN the running pipeline: `steps` more steps of exactly the timed loop (same runner, same streams, same
+    batches in flight) with a HIP-event pair around every tile-GEMM launch (rows > 64) on the stream it is launched on, and around every
+    chunk of decode-step graph replays.  → (roofline dict for the tile-GEMM family, roofline_decode dict)."""
+    from padt_amd import ops
+    alg = _alg_dims(model, cfg)
+    gt, st = ops.EventTimer(), ops.EventTimer()
+    torch.cuda.synchronize()
+    ops.GEMM_TIMER, ops.STEP_TIMER = gt, st
+    t0 = time.perf_counter()
+    run_steps(steps)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    ops.GEMM_TIMER, ops.STEP_TIMER = None, None
+    g, d = gt.results(), st.results()
+    gt.close()
+    st.close()
+    flops = sum(2.0 * M * alg(N) * alg(K) for _, (kind, M, N, K) in g)
+    ms = sum(m for m, _ in g)
+    by = {}
+    for m, (kind, M, N, K) in g:
+        e = by.setdefault((M, N, K, kind), [0, 0.0])
+        e[0] += 1
+        e[1] += m
+    top = sorted(by.items(), key=lambda kv: -kv[1][1])[:6]
+    ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+    roof = {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
+            "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
+            "how": "HIP-event pair around every tile-GEMM launch (rows > 64) of %d pipelined steps run right after the timed region with the same runner "
+                   "(algorithmic 2MNK of the un-padded shapes / sum of the bracketed durations; a bracket includes the dispatch gap in front of the kernel)" % steps,
+            "launches_per_step": round(len(g) / max(steps, 1), 1), "avg_launch_us": round(ms * 1e3 / max(len(g), 1), 2),
+            "alg_tflop_per_step": round(flops / max(steps, 1) / 1e12, 3), "ms_per_step_in_gemm": round(ms / max(steps, 1), 3),
+            "images_per_s_while_instrumented": round(args.batch * steps / wall, 2),
+            "top_shapes": [{"M": k[0], "N": k[1], "K": k[2], "kind": k[3], "launches_per_step": round(v[0] / steps, 1),
+                            "TFLOP/s": round(2.0 * k[0] * alg(k[1]) * alg(k[2]) * v[0] / (v[1] * 1e-3) / 1e12, 1)} for k, v in top]}
+    # ---- decode steps: bytes one step must read (weights of 36 layers + head table + KV of every row) / in-situ duration
+    W = model.W
+    wbytes = 0
+    for i in range(cfg.num_hidden_layers):
+        for nm in ("qkv", "o", "gu", "down"):
+            t_ = W.get(f"llm.{i}.{nm}.wq") if W.llm_weights == "fp8" else W[f"llm.{i}.{nm}.wp"]
+            wbytes += t_.numel() * t_.element_size()
+    head = W.get("llm.head.wp", W["llm.head"])
+    n_steps = sum(n for _, (n, rows) in d)
+    dms = sum(m for m, _ in d)
+    rows = max((r for _, (n, r) in d), default=0)
+    n_proto = rows * (inp["grid"][0, 1] * inp["grid"][0, 2] // 4).item()
+    kv_tok = 2 * cfg.num_key_value_heads * cfg.head_dim * 2 * cfg.num_hidden_layers
+    kv_bytes = rows * (inp["L"] + args.tnew / 2.0) * kv_tok
+    step_bytes = wbytes + head.numel() * head.element_size() + n_proto * cfg.hidden_size * 2 + kv_bytes
+    us = dms * 1e3 / max(n_steps, 1)
+    gbs = step_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
+    dec = {"bound": "hbm", "kernel": "one decode step = one hipGraph replay: %d x [norm+qkv, rope+append+split attention, merge, o+resid, norm+gate/up+SwiGLU, down+resid] "
+                                     "(gemm_skinny_kernel, decode_attn_rope_kernel) + vrt_head_kernel + greedy_step_kernel" % cfg.num_hidden_layers,
+           "rows_per_step": rows, "bytes_per_step": int(step_bytes), "weight_bytes_per_step": int(wbytes), "kv_bytes_per_step": int(kv_bytes),
+           "us_per_step": round(us, 1), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
+           "steps_timed": n_steps,
+           "how": "HIP-event pair around every chunk of graph replays on the decode stream during the same instrumented steps (the prefill of the "
+                  "next decode group runs concurrently on the other stream and takes CUs from the step)"}
+    return roof, dec
+
+
+def decode_alone_leg(model, inp, args, cfg, dec):
+    """The same decode-step graph with NOTHING else on the GPU: one decode group is prefilled, then all its steps run back to back alone
+    (the event bracket opens in stream order, i.e. after the group's last prefill)."""
+    from padt_amd import ops
+    gids = inp["proc"].assign_to_global_vrt_id(inp["ids"].clone(), inp["grid"])
+    for warm in (True, False):                                         # first pass: session allocation + graph capture
+        st = ops.EventTimer()
+        torch.cuda.synchronize()
+        ctx = None
+        for k in range(args.merge):
+            if k == args.merge - 1:
+                torch.cuda.synchronize()                               # the prefills of the other batches are done
+                ops.STEP_TIMER = st
+            ctx = model.generate_launch(gids, inp["am"], inp["pix"], inp["grid"], args.tnew, False, tuple(inp["sched"]), args.tnew, True, 7,
+                                        group=ctx, n_slots=args.merge)
+        model.generate_collect(ctx, all_batches=True)
+        torch.cuda.synchronize()
+        ops.STEP_TIMER = None
+        d = st.results()
+        st.close()
+    n = sum(k for _, (k, r) in d)
+    us = sum(m for m, _ in d) * 1e3 / max(n, 1)
+    dec["us_per_step_alone"] = round(us, 1)
+    dec["achieved_alone"] = round(dec["bytes_per_step"] / (us * 1e-6) / 1e9, 1) if us > 0 else 0.0
+    dec["frac_alone"] = round(dec["achieved_alone"] / HBM_PEAK_GBS, 4)
+    return dec
+
+
+def replay_leg(model, inp, args, cfg):
+    """The tile-GEMM launches of one step replayed back to back on an otherwise idle GPU (warm, no other kernels in between): the
+    family's rate without the pipeline around it → roofline.frac_replay."""
     from padt_amd import _lib, ops
     lib = _lib.load()
     ops.GEMM_LOG = []
     run_step(model, inp, args, 1)
     torch.cuda.synchronize()
     log, ops.GEMM_LOG = ops.GEMM_LOG, None
-    # launches that take a tile kernel (M > 64); "hp" entries are the split-precision decoder GEMMs (ops.gemm_hp: A = [hi | lo],
-    # W = [W | W], K' = 2K): their ALGORITHMIC work is the reference's 2*M*N*K, half of what the MFMA pipe executes
-    def rows_of(c):
-        return c[8] if c[0] == "hp" else (c[1].shape[0] if c[0] == "r32" else c[0].shape[0])
-    tile = [c for c in log if rows_of(c) > 64]
-    vip, vi = model.W.vit_ipad, cfg.vision_config.intermediate_size
-    lip, li = model.W.llm_ipad, cfg.intermediate_size
-    dip, di = model.W.dec_ipad, cfg.vl_decoder["intermediate_size"]
+    alg = _alg_dims(model, cfg)
 
-    def alg(n):                                                         # undo the zero padding of MLP intermediates
-        for pad, true in ((vip, vi), (lip, li), (dip, di)):
-            if n == pad:
-                return true
-            if n == 2 * pad:
-                return 2 * true
-        return n
-    flops = 0.0
+    def dims(c):
+        if c[0] == "hp":
+            return c[8], c[2].shape[0], c[2].shape[1] // 2
+        if c[0] == "r32":
+            return c[1].shape[0], c[2].shape[0], c[1].shape[1]
+        return c[0].shape[0], c[1].shape[0], (c[7] if c[7] is not None else c[0].shape[1])
+    tile = [c for c in log if dims(c)[0] > 64]
+    flops = sum(2.0 * M * alg(N) * alg(K) for M, N, K in map(dims, tile))
     alg_bytes = 0.0
     for c in tile:
-        if c[0] == "r32":                                               # fp32 residual stream: reads + writes fp32, writes the bf16 mirror
-            _, a, w, bias, x32, xb = c
-            flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(a.shape[1])
-            alg_bytes += 2.0 * (a.shape[0] * alg(a.shape[1]) + alg(w.shape[0]) * alg(a.shape[1])) + (8.0 + (2.0 if xb is not None else 0.0)) * a.shape[0] * w.shape[0]
-            continue
-        if isinstance(c[0], str):
-            _, a, w, bias, out, epi, res, out_mode, M = c
-            n, k = alg(w.shape[0]), alg(w.shape[1] // 2)
-            flops += 2.0 * M * n * k
-            alg_bytes += 4.0 * M * k + 2.0 * n * k + 4.0 * M * n * (2 if res is not None else 1)
-            continue
-        (a, w, bias, out, epi, res, f32, K, rs) = c
-        k = K if K is not None else a.shape[1]
-        flops += 2.0 * a.shape[0] * alg(w.shape[0]) * alg(k)
-        n_out = alg(w.shape[0]) // (2 if epi == 3 else 1)
-        alg_bytes += 2.0 * (a.shape[0] * alg(k) + alg(w.shape[0]) * alg(k)) + (4.0 if f32 else 2.0) * a.shape[0] * n_out \
-            + (2.0 * a.shape[0] * n_out if res is not None else 0.0)
-    import ctypes
-    ev0, ev1 = ctypes.c_void_p(), ctypes.c_void_p()
-    lib.padt_event_create(ctypes.byref(ev0))
-    lib.padt_event_create(ctypes.byref(ev1))
-    stream = torch.cuda.current_stream().cuda_stream
+        M, N, K = dims(c)
+        n_, k_ = alg(N), alg(K)
+        if c[0] == "hp":
+            alg_bytes += 4.0 * M * k_ + 2.0 * n_ * k_ + 4.0 * M * n_ * (2 if c[6] is not None else 1)
+        elif c[0] == "r32":
+            alg_bytes += 2.0 * (M * k_ + n_ * k_) + (8.0 + (2.0 if c[5] is not None else 0.0)) * M * n_
+        else:
+            n_out = n_ // (2 if c[4] == 3 else 1)
+            alg_bytes += 2.0 * (M * k_ + n_ * k_) + (4.0 if c[6] else 2.0) * M * n_out + (2.0 * M * n_out if c[5] is not None else 0.0)
 
     def replay():
         for c in tile:
             if c[0] == "r32":
                 ops.gemm_resid32(c[1], c[2], c[3], c[4], c[5])
-            elif isinstance(c[0], str):
+            elif c[0] == "hp":
                 ops.gemm_hp(c[1], c[2], c[3], out=c[4], epilogue=c[5], residual=c[6], out_mode=c[7], M=c[8])
             else:
                 (a, w, bias, out, epi, res, f32, K, rs) = c
                 ops.gemm(a, w, bias, out=out, epilogue=epi, residual=res, out_f32=f32, K=K, row_scale=rs)
     replay()
     torch.cuda.synchronize()
-    reps, best = 3, None
-    total = 0.0
+    t = ops.EventTimer()
+    tot = 0.0
+    reps = 3
     for _ in range(reps):
-        lib.padt_event_record(ev0, stream)
+        ev = t.begin()
         replay()
-        lib.padt_event_record(ev1, stream)
-        ms = ctypes.c_float()
-        lib.padt_event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
-        total += ms.value
-    if args.breakdown:                                             # per-shape efficiency of the tile kernel (stderr)
-        shapes = {}
-        for c in tile:
-            if isinstance(c[0], str):
-                continue
-            a, w, bias, out, epi, res, f32, K = c[:8]
-            shapes.setdefault((a.shape[0], w.shape[0], K if K is not None else a.shape[1], epi), []).append(c)
-        for key, calls in sorted(shapes.items()):
-            for c in calls[:2]:
-                ops.gemm(c[0], c[1], c[2], out=c[3], epilogue=c[4], residual=c[5], out_f32=c[6], K=c[7])
-            torch.cuda.synchronize()
-            lib.padt_event_record(ev0, stream)
-            for c in calls:
-                ops.gemm(c[0], c[1], c[2], out=c[3], epilogue=c[4], residual=c[5], out_f32=c[6], K=c[7])
-            lib.padt_event_record(ev1, stream)
-            ms = ctypes.c_float()
-            lib.padt_event_elapsed_ms(ev0, ev1, ctypes.byref(ms))
-            fl = 2.0 * key[0] * alg(key[1]) * alg(key[2]) * len(calls)
-            print(f"[gemm shape] M={key[0]:6d} N={key[1]:6d} K={key[2]:6d} epi={key[3]} x{len(calls):3d}: "
-                  f"{ms.value * 1e3 / len(calls):8.1f} us/call {fl / (ms.value * 1e-3) / 1e12:7.1f} TFLOP/s", file=sys.stderr)
-    lib.padt_event_destroy(ev0)
-    lib.padt_event_destroy(ev1)
-    ms_per_pass = total / reps
-    achieved = flops / (ms_per_pass * 1e-3) / 1e12
-    # HBM-side bytes per launch of the same launches from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE),
-    # and the family's IN-SITU rate from a rocprofv3 kernel trace of this command (tools/collect_profiles.sh, tools/insitu.py) — both
-    # collected separately, committed under profiles/, and only quoted for the workload / launch count they were measured on
+        t.end(ev, None)
+        tot += t.results()[0][0]
+    t.close()
+    ms = tot / reps
+    ach = flops / (ms * 1e-3) / 1e12
+    # HBM-side bytes per launch of the same launches from rocprofv3 PMC passes (FETCH_SIZE x2 per the gfx950 correction + WRITE_SIZE): collected
+    # separately (tools/collect_profiles.sh), committed under profiles/, and only quoted for the workload / launch count they were measured on
     import glob
-    pdir = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
-    traffic, traffic_src, in_situ = None, None, None
+    pdir = os.path.join(ROOT, "profiles")
+    traffic, traffic_src = None, None
     for tp in sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic.json")), reverse=True):
         tj = json.load(open(tp))
         wl = tj.get("workload", {})
@@ -240,20 +312,9 @@ def roofline_leg(model, inp, args, cfg):
                 and tj.get("gemm_calls", tj.get("launches")) == len(tile):
             traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tp)
             break
-    for tp in sorted(glob.glob(os.path.join(pdir, "r*_insitu.json")), reverse=True):
-        tj = json.load(open(tp))
-        wl = tj.get("workload", {})
-        if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and wl.get("task", "rec") == args.task \
-                and tj.get("gemm_calls_per_step") == len(tile):
-            in_situ = {"tflops": tj["in_situ_tflops"], "avg_launch_us": tj["avg_launch_us"], "source": "profiles/" + os.path.basename(tp),
-                       "note": "same launches inside the running pipeline (rocprofv3 kernel trace of bench.py --steps 20 --warmup 5)"}
-            break
-    return {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
-            "achieved": round(achieved, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": round(achieved / MFMA_BF16_PEAK_TFLOPS, 4), "traffic": traffic, "traffic_unit": "bytes per launch",
-            "traffic_source": traffic_src, "alg_bytes_per_launch": round(alg_bytes / max(len(tile), 1), 0),
-            "launches_per_step": len(tile), "avg_launch_us": round(ms_per_pass * 1e3 / max(len(tile), 1), 2),
-            "alg_tflop_per_step": round(flops / 1e12, 3), "ms_per_step_in_kernel": round(ms_per_pass, 3), "in_situ": in_situ}
+    return {"achieved_replay": round(ach, 1), "frac_replay": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "ms_per_step_replayed": round(ms, 3),
+            "launches_replayed": len(tile), "alg_bytes_per_launch": round(alg_bytes / max(len(tile), 1), 0), "traffic": traffic,
+            "traffic_unit": "bytes per launch", "traffic_source": traffic_src}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg
@@ -340,11 +401,89 @@ def cpu_baseline_leg(cfg, args, inp, model):
                       % (ids.shape[1], T, len(runs), len(runs[0]) if runs else 0, t_gen, T - 1, t_dec, t_img, cores, ncpu)}
 
 
+def short_run(model, inp, args, steps):
+    """images/s of `steps` batches through a fresh pipelined runner of the same shape as the headline's (priming pass untimed)."""
+    from padt_amd import pipeline
+    r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
+
+    def go(k):
+        for _ in range(k):
+            r.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
+        r.flush()
+    go(args.depth * args.merge)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go(steps)
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    return {"value": round(args.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3)}
+
+
+def extra_workloads(args, device, model3b, cfg3b, grid3b):
+    """BASELINE configs[3] and [4] per-GPU shapes, driver-timed as extra keys of the one JSON line (short runs, no side legs).  The OVD run
+    uses the headline's own PaDT_Pro_3B weights; the 7B model is built (random init, fp8 e4m3 decode weights) after the 3B one is released."""
+    import copy
+    out = {}
+    for key, over in (("ovd_3b", dict(model="3b", task="ovd", weights="bf16", tnew=28)), ("ric_7b_fp8", dict(model="7b", task="ric", weights="fp8", tnew=28))):
+        a = copy.copy(args)
+        for k, v in over.items():
+            setattr(a, k, v)
+        a.cap = 0
+        if key == "ovd_3b":
+            cfg, model, grid_hw = cfg3b, model3b, grid3b
+            model3b = None
+        else:
+            cfg, model, grid_hw = build_model(a, device)
+        inp = make_inputs(cfg, a, grid_hw, device, seed=4321)
+        steps = 16
+        r = short_run(model, inp, a, steps)
+        alg = alg_tflop_per_image(cfg, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
+        r.update({"workload": "%s %s, batch=%d/GPU, L=%d, T_new=%d, %d obj x %d VRT per image, %s LLM weights in the decode steps" % (
+            {"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)"}[a.model], a.task.upper(), a.batch, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], a.weights),
+            "alg_tflop_per_image": round(alg, 3), "mfma_frac_e2e": round(r["value"] * alg / MFMA_BF16_PEAK_TFLOPS, 4)})
+        out[key] = r
+        del model, inp
+        torch.cuda.empty_cache()
+    return out
+
+
+def from_images_leg(model, inp, args, grid_hw, steps):
+    """The headline pipeline fed from HOST images: 8 uint8 640x640x3 images in pinned memory per batch → H2D → bicubic resize to 644x644
+    (Pillow's resampler on the device, byte-exact) → normalize + patchify → the same runner.  f2 of SURVEY.md §8f timed in the loop."""
+    from padt_amd import pipeline
+    from padt_amd.preprocess import ImageFrontEnd
+    fe = ImageFrontEnd(inp["pix"].device)
+    g = torch.Generator().manual_seed(99)
+    hh, ww = grid_hw[0] * 14 - 4, grid_hw[1] * 14 - 4                  # 640 x 640 for the 46 x 46 grid: smart_resize brings it to 644 x 644
+    host = [torch.randint(0, 256, (hh, ww, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(args.batch)]
+    pix, grid = fe(host)
+    assert pix.shape == inp["pix"].shape and grid.tolist() == inp["grid"].tolist(), (pix.shape, grid.tolist())
+    r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
+
+    def go(k):
+        for _ in range(k):
+            pv, gr = fe(host)
+            r.submit(inp["ids"].clone(), inp["am"], pv, gr, max_new_tokens=args.tnew, schedule=inp["sched"])
+        r.flush()
+    go(args.depth * args.merge)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go(steps)
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    return {"value": round(args.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3),
+            "host_bytes_per_image": hh * ww * 3,
+            "note": "timed region starts at uint8 HWC images in pinned host memory: H2D + GPU resize + normalize + patchify inside the loop"}
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world and world == 1 and args.gpus > 1:
+        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+        sys.exit(2)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -373,43 +512,68 @@ def main():
     from padt_amd import pipeline
     runner = (pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge, shared_prefill_stream=not args.lane_streams)
               if (args.depth > 1 or args.merge > 1) else None)
+    # data-parallel exchange (world > 1): device-side pack of every batch's record, ONE asynchronous all-gather per decode group
+    exchange = None
+    gathered = []
+    if world > 1:
+        mask_hw = 4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max()))
+        exchange = pipeline.ResultExchange(args.cap, mask_hw, per_gather=args.merge, device=device)
+    dump = [] if args.dump_exchange else None
 
-    def gather(decoded):
-        if world > 1:
-            packed = pipeline.pack_results(decoded, cap=args.cap, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
-                                           device=inp["pix"].device)
-            pipeline.all_gather_results(packed)
+    def deliver(decoded):
+        if dump is not None:
+            dump.append({k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in decoded.items() if k in ("pred_boxes", "pred_score", "pred_mask", "sample_idx")})
+        if exchange is not None:
+            gathered.extend(exchange.add(decoded))
 
     def run_steps(k, runner=runner):
         """k steps = k batches through the whole path; with depth > 1 consecutive batches overlap on separate streams
-        (every batch is complete — results on the host side of vl_decode — before this returns)."""
+        (every batch is complete — results on the host side of vl_decode, exchange issued — before this returns)."""
         last = None
         if k <= 0:
             return last
         if runner is None:
             for _ in range(k):
-                last = run_step(model, inp, args, world)
-            return last
-        for _ in range(k):
-            for r in runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]):
+                last = run_step(model, inp, args, 1)
+                deliver(last)
+        else:
+            for _ in range(k):
+                for r in runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]):
+                    last = r[0]
+                    deliver(last)
+            for r in runner.flush():
                 last = r[0]
-                gather(last)
-        for r in runner.flush():
-            last = r[0]
-            gather(last)
+                deliver(last)
+        if exchange is not None:
+            gathered.extend(exchange.flush())                      # the run's last (possibly partial) group: waited for inside the timed region
         return last
 
     if runner is not None:
         run_steps(args.depth * args.merge)      # one-time: every lane allocates its session and captures its decode graph
     run_steps(args.warmup)
+    if dump is not None:
+        dump.clear()
+    gathered.clear()
     barrier()
     t0 = time.perf_counter()
     decoded = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert decoded["pred_boxes"].shape == (args.batch * inp["n_obj"], 4) and torch.isfinite(decoded["pred_boxes"]).all()
+    if args.dump_exchange:                                             # tests: what this rank computed and what it received from everybody
+        os.makedirs(args.dump_exchange, exist_ok=True)
+        torch.save({"local": dump, "gathered": [g.cpu() for g in gathered], "cap": args.cap, "batch": args.batch},
+                   os.path.join(args.dump_exchange, f"rank{rank}.pt"))
+
+    side = world == 1 and rank == 0 and not args.no_alt
     # same workload with every batch decoding alone (merge = 1, two batches in flight), for comparison in the same run
     alt = None
-    if runner is not None and args.merge > 1 and world == 1 and not args.no_alt:
+    if side and runner is not None and args.merge > 1:
         r1 = pipeline.PipelinedRunner(model, inp["proc"], depth=2, merge=1)
         run_steps(3, r1)
         barrier()
@@ -421,15 +585,9 @@ def main():
         alt = {"value": round(args.batch * k1 / e1, 3), "unit": "images/s", "steps": k1, "ms_per_step": round(e1 / k1 * 1e3, 3),
                "note": "decode groups of ONE batch (8 rows per decode step), 2 batches in flight"}
         del r1
-    if world > 1:
-        import torch.distributed as dist
-        t = torch.tensor([elapsed], device=device, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    assert decoded["pred_boxes"].shape == (args.batch * inp["n_obj"], 4) and torch.isfinite(decoded["pred_boxes"]).all()
     # latency of ONE batch running alone (depth 1, merge 1: no other batch in flight), same workload
     lat = None
-    if world == 1 and not args.no_alt:
+    if side:
         for _ in range(2):
             run_step(model, inp, args, 1)
         torch.cuda.synchronize()
@@ -440,7 +598,8 @@ def main():
         torch.cuda.synchronize()
         el = (time.perf_counter() - tl) / kl
         lat = {"ms_per_batch": round(el * 1e3, 3), "images_per_s": round(args.batch / el, 3),
-               "note": "one batch alone on the GPU (depth 1, merge 1): ViT + prefill + decode + parse + PaDT decoder back to back"}
+               "note": "one batch alone on the GPU (depth 1, merge 1): ViT + prefill + decode at 8 rows per step + parse + PaDT decoder back to back; "
+                       "GPU-bound (host enqueue time of the whole batch ≈ 7 ms, tools/latency_breakdown.py)"}
 
     if args.timeline and runner is not None and rank == 0:
         # stream timeline of a few pipelined steps (events on the prefill / per-lane decode streams), ms from the first mark
@@ -458,29 +617,14 @@ def main():
             print(f"[timeline] {t:8.2f} ms  batch {b - b0}  {tag}", file=sys.stderr)
         runner.trace = None
 
-    if args.breakdown and rank == 0:
-        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
-        from padt_amd.llm import plan_prompt
-        torch.cuda.synchronize()
-        ev[0].record()
-        low, high, pe = model.visual(inp["pix"], inp["grid"])
-        ev[1].record()
-        t1 = time.perf_counter()
-        out = model.generate(input_ids=inp["ids"].clone(), attention_mask=inp["am"], pixel_values=inp["pix"], image_grid_thw=inp["grid"],
-                             max_new_tokens=args.tnew, schedule=inp["sched"], sync_every=args.tnew)
-        ev[2].record()
-        torch.cuda.synchronize()
-        print(f"[breakdown] vit {ev[0].elapsed_time(ev[1]):.2f} ms; generate (vit+prefill+decode) {ev[1].elapsed_time(ev[2]):.2f} ms",
-              file=sys.stderr)
-
     if rank == 0:
         n_img = args.batch * args.steps * world
         value = n_img / elapsed
         alg_tf = alg_tflop_per_image(cfg, inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
-        fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 (split-precision "
-               "PaDT decoder" + (", fp8 e4m3 LLM weights in the decode steps" if args.weights == "fp8" else "") + "), random-init weights; "
-               "batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps of %d consecutive batches share one "
-               "weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
+        fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 MFMA operands, fp32 "
+               "residual streams in ViT / LLM, split-precision PaDT decoder" + (", fp8 e4m3 LLM weights in the decode steps" if args.weights == "fp8" else "") +
+               ", random-init weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps of %d consecutive "
+               "batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
         wl = fmt % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
                     args.batch, grid_hw[0], grid_hw[1], inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], args.batch, args.merge)
         line = {
@@ -495,14 +639,29 @@ def main():
             "alg_tflops_e2e": round(value * alg_tf, 1),
             "mfma_frac_e2e": round(value * alg_tf / MFMA_BF16_PEAK_TFLOPS / world, 4),
         }
+        if exchange is not None:
+            line["exchange"] = {"all_gathers": exchange.n_gathers, "batches_per_gather": args.merge, "bytes_per_rank_per_gather": exchange.words * 4 * args.merge,
+                                "note": "device-side pack (one kernel per batch) + one asynchronous all_gather_into_tensor per decode group"}
         if lat is not None:
             line["single_batch_latency"] = lat
         if alt is not None:
             line["unmerged_decode"] = alt
-        if not args.no_roofline:
-            line["roofline"] = roofline_leg(model, inp, args, cfg)
+        if world == 1 and not args.no_roofline and runner is not None:
+            roof, dec = insitu_leg(model, inp, args, cfg, run_steps, min(args.steps, 16))
+            roof.update(replay_leg(model, inp, args, cfg))
+            line["roofline"] = roof
+            line["roofline_decode"] = decode_alone_leg(model, inp, args, cfg, dec)
+        if world == 1 and args.from_images and runner is not None:
+            line["from_images"] = from_images_leg(model, inp, args, grid_hw, min(args.steps, 24))
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline_leg(cfg, args, inp, model)
+        if "cpu_baseline" in line:
+            line["parity_vs_oracle"] = line["cpu_baseline"]["parity"]      # top level too: the metric's "box IoU vs ref" read-out of this run
+        if world == 1 and args.extras:
+            del runner
+            m3, model = model, None
+            line["extra_workloads"] = extra_workloads(args, device, m3, cfg, grid_hw)
+            del m3
         print(json.dumps(line), flush=True)
     if world > 1:
         import torch.distributed as dist

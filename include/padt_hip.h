@@ -259,6 +259,16 @@ int padt_patchify_normalize(void* stream, const void* img_u8, int H, int W, cons
 int padt_resample_pass_u8(void* stream, const void* in_u8, int in_h, int in_w, int channels, void* out_u8, int out_h, int out_w,
                           const int* bounds, const int* kk, int ksize, int horizontal);
 
+/* ---- data-parallel result exchange ---------------------------------------------------------------------------------------------
+ * One batch's vl_decode output as ONE fixed-capacity int32 record (floats as bit patterns):
+ *   [n, cap, mask_hw, has_mask | sample_idx (cap) | valid_hw (2 cap) | boxes (4 cap) | scores (cap) | mask logits (cap * mask_hw^2)]
+ * words = 4 + 8 cap + cap mask_hw^2; zero outside the n objects / the H x W window.  masks_f32 may be null (no mask head).  The records of
+ * every rank then move with one RCCL all-gather (the reference gathers per-rank JSONL files on disk: eval/evaluation_scripts/utils.py:
+ * 249-266 writes them, eval_refcoco.py / eval_coco.py read all eight). */
+int padt_pack_results(void* stream, void* out_i32, long words, int n, int cap, int mask_hw, const int* sample_idx, const long* valid_h,
+                      const long* valid_w, const void* boxes_f32, long ld_box, const void* scores_f32, long ld_score, const void* masks_f32,
+                      long ld_obj, long ld_row, int H, int W);
+
 #ifdef __cplusplus
 }
 #endif

@@ -712,3 +712,55 @@ extern "C" int padt_patchify_normalize(void* stream, const void* img_u8, int H, 
     PADT_CHECK_LAUNCH("patchify_normalize");
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// Result record of the data-parallel exchange (pipeline.pack_results, SURVEY.md §8e: the decoded boxes / masks of one batch as ONE
+// fixed-capacity record, so that one all-gather moves it).  32-bit words:
+//   [n, cap, mask_hw, has_mask | sample_idx (cap) | valid_hw (2 cap) | boxes f32 (4 cap) | scores f32 (cap) | mask logits f32 (cap * mask_hw^2)]
+// floats travel as their bit patterns; everything outside the n valid objects / the H x W mask window is zero.  One thread per word, no host
+// round trip (the torch statement of this pack was a dozen small ops + three pageable H2D copies per batch).
+struct PackArgs {
+    int* out; long words;
+    int n, cap, mask_hw, has_mask;
+    const int* sample_idx; const long* valid_h; const long* valid_w;
+    const float* boxes; long ld_box; const float* scores; long ld_score;
+    const float* masks; long ld_obj, ld_row; int H, W;
+};
+
+__global__ __launch_bounds__(256) void pack_results_kernel(PackArgs p) {
+    const long o_idx = 4, o_hw = o_idx + p.cap, o_box = o_hw + 2L * p.cap, o_sc = o_box + 4L * p.cap, o_mask = o_sc + p.cap;
+    const long plane = (long)p.mask_hw * p.mask_hw;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < p.words; i += (long)gridDim.x * blockDim.x) {
+        int v = 0;
+        if (i < o_idx) v = i == 0 ? p.n : (i == 1 ? p.cap : (i == 2 ? p.mask_hw : p.has_mask));
+        else if (i < o_hw) { const long k = i - o_idx; if (k < p.n) v = p.sample_idx[k]; }
+        else if (i < o_box) { const long k = (i - o_hw) >> 1; if (k < p.n && p.has_mask) v = (int)(((i - o_hw) & 1) ? p.valid_w[k] : p.valid_h[k]); }
+        else if (i < o_sc) { const long k = (i - o_box) >> 2; if (k < p.n) v = __builtin_bit_cast(int, p.boxes[k * p.ld_box + ((i - o_box) & 3)]); }
+        else if (i < o_mask) { const long k = i - o_sc; if (k < p.n) v = __builtin_bit_cast(int, p.scores[k * p.ld_score]); }
+        else if (p.has_mask) {
+            const long k = (i - o_mask) / plane, r = (i - o_mask) % plane;
+            const int y = (int)(r / p.mask_hw), x = (int)(r % p.mask_hw);
+            if (k < p.n && y < p.H && x < p.W) v = __builtin_bit_cast(int, p.masks[k * p.ld_obj + (long)y * p.ld_row + x]);
+        }
+        p.out[i] = v;
+    }
+}
+
+extern "C" int padt_pack_results(void* stream, void* out_i32, long words, int n, int cap, int mask_hw, const int* sample_idx, const long* valid_h,
+                                 const long* valid_w, const void* boxes_f32, long ld_box, const void* scores_f32, long ld_score,
+                                 const void* masks_f32, long ld_obj, long ld_row, int H, int W) {
+    const int has_mask = (masks_f32 != nullptr && n > 0) ? 1 : 0;
+    if (n < 0 || n > cap || words != 4 + 8L * cap + (long)cap * mask_hw * mask_hw || (has_mask && (H > mask_hw || W > mask_hw)) ||
+        (n > 0 && (sample_idx == nullptr || boxes_f32 == nullptr || scores_f32 == nullptr)) || (has_mask && (valid_h == nullptr || valid_w == nullptr))) {
+        padt_set_error("padt_pack_results: n <= cap, words = 4 + 8 cap + cap mask_hw^2, mask H, W <= mask_hw and non-null fields required");
+        return -1;
+    }
+    PackArgs a{(int*)out_i32, words, n, cap, mask_hw, has_mask, sample_idx, valid_h, valid_w, (const float*)boxes_f32, ld_box,
+               (const float*)scores_f32, ld_score, (const float*)masks_f32, ld_obj, ld_row, H, W};
+    long blocks = (words + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, a);
+    PADT_CHECK_LAUNCH("pack_results");
+    return 0;
+}
+

@@ -275,8 +275,12 @@ class DecodeSession:
             with torch.cuda.graph(g):
                 self.step_kernels()
             self.graphs[self.do_sample] = g
+        t = ops.STEP_TIMER
+        ev = t.begin() if t is not None else None
         for _ in range(n):
             self.graphs[self.do_sample].replay()
+        if ev is not None:
+            t.end(ev, (n, self.B))
 
 
 class LanguageModel:

@@ -395,8 +395,9 @@ class PaDTForConditionalGeneration:
             high_res_image_embeds = ops.cast_f32_bf16(high_res_image_embeds.contiguous())
         bbox, score, masks, hw = self.vl_decoder.forward_objects(
             feats_cat, n_vp, low_res_image_embeds, high_res_image_embeds, visual_pes, obj_sample, patch_off, patch_num, grids)
+        # "sample_idx_t": the same list as a device tensor (cached with the decoder's plan) for the device-side result pack
         return {"pred_boxes": bbox, "pred_score": score, "pred_mask": masks, "pred_mask_valid_hw": hw,
-                "sample_idx": obj_sample}
+                "sample_idx": obj_sample, "sample_idx_t": self.vl_decoder.last_sample_t}
 
     def forward(self, *args, is_main=True, **kwargs):
         if is_main:

@@ -25,6 +25,60 @@ def _chk_bf16(*ts):
 GEMM_LOG = None   # bench.py sets this to a list to record (and later replay) every GEMM launch of one step
 
 
+class EventTimer:
+    """HIP-event brackets on the stream a kernel is launched on (bench.py's in-situ roofline: torch.cuda.Event only sees torch's current
+    stream object, these see whatever stream the launch uses).  begin() / end(ev, meta) around a launch; results() → [(ms, meta)]."""
+
+    def __init__(self):
+        import ctypes
+        self._ct = ctypes
+        self.recs = []
+        self._free = []
+        self._all = []
+
+    def _event(self):
+        if self._free:
+            return self._free.pop()
+        ev = self._ct.c_void_p()
+        _lib.check(_lib.load().padt_event_create(self._ct.byref(ev)), "padt_event_create")
+        self._all.append(ev)
+        return ev
+
+    def begin(self):
+        ev = self._event()
+        _lib.load().padt_event_record(ev, _stream())
+        return ev
+
+    def end(self, ev0, meta):
+        ev1 = self._event()
+        _lib.load().padt_event_record(ev1, _stream())
+        self.recs.append((ev0, ev1, meta))
+
+    def results(self):
+        out = []
+        ms = self._ct.c_float()
+        for ev0, ev1, meta in self.recs:
+            _lib.check(_lib.load().padt_event_elapsed_ms(ev0, ev1, self._ct.byref(ms)), "padt_event_elapsed_ms")
+            out.append((ms.value, meta))
+            self._free += [ev0, ev1]
+        self.recs = []
+        return out
+
+    def close(self):
+        for ev in self._all:
+            _lib.load().padt_event_destroy(ev)
+        self._all, self._free, self.recs = [], [], []
+
+
+GEMM_TIMER = None   # an EventTimer: every tile-GEMM launch (rows > 64) is bracketed, meta = (kind, M, N, K)
+STEP_TIMER = None   # an EventTimer: every chunk of decode-step graph replays is bracketed (llm.DecodeSession.run_steps), meta = (steps, rows)
+
+
+def _tg_begin(M):
+    t = GEMM_TIMER
+    return t.begin() if (t is not None and M > 64) else None
+
+
 def row_rstd(x, eps=1e-6, out=None):
     """fp32 rsqrt(mean(x^2) + eps) per row — feeds gemm(..., row_scale=) for an RMSNorm whose weight is folded into W."""
     M, D = x.shape
@@ -50,9 +104,12 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
         assert row_scale.dtype == torch.float32 and row_scale.numel() >= M and row_scale.is_contiguous()
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K, row_scale))
+    ev = _tg_begin(M)
     _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
                                   _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
                                   1 if out_f32 else 0, _p(row_scale)), "padt_gemm_bf16")
+    if ev is not None:
+        GEMM_TIMER.end(ev, ("gemm", M, N, K))
     return out
 
 
@@ -65,8 +122,11 @@ def gemm_resid32(a, w, bias, x32, xb=None):
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and x32.shape[0] >= M and x32.shape[1] >= N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("r32", a, w, bias, x32, xb))
+    ev = _tg_begin(M)
     _lib.check(lib.padt_gemm_resid32(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
                                      xb.stride(0) if xb is not None else 0, M, N, K), "padt_gemm_resid32")
+    if ev is not None:
+        GEMM_TIMER.end(ev, ("r32", M, N, K))
     return x32
 
 
@@ -85,9 +145,12 @@ def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
     assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(0) == sin.stride(0)
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, EPI_NONE, None, False, None, row_scale))
+    ev = _tg_begin(M)
     _lib.check(lib.padt_gemm_rope_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                        _p(row_scale), _p(cos), _p(sin), cos.stride(0), int(rope_cols), int(head_dim)),
                "padt_gemm_rope_bf16")
+    if ev is not None:
+        GEMM_TIMER.end(ev, ("gemm", M, N, K))
     return out
 
 
@@ -498,9 +561,12 @@ def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, 
         lo_off = N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("hp", a_split, w2, bias, out, epilogue, residual, out_mode, M))
+    ev = _tg_begin(M)
     _lib.check(lib.padt_gemm_bf16_ex(_stream(), _p(a_split), a_split.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out), out.stride(0),
                                      _p(residual), residual.stride(0) if residual is not None else 0, M, N, K2, epilogue,
                                      1 if out_mode == OUT_F32 else 0, 0, 1 if residual is not None else 0, lo_off), "padt_gemm_bf16_ex")
+    if ev is not None:
+        GEMM_TIMER.end(ev, ("hp", M, N, K2 // 2))                     # algorithmic K: the MFMA pipe executes 2K (hi and lo operands)
     return out
 
 
@@ -568,6 +634,21 @@ def resample_pass_u8(img, out, bounds, kk, horizontal):
     assert bounds.shape == (n, 2) and kk.shape[0] == n and img.shape[2] == out.shape[2]
     _lib.check(_lib.load().padt_resample_pass_u8(_stream(), _p(img), img.shape[0], img.shape[1], img.shape[2], _p(out), out.shape[0],
                                                  out.shape[1], _p(bounds), _p(kk), kk.shape[1], 1 if horizontal else 0), "padt_resample_pass_u8")
+    return out
+
+
+def pack_results(out, n, cap, mask_hw, sample_idx, valid_h, valid_w, boxes, scores, masks):
+    """One batch's vl_decode output → the fixed-capacity int32 exchange record `out` (padt_pack_results), on the current stream."""
+    assert out.dtype == torch.int32 and out.is_contiguous() and out.is_cuda
+    H, Wd = (masks.shape[1], masks.shape[2]) if masks is not None else (0, 0)
+    if n:
+        assert sample_idx.dtype == torch.int32 and boxes.dtype == torch.float32 and scores.dtype == torch.float32
+        assert boxes.stride(-1) == 1 and (masks is None or (masks.dtype == torch.float32 and masks.stride(-1) == 1))
+        assert masks is None or (valid_h.dtype == torch.int64 and valid_w.dtype == torch.int64)
+    _lib.check(_lib.load().padt_pack_results(_stream(), _p(out), out.numel(), int(n), int(cap), int(mask_hw), _p(sample_idx), _p(valid_h), _p(valid_w),
+                                             _p(boxes), boxes.stride(0) if n else 0, _p(scores), scores.stride(0) if n else 0,
+                                             _p(masks) if n else 0, masks.stride(0) if masks is not None else 0,
+                                             masks.stride(1) if masks is not None else 0, int(H), int(Wd)), "padt_pack_results")
     return out
 
 

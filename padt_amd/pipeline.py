@@ -160,14 +160,29 @@ def _record_words(cap: int, mask_hw: int) -> int:
     return _HDR + cap * (1 + 2 + 4 + 1) + cap * mask_hw * mask_hw
 
 
-def pack_results(decoded: dict, cap: int, mask_hw: int, device) -> torch.Tensor:
-    """vl_decode output → one int32 record (floats bit-cast) of fixed size, so every rank contributes the same shape."""
+def pack_results(decoded: dict, cap: int, mask_hw: int, device, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """vl_decode output → one int32 record (floats bit-cast) of fixed size, so every rank contributes the same shape.
+    On the GPU this is ONE kernel launch (padt_pack_results: no host round trip, no H2D copy); host tensors (the protocol tests) are
+    packed with the equivalent indexing statements below."""
     n = decoded["pred_boxes"].shape[0]
     if n > cap:
         raise ValueError(f"{n} objects exceed the exchange capacity {cap}")
-    buf = torch.zeros(_record_words(cap, mask_hw), dtype=torch.int32, device=device)
-    fbuf = buf.view(torch.float32)
+    words = _record_words(cap, mask_hw)
     has_mask = decoded.get("pred_mask") is not None and n > 0
+    if has_mask and (decoded["pred_mask"].shape[1] > mask_hw or decoded["pred_mask"].shape[2] > mask_hw):
+        raise ValueError(f"mask {tuple(decoded['pred_mask'].shape[1:])} exceeds exchange capacity {mask_hw}")
+    if torch.device(device).type == "cuda":
+        from . import ops
+        buf = out if out is not None else torch.empty(words, dtype=torch.int32, device=device)
+        sidx = decoded.get("sample_idx_t")
+        if n and (sidx is None or sidx.numel() != n):                 # a dict that did not come from vl_decode
+            sidx = torch.tensor(decoded["sample_idx"], dtype=torch.int32).to(device, non_blocking=True)
+        hw = decoded["pred_mask_valid_hw"] if has_mask else (None, None)
+        return ops.pack_results(buf, n, cap, mask_hw, sidx, hw[0], hw[1], decoded["pred_boxes"] if n else None,
+                                decoded["pred_score"] if n else None, decoded["pred_mask"] if has_mask else None)
+    buf = out if out is not None else torch.empty(words, dtype=torch.int32, device=device)
+    buf.zero_()
+    fbuf = buf.view(torch.float32)
     buf[:_HDR] = torch.tensor([n, cap, mask_hw, 1 if has_mask else 0], dtype=torch.int32, device=device)
     o = _HDR
     if n:
@@ -183,8 +198,6 @@ def pack_results(decoded: dict, cap: int, mask_hw: int, device) -> torch.Tensor:
     o += cap
     if has_mask:
         H, Wd = decoded["pred_mask"].shape[1:]
-        if H > mask_hw or Wd > mask_hw:
-            raise ValueError(f"mask {H}x{Wd} exceeds exchange capacity {mask_hw}")
         fbuf[o:].view(cap, mask_hw, mask_hw)[:n, :H, :Wd] = decoded["pred_mask"].to(device=device, dtype=torch.float32)
         hw[:n, 0] = decoded["pred_mask_valid_hw"][0].to(device=device, dtype=torch.int32)
         hw[:n, 1] = decoded["pred_mask_valid_hw"][1].to(device=device, dtype=torch.int32)
@@ -227,3 +240,56 @@ def rank_batches(n_items: int, batch_size: int, rank: int, world: int):
     import math
     all_number = math.ceil(n_items / (world * batch_size)) * world * batch_size
     return list(range(rank * batch_size, all_number, world * batch_size))
+
+
+class ResultExchange:
+    """The data-parallel exchange without lock-step: every rank packs `per_gather` consecutive batch records (normally one decode group)
+    into one buffer and issues ONE asynchronous all_gather_into_tensor for them (RCCL runs it on its own stream); the handle is only waited
+    on when the NEXT gather is issued or at flush(), so ranks meet once per decode group at most and a straggler delays nobody's compute.
+    Every rank must add() the same number of batches.
+
+        ex = ResultExchange(cap, mask_hw, per_gather=8, device=dev)
+        for decoded in ...: done += ex.add(decoded)        # → list of (world, per_gather, words) int32 tensors whose gather completed
+        done += ex.flush()
+    """
+
+    def __init__(self, cap: int, mask_hw: int, per_gather: int, device, group=None):
+        import torch.distributed as dist
+        self.cap, self.mask_hw, self.per, self.device, self.group = cap, mask_hw, max(1, per_gather), device, group
+        self.world = dist.get_world_size(group)
+        self.words = _record_words(cap, mask_hw)
+        self._bufs = [torch.zeros((self.per, self.words), dtype=torch.int32, device=device) for _ in range(2)]   # double buffer
+        self._outs = [torch.empty((self.world, self.per, self.words), dtype=torch.int32, device=device) for _ in range(2)]
+        self._cur, self._fill, self._inflight = 0, 0, None
+        self.n_gathers = 0
+
+    def add(self, decoded: dict) -> List[torch.Tensor]:
+        pack_results(decoded, self.cap, self.mask_hw, self.device, out=self._bufs[self._cur][self._fill])
+        self._fill += 1
+        return self._launch() if self._fill == self.per else []
+
+    def _wait(self) -> List[torch.Tensor]:
+        if self._inflight is None:
+            return []
+        work, out = self._inflight
+        work.wait()
+        self._inflight = None
+        return [out]
+
+    def _launch(self) -> List[torch.Tensor]:
+        import torch.distributed as dist
+        done = self._wait()                                            # at most one gather in flight: its buffers are free again
+        buf, out = self._bufs[self._cur], self._outs[self._cur]
+        if self._fill < self.per:
+            buf[self._fill:].zero_()                                   # partially filled last group: n = 0 records
+        work = dist.all_gather_into_tensor(out.view(-1), buf.view(-1), group=self.group, async_op=True)
+        self._inflight = (work, out)
+        self.n_gathers += 1
+        self._cur ^= 1
+        self._fill = 0
+        return done
+
+    def flush(self) -> List[torch.Tensor]:
+        done = self._launch() if self._fill else []
+        return done + self._wait()
+

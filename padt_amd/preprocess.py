@@ -214,9 +214,16 @@ class ImageFrontEnd:
         else:
             imgs = []
             for im in images:
-                arr = self._to_rgb_array(im)
-                cur = torch.from_numpy(arr).to(self.device, non_blocking=True)
-                for (ow, oh, flt) in self._plan_sizes(arr.shape[1], arr.shape[0]):
+                if isinstance(im, torch.Tensor):                   # (H, W, 3) uint8, host (ideally pinned: the copy is then asynchronous) or device
+                    if im.dtype != torch.uint8 or im.dim() != 3 or im.shape[2] != 3:
+                        raise ValueError(f"tensor images must be (H, W, 3) uint8, got {tuple(im.shape)} {im.dtype}")
+                    cur = im.to(self.device, non_blocking=True).contiguous()
+                    h0, w0 = int(im.shape[0]), int(im.shape[1])
+                else:
+                    arr = self._to_rgb_array(im)
+                    cur = torch.from_numpy(arr).to(self.device, non_blocking=True)
+                    h0, w0 = arr.shape[0], arr.shape[1]
+                for (ow, oh, flt) in self._plan_sizes(w0, h0):
                     cur = self.resize_device(cur, ow, oh, flt)
                 imgs.append(cur)
         grids = [[1, a.shape[0] // self.patch, a.shape[1] // self.patch] for a in imgs]

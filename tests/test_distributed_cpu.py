@@ -69,3 +69,47 @@ def test_pack_capacity_errors():
         pipeline.pack_results(_fake_decoded(0, 5), cap=4, mask_hw=32, device="cpu")
     with pytest.raises(ValueError, match="exceeds exchange capacity"):
         pipeline.pack_results(_fake_decoded(0, 2), cap=4, mask_hw=16, device="cpu")
+
+
+def _worker_exchange(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = pipeline.ResultExchange(cap=8, mask_hw=32, per_gather=3, device="cpu")
+    done = []
+    for b in range(7):                                          # 7 batches, 3 per gather → gathers of 3, 3 and 1 (+ 2 empty records)
+        n = (b + rank) % 4                                      # ragged object counts, some batches empty
+        dec = _fake_decoded(10 * rank + b, n) if n else {"pred_boxes": torch.zeros(0, 4), "pred_score": torch.zeros(0, 1),
+                                                         "pred_mask": torch.zeros(0, 8, 8), "sample_idx": [], "pred_mask_valid_hw": ()}
+        done += [t.clone() for t in ex.add(dec)]
+    done += [t.clone() for t in ex.flush()]
+    q.put((rank, ex.n_gathers, [d.clone() for d in done]))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_result_exchange_groups_gather_asynchronously_and_in_order():
+    """ResultExchange: one asynchronous all-gather per group of batches, at most one in flight, results delivered in submission order;
+    every rank sees every rank's records bit for bit (incl. empty batches and the zero-padded tail group)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_gathers, done in got:
+        assert n_gathers == 3 and len(done) == 3
+        recs = torch.cat(done, dim=1)                           # (world, 9, words): 7 real batches + 2 zero records
+        assert recs.shape[:2] == (2, 9)
+        for r in range(2):
+            for b in range(9):
+                res = pipeline.unpack_results(recs[r, b][None], batch_per_rank=0)[0]
+                n = (b + r) % 4 if b < 7 else 0
+                assert res["boxes"].shape == (n, 4)
+                if n:
+                    ref = _fake_decoded(10 * r + b, n)
+                    assert torch.equal(res["boxes"], ref["pred_boxes"]) and torch.equal(res["masks"][:, :24, :32], ref["pred_mask"])
+                    assert res["sample_idx"].tolist() == ref["sample_idx"]

@@ -611,14 +611,17 @@ def test_bench_contract_small_config():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "cpu_baseline"):
+              "data", "config", "roofline", "roofline_decode", "from_images", "cpu_baseline", "parity_vs_oracle"):
         assert k in d, k
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
     assert d["unit"] == "images/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
     rf = d["roofline"]
-    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "frac_replay", "how"):
         assert k in rf, k
     assert rf["bound"] in ("hbm", "mfma") and abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-3
+    rd = d["roofline_decode"]
+    assert rd["bound"] == "hbm" and rd["rows_per_step"] == 64 and rd["us_per_step"] > 0 and rd["us_per_step_alone"] > 0 and rd["bytes_per_step"] > 0
+    assert abs(rd["frac"] - rd["achieved"] / rd["peak"]) < 1e-3 and d["from_images"]["value"] > 0
     cb = d["cpu_baseline"]
     for k in ("value", "unit", "cores", "kind", "sample", "parity"):
         assert k in cb, k
@@ -626,3 +629,67 @@ def test_bench_contract_small_config():
     same, total = (int(v) for v in cb["parity"]["tokens_equal_oracle_argmax"].split("/"))
     assert total > 0 and same >= total - 2, cb["parity"]
     assert all(iou > 0.9 for iou in cb["parity"]["box_iou_vs_oracle"]), cb["parity"]
+
+
+def test_pack_results_kernel_matches_the_host_statement():
+    """padt_pack_results (one launch, no host round trip) == the indexing statements of pipeline.pack_results on host copies, bit for
+    bit: header, sample indices, valid sizes, boxes, scores, mask window, zeros elsewhere; empty batch; no mask head."""
+    from padt_amd import pipeline
+    g = torch.Generator().manual_seed(5)
+    for n, H, Wd, cap, mhw in ((5, 24, 32, 8, 40), (8, 40, 40, 8, 40), (0, 8, 8, 4, 16)):
+        dec = {"pred_boxes": torch.rand(n, 4, generator=g), "pred_score": torch.randn(n, 1, generator=g), "pred_mask": torch.randn(n, H, Wd, generator=g),
+               "sample_idx": [i % 3 for i in range(n)], "pred_mask_valid_hw": (torch.full((n,), H - 4), torch.full((n,), Wd - 8)) if n else ()}
+        ref = pipeline.pack_results(dec, cap, mhw, "cpu")
+        dev = {k: (v.cuda() if isinstance(v, torch.Tensor) else v) for k, v in dec.items()}
+        if n:
+            dev["pred_mask_valid_hw"] = tuple(t.cuda() for t in dec["pred_mask_valid_hw"])
+        dirty = torch.full((ref.numel(),), 77, dtype=torch.int32, device="cuda")
+        got = pipeline.pack_results(dev, cap, mhw, "cuda", out=dirty)
+        assert torch.equal(got.cpu(), ref), (n, H, Wd)
+        if n:
+            nomask = dict(dev, pred_mask=None, pred_mask_valid_hw=())
+            ref2 = pipeline.pack_results(dict(dec, pred_mask=None, pred_mask_valid_hw=()), cap, mhw, "cpu")
+            assert torch.equal(pipeline.pack_results(nomask, cap, mhw, "cuda").cpu(), ref2)
+    with pytest.raises(ValueError, match="exceed the exchange capacity"):
+        pipeline.pack_results({"pred_boxes": torch.zeros(5, 4).cuda()}, 4, 16, "cuda")
+
+
+def test_bench_two_ranks_exchange_delivers_every_ranks_results(tmp_path):
+    """The REAL multi-rank path of bench.py under torch.distributed.run with 2 ranks (gloo, both on this GPU — RCCL refuses two ranks per
+    device; the driver's 8-GPU run uses nccl = RCCL): device-side pack, one asynchronous all-gather per decode group, and every rank ends up
+    with every rank's boxes / scores / mask logits bit for bit.  Small plumbing config; no RCCL run exists on the builder's side."""
+    import json
+    import socket
+    import subprocess
+    import sys
+    from padt_amd import pipeline
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ, PADT_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--model", "small", "--steps", "5", "--warmup", "1",
+                        "--merge", "2", "--dump-exchange", str(tmp_path)], capture_output=True, text=True, timeout=900, cwd=root, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and d["exchange"]["all_gathers"] >= 3 and d["exchange"]["batches_per_gather"] == 2
+    dumps = [torch.load(os.path.join(str(tmp_path), f"rank{k}.pt")) for k in range(2)]
+    for me in range(2):
+        recs = torch.cat(dumps[me]["gathered"], dim=1)              # (world, batches rounded up to whole gathers, words)
+        assert recs.shape[0] == 2 and recs.shape[1] >= 5
+        for src in range(2):
+            local = dumps[src]["local"]
+            assert len(local) == 5
+            for b in range(recs.shape[1]):
+                got = pipeline.unpack_results(recs[src, b][None], batch_per_rank=0)[0]
+                if b >= 5:
+                    assert got["boxes"].shape[0] == 0               # zero-padded records of the last, partially filled gather
+                    continue
+                ref = local[b]
+                assert torch.equal(got["boxes"], ref["pred_boxes"].float()) and torch.equal(got["scores"], ref["pred_score"].float().reshape(-1))
+                H, Wd = ref["pred_mask"].shape[1:]
+                assert torch.equal(got["masks"][:, :H, :Wd], ref["pred_mask"].float()) and got["sample_idx"].tolist() == list(ref["sample_idx"])
