@@ -524,7 +524,8 @@ def main():
         if dump is not None:
             dump.append({k: (v.detach().cpu() if isinstance(v, torch.Tensor) else v) for k, v in decoded.items() if k in ("pred_boxes", "pred_score", "pred_mask", "sample_idx")})
         if exchange is not None:
-            gathered.extend(exchange.add(decoded))
+            got = exchange.add(decoded)                                # views of the exchange's double buffer: consume (here: copy for the dump) now
+            gathered.extend([t.clone() for t in got] if dump is not None else got)
 
     def run_steps(k, runner=runner):
         """k steps = k batches through the whole path; with depth > 1 consecutive batches overlap on separate streams
@@ -545,7 +546,8 @@ def main():
                 last = r[0]
                 deliver(last)
         if exchange is not None:
-            gathered.extend(exchange.flush())                      # the run's last (possibly partial) group: waited for inside the timed region
+            got = exchange.flush()                                     # the run's last (possibly partial) group: waited for inside the timed region
+            gathered.extend([t.clone() for t in got] if dump is not None else got)
         return last
 
     if runner is not None:

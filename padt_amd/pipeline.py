@@ -251,6 +251,7 @@ class ResultExchange:
         ex = ResultExchange(cap, mask_hw, per_gather=8, device=dev)
         for decoded in ...: done += ex.add(decoded)        # → list of (world, per_gather, words) int32 tensors whose gather completed
         done += ex.flush()
+    The returned tensors are views of a double buffer: consume (unpack / copy) them before the second-next gather is issued.
     """
 
     def __init__(self, cap: int, mask_hw: int, per_gather: int, device, group=None):

@@ -476,6 +476,83 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     assert float(db.max()) < 2 * float(fdb.max()) + 2e-4 and min(ious) > 0.98 and mx < 2 * fmx and rms < 2 * frms
 
 
+@pytest.mark.parametrize("llm_weights", ["bf16", "fp8"])
+def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
+    """BASELINE configs[4] at ITS geometry: padt_pro_7b() — D = 3584, 28 q / 4 kv heads (GQA group 7), MLP 18944 (padded to 18944 = 296 x 64),
+    untied 152 064-row lm_head next to the embedding table, real 1280-wide ViT blocks and the real 98 M-parameter decoder — with the depth cut
+    to 2 LLM layers / 2 ViT blocks so that the fp32 oracle runs in seconds.  Two ragged images, a RIC-shaped completion (caption text with
+    4 interleaved runs of 5 VRTs, src/preprocess/process_ric.py:147,150 templates) through generate → parse → vl_decode:
+    ids by the margin rule, per-step hidden rows, object grouping of the parser, boxes.  bf16 weights, and the fp8 e4m3 weight path
+    (decode steps stream the fp8 image; the oracle runs the dequantised matrices, parity_util.effective_llm_weights)."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    import parity_util as U
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.synthetic import multi_object_schedule
+    O = U.O
+    base = padt_amd.padt_pro_7b()
+    cfg = dataclasses.replace(base, num_hidden_layers=2,
+                              vision_config=dataclasses.replace(base.vision_config, depth=2, fullatt_block_indexes=(1,)))
+    assert (cfg.hidden_size, cfg.num_attention_heads, cfg.num_key_value_heads, cfg.intermediate_size, cfg.vocab_size, cfg.tie_word_embeddings) == \
+        (3584, 28, 4, 18944, 152064, False)
+    w = U.bf16_weights(cfg, seed=31, std=0.02)
+    model = PaDTForConditionalGeneration(cfg, w, device="cuda", llm_weights=llm_weights)
+    assert ("llm.0.gu.wq" in model.W) == (llm_weights == "fp8") and model.W["llm.head"].data_ptr() != model.W["llm.embed"].data_ptr()
+    wo = U.effective_llm_weights(model, w) if llm_weights == "fp8" else w
+    oc = U.oracle_config(cfg)
+    grids = [[1, 16, 20], [1, 12, 12]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=9, n_post=20, ragged=True, seed=88)
+    T, n_obj, n_vrt = 40, 4, 5
+    sched = multi_object_schedule(T, n_obj=n_obj, n_vrt=n_vrt)
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    seq = out.sequences.cpu()
+    toks = seq[:, L:]
+    assert toks.shape == (2, T) and (toks[:, -1] == cfg.eos_token_id).all()
+    with torch.no_grad():
+        ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    n_tie = 0
+    for t in range(T):
+        lg = ores["logits"][t]
+        top2 = lg.topk(2, dim=-1).values
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        for b in range(2):
+            fin = torch.isfinite(lg[b])
+            floor = 2.5e-2 * lg[b][fin].abs().max().item()          # bf16-operand logit noise: 1.8-2.5 % of |logit|max (measured at full depth)
+            second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
+            if (top2[b, 0] - second).item() > floor:
+                assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
+            else:
+                n_tie += 1
+                assert (top2[b, 0] - chosen[b]).item() <= floor
+    assert n_tie <= T // 2
+    hid = out.hidden_states.last_layer_rows().cpu().float()
+    worst = 0.0
+    for t in range(T):
+        mx, rms = rel(hid[t], ores["hidden"][t][:, -1])
+        worst = max(worst, rms)
+        assert rms < 1.5e-2, f"hidden step {t}: rel rms {rms:.3e}"
+    # ---- parser: 4 interleaved VRT runs per sample → 4 objects of 5 VRT features each; decoder on both sides
+    n_m = [g[1] * g[2] // 4 for g in grids]
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, max(n_m)), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    local = proc.assign_to_local_vrt_id(seq.clone(), grid)[:, L:]
+    comps, feats, labels, vrts, _ = padt_amd.parseVRTintoCompletion(proc, local, out["hidden_states"], torch.Tensor([False] * 2))
+    assert [len(f) for f in feats] == [n_obj, n_obj] and all(o.shape == (n_vrt, cfg.hidden_size) for f in feats for o in f)
+    dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+    runs = [[t for t in range(T) if sched[t] == "v"][k * n_vrt: (k + 1) * n_vrt] for k in range(n_obj)]
+    with torch.no_grad():
+        st = ores["state"]
+        ofeats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in r], 0) for r in runs] for b in range(2)]
+        odec = O.vl_decode(wo, oc, ofeats, st.proto, st.high_res, grid, st.visual_pe)
+    assert dec["sample_idx"] == odec["sample_idx"] == [0] * n_obj + [1] * n_obj
+    db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
+    mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
+    print(f"\n[7B geometry, {llm_weights}] ties {n_tie}/{2 * T}; hidden rel rms worst {worst:.3e}; {2 * n_obj} objects: box |d|max {db:.3e}, mask rel max {mx:.3e} rms {rms:.3e}")
+    assert db < 2e-3 and mx < 3e-2
+
+
 def test_padt_decoder_ovd_shape_seven_objects_per_image():
     """BASELINE configs[3] (OVD COCO: ≈7 objects x 5 VRTs per image, eval/evaluation_scripts/inference_coco.py:101-110): vl_decode at the
     real decoder shape with 7 objects on each of two images (14 objects, 56 + 42 query rows → the tile-GEMM path on the query side,
