@@ -373,6 +373,9 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     // U/2 of its pairs in flight, consumed in K order.  The pair → wave map does NOT depend on the row count (MT) — only U does — so a
     // row's fp32 summation order, and with it every output bit, is the same whether 8, 16, 32 or 64 rows share the launch (in-flight
     // batching of decode groups must not change a sample's tokens; tools/check_rows_invariance.py).
+    // Round 3 measured three restructurings of this loop at 64 rows and kept none (profiles/r03_decode_experiments.md): a two-stage register
+    // ping-pong (gate/up 26.0 → 27.6 us: 204 VGPRs, 2 waves per SIMD), and two "shared activation" kernels whose waves split the weight rows
+    // instead of K so that a block reads the activations once (through L1: 24.5 us; through an LDS double buffer: 26.2 us; 12 waves: spills).
     // split-K: gridDim.y blocks share an n-block, block y takes pairs y*NW + wave, stepping by NW*gridDim.y
     constexpr int KG = 2, GPI = U / KG;
     static_assert(U % KG == 0, "U is a whole number of K-step pairs");
