@@ -12,6 +12,7 @@
 // (padt_processor.py:125), advance cache slots / rope positions / step counter — all on device, so a decode step is one
 // replayable hipGraph.
 #include "common.h"
+#include <stdlib.h>
 #include <cstdint>
 
 extern "C" void padt_set_error(const char* msg);
@@ -46,19 +47,31 @@ struct HeadArgs {
 
 // PACKED: text rows come from a fragment-packed copy of the table ([V/16][D/32][64 lanes][8], ops.pack_weight — every wave
 // load is 1 KiB contiguous) and the hidden rows from the 16-row fragment-packed activation layout; prototype rows (rebuilt
-// per batch) stay row-major.  Waves take groups of U consecutive K-steps; wave w finishes sample blocks w, w + 4 (< MT).
-template <int MT, bool PACKED>
+// per batch) stay row-major.  Waves take groups of U consecutive K-steps; wave w finishes (row block, sample block) pairs w, w + 4, ...
+// NT: 16-row table blocks per thread block — they share every hidden-row fragment a wave loads (at 64 rows a wave loads 4 KiB of hidden
+// fragments per K-step: with one table block per thread block that is 4 bytes of L2 traffic per byte of table, 2.5 GB per step; with NT = 4,
+// 1:1).  The K-step → wave map and the cross-wave order are those of NT = 1: a logit's bits depend neither on NT nor on the row count.
+template <int MT, int NT, bool PACKED>
 __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
-    __shared__ __attribute__((aligned(16))) float red[4][MT][64][4];
+    extern __shared__ __attribute__((aligned(16))) float red_raw[];
+    typedef float RedT[NT * MT][64][4];
+    RedT* red = reinterpret_cast<RedT*>(red_raw);                 // [4 waves]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
-    const int n0 = blockIdx.x * 16;
-    const int NT = p.V + p.NP;
-    int n = n0 + frow;
-    n = n < NT ? n : NT - 1;
-    const bool in_text = PACKED && (n0 + 16 <= p.V);              // whole block inside the packed text table
-    const bf16_t* wrow = (n < p.V) ? p.E + (long)n * p.D : p.proto + (long)(n - p.V) * p.D;
-    const bf16_t* wpk = PACKED ? p.Ep + (long)(n0 >> 4) * (p.D >> 5) * 512 + lane * 8 : nullptr;
+    const int NTOT = p.V + p.NP;
+    const int nblk = (NTOT + 15) / 16;
+    const bf16_t* wrow[NT];
+    const bf16_t* wpk[NT];
+    bool in_text[NT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n0 = (blockIdx.x * NT + i) * 16;
+        int n = n0 + frow;
+        n = n < NTOT ? n : NTOT - 1;
+        in_text[i] = PACKED && (n0 + 16 <= p.V);                  // whole block inside the packed text table
+        wrow[i] = (n < p.V) ? p.E + (long)n * p.D : p.proto + (long)(n - p.V) * p.D;
+        wpk[i] = PACKED ? p.Ep + (long)(min(n0, p.V - 16) >> 4) * (p.D >> 5) * 512 + lane * 8 : nullptr;
+    }
     const bf16_t* xrow[MT];
     bool xok[MT];
 #pragma unroll
@@ -68,67 +81,84 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
         xrow[j] = PACKED ? p.h + (long)j * 16 * p.ldh + lane * 8 : p.h + (long)(m < p.B ? m : 0) * p.ldh + fq * 8;
     }
     const int xstep = PACKED ? 512 : 32;
-    f32x4 acc[MT];
+    f32x4 acc[NT][MT];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int nks = (p.D + 31) / 32;
-    constexpr int U = 4;
+    constexpr int U = 4;                                          // K-steps per wave group (fixes the summation order)
+    constexpr int UH = (NT * MT > 8) ? 2 : 4;                     // K-steps loaded at a time (register budget); same MFMA order either way
     for (int g0 = wave; g0 * U < nks; g0 += 4) {
-        bf16x8 wf[U], xf[U][MT];
 #pragma unroll
-        for (int u = 0; u < U; ++u) {
-            const int ks = g0 * U + u;
-            const int k = ks * 32 + fq * 8;
-            const bool kok = (ks < nks) && (k < p.D);
-            if (PACKED && in_text) wf[u] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wpk + (long)ks * 512)) : zero_frag();
-            else wf[u] = kok ? ld_frag(wrow + k) : zero_frag();
+        for (int uh = 0; uh < U; uh += UH) {
+            bf16x8 wf[UH][NT], xf[UH][MT];
 #pragma unroll
-            for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
+            for (int u = 0; u < UH; ++u) {
+                const int ks = g0 * U + uh + u;
+                const int k = ks * 32 + fq * 8;
+                const bool kok = (ks < nks) && (k < p.D);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    if (PACKED && in_text[i]) wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wpk[i] + (long)ks * 512)) : zero_frag();
+                    else wf[u][i] = kok ? ld_frag(wrow[i] + k) : zero_frag();
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
+            }
+#pragma unroll
+            for (int u = 0; u < UH; ++u)
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[u][i], xf[u][j], acc[i][j]);
         }
-#pragma unroll
-        for (int u = 0; u < U; ++u)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[j] = mfma16(wf[u], xf[u][j], acc[j]);
     }
 #pragma unroll
-    for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave][j][lane][0]) = acc[j];
-    __syncthreads();
-    for (int j = wave; j < MT; j += 4) {                      // sample blocks this wave finishes (two of them at MT = 8)
-    f32x4 sum = *reinterpret_cast<f32x4*>(&red[0][j][lane][0]);
+    for (int i = 0; i < NT; ++i)
 #pragma unroll
-    for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<f32x4*>(&red[w][j][lane][0]);
+        for (int j = 0; j < MT; ++j) *reinterpret_cast<f32x4*>(&red[wave][i * MT + j][lane][0]) = acc[i][j];
+    __syncthreads();
     const int mode = (p.mode_table && p.step) ? p.mode_table[*p.step] : 0;
     const float pen = (p.gen && p.seen) ? p.gen->penalty : 1.0f;
-    const int m = j * 16 + frow;                              // sample
-    float best = -INFINITY;
-    int bidx = 0x7fffffff;
-    int lo = 0, hi = 0;
-    if (m < p.B) { lo = p.vrt_off[m]; hi = p.vrt_off[m + 1]; }
+    for (int q = wave; q < NT * MT; q += 4) {                     // (table block, sample block) pairs this wave finishes
+        const int i = q / MT, j = q % MT;
+        const int blk = blockIdx.x * NT + i;
+        if (blk >= nblk) continue;
+        const int n0 = blk * 16;
+        f32x4 sum = *reinterpret_cast<f32x4*>(&red[0][q][lane][0]);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = n0 + fq * 4 + r;
-        bool ok = (m < p.B) && (row < NT);
-        if (ok) {
-            if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
-            else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
+        for (int w = 1; w < 4; ++w) sum += *reinterpret_cast<f32x4*>(&red[w][q][lane][0]);
+        const int m = j * 16 + frow;                              // sample
+        float best = -INFINITY;
+        int bidx = 0x7fffffff;
+        int lo = 0, hi = 0;
+        if (m < p.B) { lo = p.vrt_off[m]; hi = p.vrt_off[m + 1]; }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int row = n0 + fq * 4 + r;
+            bool ok = (m < p.B) && (row < NTOT);
+            if (ok) {
+                if (row < p.V) ok = (mode == 0 || mode == 1 || (mode == 3 && row == p.eos));
+                else { const int jv = row - p.V; ok = (jv >= lo && jv < hi) && (mode == 0 || mode == 2); }
+            }
+            float sc = sum[r];
+            if (pen != 1.0f && ok && ((p.seen[(long)m * p.seen_words + (row >> 5)] >> (row & 31)) & 1u)) sc = sc < 0.f ? sc * pen : sc / pen;
+            const float v = ok ? sc : -INFINITY;
+            if (p.logits && m < p.B && row < NTOT) p.logits[(long)m * p.ldl + row] = v;
+            if (v > best) { best = v; bidx = row; }               // rows ascend with r → first max wins
         }
-        float sc = sum[r];
-        if (pen != 1.0f && ok && ((p.seen[(long)m * p.seen_words + (row >> 5)] >> (row & 31)) & 1u)) sc = sc < 0.f ? sc * pen : sc / pen;
-        const float v = ok ? sc : -INFINITY;
-        if (p.logits && m < p.B && row < NT) p.logits[(long)m * p.ldl + row] = v;
-        if (v > best) { best = v; bidx = row; }               // rows ascend with r → first max wins
-    }
-    // combine the 4 lanes (fq = 0..3) that hold the same sample
+        // combine the 4 lanes (fq = 0..3) that hold the same sample
 #pragma unroll
-    for (int off = 16; off <= 32; off <<= 1) {
-        const float ov = __shfl_xor(best, off, 64);
-        const int oi = __shfl_xor(bidx, off, 64);
-        if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
-    }
-    if (fq == 0 && m < p.B) {
-        p.part_val[(long)blockIdx.x * p.B + m] = best;
-        p.part_idx[(long)blockIdx.x * p.B + m] = bidx;
-    }
+        for (int off = 16; off <= 32; off <<= 1) {
+            const float ov = __shfl_xor(best, off, 64);
+            const int oi = __shfl_xor(bidx, off, 64);
+            if (ov > best || (ov == best && oi < bidx)) { best = ov; bidx = oi; }
+        }
+        if (fq == 0 && m < p.B) {
+            p.part_val[(long)blk * p.B + m] = best;
+            p.part_idx[(long)blk * p.B + m] = bidx;
+        }
     }
 }
 
@@ -199,6 +229,17 @@ __global__ void step_inc_kernel(int* step) { *step += 1; }
 
 extern "C" long padt_vrt_head_nblk(long vocab, long n_proto) { return (vocab + n_proto + 15) / 16; }
 
+template <int MT, int NT, bool PACKED>
+static void launch_head(const HeadArgs& a, int nblk, hipStream_t s) {
+    constexpr int lds = 4 * NT * MT * 64 * 16;
+    if constexpr (lds > 64 * 1024) {
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&vrt_head_kernel<MT, NT, PACKED>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+    }
+    hipLaunchKernelGGL((vrt_head_kernel<MT, NT, PACKED>), dim3((nblk + NT - 1) / NT), dim3(256), lds, s, a);
+}
+
 extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
                              const void* proto, long n_proto, const int* vrt_off, const int* mode_table,
                              const int* step, void* logits_f32, long ld_logits, void* part_val, void* part_idx,
@@ -216,15 +257,19 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
     if (seen && seen_words * 32 < vocab + n_proto) { padt_set_error("padt_vrt_head: seen bitmap narrower than the table"); return -1; }
     const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
     hipStream_t s = (hipStream_t)stream;
+    static const int nt_knob = getenv("PADT_HEAD_NT") ? atoi(getenv("PADT_HEAD_NT")) : 0;      // A/B knob: 1 = one table block per thread block
     if (embed_table_packed) {
-        if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, true>), dim3(nblk), dim3(256), 0, s, a);
-        else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, true>), dim3(nblk), dim3(256), 0, s, a);
-        else if (batch <= 64) hipLaunchKernelGGL((vrt_head_kernel<4, true>), dim3(nblk), dim3(256), 0, s, a);
-        else hipLaunchKernelGGL((vrt_head_kernel<8, true>), dim3(nblk), dim3(256), 0, s, a);
-    } else if (batch <= 16) hipLaunchKernelGGL((vrt_head_kernel<1, false>), dim3(nblk), dim3(256), 0, s, a);
-    else if (batch <= 32) hipLaunchKernelGGL((vrt_head_kernel<2, false>), dim3(nblk), dim3(256), 0, s, a);
-    else if (batch <= 64) hipLaunchKernelGGL((vrt_head_kernel<4, false>), dim3(nblk), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((vrt_head_kernel<8, false>), dim3(nblk), dim3(256), 0, s, a);
+        if (nt_knob == 1) {
+            if (batch <= 16) launch_head<1, 1, true>(a, nblk, s); else if (batch <= 32) launch_head<2, 1, true>(a, nblk, s);
+            else if (batch <= 64) launch_head<4, 1, true>(a, nblk, s); else launch_head<8, 1, true>(a, nblk, s);
+        } else if (batch <= 16) launch_head<1, 4, true>(a, nblk, s);
+        else if (batch <= 32) launch_head<2, 4, true>(a, nblk, s);
+        else if (batch <= 64) launch_head<4, 4, true>(a, nblk, s);
+        else launch_head<8, 2, true>(a, nblk, s);
+    } else if (batch <= 16) launch_head<1, 1, false>(a, nblk, s);
+    else if (batch <= 32) launch_head<2, 1, false>(a, nblk, s);
+    else if (batch <= 64) launch_head<4, 1, false>(a, nblk, s);
+    else launch_head<8, 1, false>(a, nblk, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

