@@ -455,7 +455,8 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     for t in range(T):
         f_t = 0.0
         for b in range(NF):
-            lg, lf = ores["logits"][t][b], fres["logits"][t][b]
+            lf = fres["logits"][t][b]
+            lg = ores["logits"][t][b][: lf.numel()]                # the floor run's table holds the first NF images' prototypes only
             fin = torch.isfinite(lg)
             f_t = max(f_t, (lf[fin] - lg[fin]).abs().max().item() / (lg[fin].abs().max().item() + 1e-30))
         frac.append(f_t)
