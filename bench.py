@@ -8,8 +8,9 @@ A "step" = one batch of `--batch` (default 8) synthetic 640x640-equivalent image
   ViT → prototypes → packed prefill → 27 hipGraph decode steps over text‖VRT (scripted 28-token REC completion: one run
   of 5 VRTs, forced EOS) → parseVRTintoCompletion → PaDT decoder (boxes + 184x184 mask logits) [→ RCCL all-gather].
 Weights: random-init PaDT_Pro_3B architecture (3.85 B parameters, bf16).  Rank 0 prints ONE JSON line.
-Extra objects on that line (N=1): "roofline" (bf16 MFMA tile-GEMM family, HIP-event brackets around every tile-GEMM launch INSIDE the
-running pipeline; frac_replay = the same launches replayed alone), "roofline_decode" (HBM bytes of a decode step / its in-situ and stand-alone
+Extra objects on that line (N=1): "roofline" (bf16 MFMA tile-GEMM family: in-kernel start / end stamps of every tile-GEMM call INSIDE the
+running pipeline — HIP-event pairs around 290 launches per step cost 10 % throughput and count the dispatch gaps; frac_replay = the same
+launches replayed alone between one event pair), "roofline_decode" (HBM bytes of a decode step / its in-situ and stand-alone
 duration), "from_images" (the same pipeline fed from uint8 host images), "cpu_baseline" (the fp32 CPU oracle timed on this host, with the
 parity read-out), "extra_workloads" (BASELINE configs[3] OVD and configs[4] 7B RIC fp8 per-GPU shapes, short runs).
 """
@@ -159,20 +160,21 @@ def _alg_dims(model, cfg):
 
 def insitu_leg(model, inp, args, cfg, run_steps, steps):
     """The two rooflines measured IN the running pipeline: `steps` more steps of exactly the timed loop (same runner, same streams, same
-    batches in flight) with a HIP-event pair around every tile-GEMM launch (rows > 64) on the stream it is launched on, and around every
-    chunk of decode-step graph replays.  → (roofline dict for the tile-GEMM family, roofline_decode dict)."""
+    batches in flight) with in-kernel start / end stamps of every tile-GEMM call (ops.GemmProfile: nothing is added to the queues) and a
+    HIP-event pair around every chunk of decode-step graph replays on the decode stream.  → (roofline dict for the tile-GEMM family,
+    roofline_decode dict)."""
     from padt_amd import ops
     alg = _alg_dims(model, cfg)
-    gt, st = ops.EventTimer(), ops.EventTimer()
-    torch.cuda.synchronize()
-    ops.GEMM_TIMER, ops.STEP_TIMER = gt, st
+    gp, st = ops.GemmProfile(400 * (steps + 2), inp["pix"].device), ops.EventTimer()
+    gp.start()
+    ops.STEP_TIMER = st
     t0 = time.perf_counter()
     run_steps(steps)
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
-    ops.GEMM_TIMER, ops.STEP_TIMER = None, None
-    g, d = gt.results(), st.results()
-    gt.close()
+    ops.STEP_TIMER = None
+    gp.stop()
+    g, d = gp.results(), st.results()
     st.close()
     flops = sum(2.0 * M * alg(N) * alg(K) for _, (kind, M, N, K) in g)
     ms = sum(m for m, _ in g)
@@ -185,8 +187,9 @@ def insitu_leg(model, inp, args, cfg, run_steps, steps):
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
     roof = {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
-            "how": "HIP-event pair around every tile-GEMM launch (rows > 64) of %d pipelined steps run right after the timed region with the same runner "
-                   "(algorithmic 2MNK of the un-padded shapes / sum of the bracketed durations; a bracket includes the dispatch gap in front of the kernel)" % steps,
+            "how": "in-kernel wall-clock stamps (first block start → last block end, 100 MHz s_memrealtime) of every tile-GEMM call (rows > 64) of %d pipelined "
+                   "steps run right after the timed region with the same runner: algorithmic 2MNK of the un-padded shapes / sum of those durations; the decode "
+                   "group of the other stream runs concurrently and takes CUs from the GEMMs (under rocprofv3 the streams are serialised)" % steps,
             "launches_per_step": round(len(g) / max(steps, 1), 1), "avg_launch_us": round(ms * 1e3 / max(len(g), 1), 2),
             "alg_tflop_per_step": round(flops / max(steps, 1) / 1e12, 3), "ms_per_step_in_gemm": round(ms / max(steps, 1), 3),
             "images_per_s_while_instrumented": round(args.batch * steps / wall, 2),

@@ -57,6 +57,11 @@ int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long
  * group_m rasterisation patch height.  -1 keeps a field.  The defaults are read once from PADT_GEMM256 / PADT_GEMM_MF / PADT_GEMM_PEEL /
  * PADT_GEMM_COLSPLIT / PADT_GEMM_GROUP_M when the library loads.  Process-wide, not thread-safe (a test / tuning surface). */
 int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m);
+/* Measurement surface (bench.py's in-situ roofline): while a slot array (capacity pairs of uint64, initialised to {~0, 0} by the caller) is
+ * registered, every tile-GEMM call (M > 64) takes the next slot and its kernels record {first block start, last block end} in 100 MHz
+ * wall-clock ticks — no event packets, no serialisation of the stream.  slots = NULL stops.  Returns the number of calls recorded since the
+ * previous registration.  Process-wide, not thread-safe. */
+long padt_gemm_profile(void* slots_u64, long capacity);
 /* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above). */
 int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 

@@ -27,6 +27,19 @@ struct PerDeviceOnce {
     }
 };
 
+// In-kernel launch timing (bench.py's in-situ roofline): thread 0 of every block folds its start / end wall-clock tick (100 MHz constant
+// clock, s_memrealtime) into {min start, max end} of the launch's slot.  No barrier, no extra packet in the queue: unlike an event pair
+// around the launch it neither serialises the stream nor counts the dispatch gap.  prof == nullptr: two predicated-off instructions.
+struct ProfScope {
+    unsigned long long* slot;
+    __device__ __forceinline__ ProfScope(unsigned long long* s, int tid) : slot(tid == 0 ? s : nullptr) {
+        if (slot) atomicMin(slot, (unsigned long long)wall_clock64());
+    }
+    __device__ __forceinline__ ~ProfScope() {
+        if (slot) atomicMax(slot + 1, (unsigned long long)wall_clock64());
+    }
+};
+
 PADT_DEV float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
 
 // round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32); NaN stays NaN, +-inf stays +-inf

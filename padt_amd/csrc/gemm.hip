@@ -38,6 +38,7 @@ struct GemmArgs {
     const float* cs = nullptr;   // optional per-output-column scale applied to the accumulator before bias (fp8 weights: dequantisation scale of weight row n)
     int r_f32 = 0;               // EPI_RESID: R is fp32 [M][ldr] (fp32 residual stream; with OUT_F32)
     long lo_off = 0;             // bf16 output: also store lo = bf16(x - hi) at C + lo_off (split-precision pair, padt_gemm_bf16_ex)
+    unsigned long long* prof = nullptr;   // tile kernels: optional in-kernel launch timing slot (padt_gemm_profile)
     bf16_t* C2 = nullptr;        // fp32 output: optional bf16 mirror of C (fp32 residual stream → the next projection's A operand), row-major
     long ldc2 = 0;               //   or, with c_pack, in the fragment-packed activation layout (decode steps)
 };
@@ -203,6 +204,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
     using T = TileCfg<BK>;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    ProfScope prof_scope(p.prof, tid);
     const int ntn = (p.N + BN - 1) / BN, ntm = (p.M + BM - 1) / BM;
     const int id = xcd_remap(blockIdx.x, ntm * ntn);
     const int tm = id / ntn, tn = id % ntn;
@@ -523,7 +525,24 @@ extern "C" void padt_set_error(const char* msg);
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
-                                void* C2, long ldc2);
+                                void* C2, long ldc2, unsigned long long* prof);
+
+// Measurement surface: while a slot array is registered, every tile-GEMM call (M > 64) of this process takes the next {start, end} slot
+// (host-side counter) and its kernels record their first block start / last block end in 100 MHz ticks.  The caller initialises the slots
+// to {~0, 0}.  Process-wide, not thread-safe: bench.py's in-situ roofline leg only.
+static unsigned long long* g_prof_slots = nullptr;
+static long g_prof_cap = 0, g_prof_n = 0;
+extern "C" long padt_gemm_profile(void* slots_u64, long capacity) {
+    const long used = g_prof_n;
+    g_prof_slots = (unsigned long long*)slots_u64;
+    g_prof_cap = slots_u64 ? capacity : 0;
+    g_prof_n = 0;
+    return used;                                                  // calls recorded since the previous registration
+}
+static unsigned long long* next_prof_slot() {
+    if (!g_prof_slots || g_prof_n >= g_prof_cap) return nullptr;
+    return g_prof_slots + 2 * (g_prof_n++);
+}
 
 template <int EPI, bool F32, int BK>
 static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
@@ -616,7 +635,8 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         padt_set_error("padt_gemm_resid32: the bf16 mirror needs fp32 output, ldxb % 8 == 0, ldxb >= N and a 16-byte aligned pointer");
         return -1;
     }
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2) == 0) {
+    unsigned long long* prof = (M > 64) ? next_prof_slot() : nullptr;
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -639,6 +659,7 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
     a.lo_off = lo_off;
     a.C2 = (bf16_t*)C2;
     a.ldc2 = ldc2;
+    a.prof = (M > 64) ? prof : nullptr;                           // a peeled <= 64-row tail runs on the skinny kernel: not part of the tile-GEMM time
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: dispatch_m<EPI_NONE, false>(a, s); break;

@@ -34,6 +34,7 @@ struct Gemm256Args {
     int r_f32;                      // EPI_RESID: R is fp32 [M][ldr] (with OUT_F32)
     long lo_off;                    // bf16 output: also store lo = bf16(x - hi) at C + lo_off (padt_gemm_bf16_ex)
     bf16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
+    unsigned long long* prof;       // optional {first block start, last block end} in 100 MHz wall-clock ticks (padt_gemm_profile)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
@@ -88,6 +89,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
+    ProfScope prof_scope(p.prof, tid);
     const int ntn = (p.N + TN - 1) / TN, ntm = (p.M + TMV - 1) / TMV;
     // Each XCD owns a contiguous run of tile ids (xcd_remap) and its 32 CUs work on ~32 consecutive ids at a time; walking
     // the ids in group_m x (32 / group_m) patches makes those tiles share group_m A panels and 32/group_m W panels in the
@@ -543,7 +545,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
-                                void* C2, long ldc2) {
+                                void* C2, long ldc2, unsigned long long* prof) {
     const int mode = g_knobs.mode;                                // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -555,7 +557,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     const int group_m = g_knobs.group_m;
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;

@@ -70,13 +70,46 @@ class EventTimer:
         self._all, self._free, self.recs = [], [], []
 
 
-GEMM_TIMER = None   # an EventTimer: every tile-GEMM launch (rows > 64) is bracketed, meta = (kind, M, N, K)
+class GemmProfile:
+    """In-kernel timing of every tile-GEMM call (rows > 64) between start() and stop() (padt_gemm_profile): the kernels fold their first
+    block start / last block end (100 MHz wall-clock ticks) into one slot per call — no event packets in the queue, nothing serialised,
+    the dispatch gap in front of a kernel is not counted.  results() → [(ms, (kind, M, N, K))] in call order."""
+
+    def __init__(self, capacity, device):
+        self.cap = int(capacity)
+        self.slots = torch.empty((self.cap, 2), dtype=torch.int64, device=device)
+        self.meta = []
+
+    def start(self):
+        global GEMM_PROF
+        self.slots[:, 0] = -1                                        # 0xFFFF...: the atomicMin identity
+        self.slots[:, 1] = 0
+        self.meta = []
+        torch.cuda.synchronize()
+        _lib.load().padt_gemm_profile(self.slots.data_ptr(), self.cap)
+        GEMM_PROF = self
+
+    def stop(self):
+        global GEMM_PROF
+        GEMM_PROF = None
+        n = _lib.load().padt_gemm_profile(None, 0)
+        torch.cuda.synchronize()
+        assert n == len(self.meta) or n == self.cap, (n, len(self.meta))
+        return n
+
+    def results(self):
+        t = self.slots[: min(len(self.meta), self.cap)].cpu()
+        ticks = (t[:, 1] - t[:, 0]).tolist()
+        return [(d * 1e-5, m) for d, m in zip(ticks, self.meta)]     # 100 MHz ticks → ms
+
+
+GEMM_PROF = None    # a started GemmProfile: the wrappers below append (kind, M, N, K) for every call the library gives a slot
 STEP_TIMER = None   # an EventTimer: every chunk of decode-step graph replays is bracketed (llm.DecodeSession.run_steps), meta = (steps, rows)
 
 
-def _tg_begin(M):
-    t = GEMM_TIMER
-    return t.begin() if (t is not None and M > 64) else None
+def _tg_note(kind, M, N, K):
+    if GEMM_PROF is not None and M > 64:
+        GEMM_PROF.meta.append((kind, M, N, K))
 
 
 def row_rstd(x, eps=1e-6, out=None):
@@ -104,12 +137,10 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
         assert row_scale.dtype == torch.float32 and row_scale.numel() >= M and row_scale.is_contiguous()
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K, row_scale))
-    ev = _tg_begin(M)
+    _tg_note("gemm", M, N, K)
     _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
                                   _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
                                   1 if out_f32 else 0, _p(row_scale)), "padt_gemm_bf16")
-    if ev is not None:
-        GEMM_TIMER.end(ev, ("gemm", M, N, K))
     return out
 
 
@@ -122,11 +153,9 @@ def gemm_resid32(a, w, bias, x32, xb=None):
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and x32.shape[0] >= M and x32.shape[1] >= N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("r32", a, w, bias, x32, xb))
-    ev = _tg_begin(M)
+    _tg_note("r32", M, N, K)
     _lib.check(lib.padt_gemm_resid32(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
                                      xb.stride(0) if xb is not None else 0, M, N, K), "padt_gemm_resid32")
-    if ev is not None:
-        GEMM_TIMER.end(ev, ("r32", M, N, K))
     return x32
 
 
@@ -145,12 +174,10 @@ def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
     assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(0) == sin.stride(0)
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, EPI_NONE, None, False, None, row_scale))
-    ev = _tg_begin(M)
+    _tg_note("gemm", M, N, K)
     _lib.check(lib.padt_gemm_rope_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                        _p(row_scale), _p(cos), _p(sin), cos.stride(0), int(rope_cols), int(head_dim)),
                "padt_gemm_rope_bf16")
-    if ev is not None:
-        GEMM_TIMER.end(ev, ("gemm", M, N, K))
     return out
 
 
@@ -561,12 +588,10 @@ def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, 
         lo_off = N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("hp", a_split, w2, bias, out, epilogue, residual, out_mode, M))
-    ev = _tg_begin(M)
+    _tg_note("hp", M, N, K2 // 2)                                    # algorithmic K: the MFMA pipe executes 2K (hi and lo operands)
     _lib.check(lib.padt_gemm_bf16_ex(_stream(), _p(a_split), a_split.stride(0), _p(w2), w2.stride(0), _p(bias), _p(out), out.stride(0),
                                      _p(residual), residual.stride(0) if residual is not None else 0, M, N, K2, epilogue,
                                      1 if out_mode == OUT_F32 else 0, 0, 1 if residual is not None else 0, lo_off), "padt_gemm_bf16_ex")
-    if ev is not None:
-        GEMM_TIMER.end(ev, ("hp", M, N, K2 // 2))                     # algorithmic K: the MFMA pipe executes 2K (hi and lo operands)
     return out
 
 
