@@ -67,39 +67,6 @@ def effective_llm_weights(model, w):
 
 
 # ------------------------------------------------------------------------------------------------ bf16-operand floor
-def _private_oracle_copy():
-    """A second, independent instance of the oracle module (same source file): patching it leaves `O` untouched, so a floor run and
-    a plain fp32 run can execute CONCURRENTLY on two host threads (torch CPU ops release the GIL; each thread gets its own OpenMP team)."""
-    import importlib.util
-    spec = importlib.util.spec_from_file_location("padt_oracle_floor_copy", O.__file__)
-    m = importlib.util.module_from_spec(spec)
-    sys.modules[spec.name] = m                     # dataclasses resolve their module through sys.modules
-    spec.loader.exec_module(m)
-    return m
-
-
-def run_concurrently(*thunks):
-    """Run the thunks on one host thread each, return their results in order (exceptions re-raised)."""
-    import threading
-    res, err = [None] * len(thunks), [None] * len(thunks)
-
-    def go(i):
-        try:
-            with torch.no_grad():
-                res[i] = thunks[i]()
-        except BaseException as e:                 # noqa: BLE001
-            err[i] = e
-    ts = [threading.Thread(target=go, args=(i,)) for i in range(len(thunks))]
-    for t in ts:
-        t.start()
-    for t in ts:
-        t.join()
-    for e in err:
-        if e is not None:
-            raise e
-    return res
-
-
 class bf16_operand_floor:
     """Context manager: inside it the ORACLE's ViT / LLM arithmetic rounds every matrix-multiply operand on the activation side to
     bf16 — the normalised rows entering qkv / gate-up, q / k / v (and with them the KV cache), the un-normalised probabilities P, the
@@ -109,20 +76,8 @@ class bf16_operand_floor:
     parity test measures it on its own inputs and bounds the HIP path by a multiple of it (tests/studies/e2e_precision_floor.py prints
     the numbers).  The PaDT decoder is left alone (the HIP decoder runs split-precision operands)."""
 
-    def __init__(self, module=None):
-        self.M = O if module is None else module
-
-    @classmethod
-    def private(cls):
-        """→ an oracle module instance with the floor hooks installed for good (use its generate / vl_decode directly; thread-safe
-        next to the un-patched `O`)."""
-        m = _private_oracle_copy()
-        cls(m).__enter__()
-        return m
-
     def __enter__(self):
         import torch.nn.functional as F
-        O = self.M                                 # noqa: N806  (the hooks below close over the module they patch)
         bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
         self._saved = {k: getattr(O, k) for k in ("vit_block", "llm_layer", "linear", "vrt_logits")}
 
@@ -180,5 +135,5 @@ class bf16_operand_floor:
 
     def __exit__(self, *exc):
         for k, v in self._saved.items():
-            setattr(self.M, k, v)
+            setattr(O, k, v)
         return False

@@ -308,10 +308,10 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     V = cfg.vocab_size
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     t0 = time.perf_counter()
-    F = U.bf16_operand_floor.private()                              # a second oracle instance with the floor hooks: both runs go concurrently
-    ores, fres = U.run_concurrently(
-        lambda: O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks),
-        lambda: F.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks))
+    with torch.no_grad():
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        with U.bf16_operand_floor():
+            fres = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
     t_or = time.perf_counter() - t0
     assert torch.equal(ores["sequences"], seq)
     st, fst = ores["state"], fres["state"]
@@ -389,9 +389,9 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     — 64-row decode steps, 8 x 529 prototypes per batch in one table, 16 REC tokens per image (VRT run of 5) — against
       (a) the un-merged path (rec_batch, one batch at a time): tokens, boxes, scores, mask logits BIT-identical for every batch;
       (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch (≈2 min of host CPU), and the oracle's
-          bf16-operand floor run (parity_util.bf16_operand_floor, a second oracle instance on a second host thread) on the first 4 of those images:
+          bf16-operand floor run (parity_util.bf16_operand_floor) on the first 3 of those images (samples are independent; ≈1 min):
           every token by the margin rule with 2x the logit noise the floor run shows at that step (relative to the largest |logit|,
-          worst of the floor samples); the batch's largest box error within 3x the largest of the floor samples (+2e-4), every
+          worst of the 3 floor samples); the batch's largest box error within 3x the largest of the 3 floor samples (+2e-4), every
           IoU > 0.98, mask logits within 3x the floor's.  (The north star's flat 1e-3 on box coordinates is below what bf16 MFMA
           operands alone allow on several of these 8 images — the floor run's own errors are printed.)"""
     if not torch.cuda.is_available():
@@ -439,13 +439,12 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     decm = res[0][0]
     torch.set_num_threads(min(64, os.cpu_count() or 8))
     t0 = time.perf_counter()
-    NF = 4                                                          # floor run on the first NF images (samples are independent)
-    P1 = 46 * 46
-    F = U.bf16_operand_floor.private()                              # second oracle instance with the floor hooks: runs next to the fp32 run
-    ores, fres = U.run_concurrently(
-        lambda: O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks),
-        lambda: F.generate(w, oc, ids[:NF], am[:NF], pix[: NF * P1], grid[:NF], T, schedule=sched, collect_logits=True, force_tokens=toks[:NF]))
     with torch.no_grad():
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        NF = 3                                                      # floor run on the first NF images (samples are independent)
+        P1 = 46 * 46
+        with U.bf16_operand_floor():
+            fres = O.generate(w, oc, ids[:NF], am[:NF], pix[: NF * P1], grid[:NF], T, schedule=sched, collect_logits=True, force_tokens=toks[:NF])
         vf = lambda r, nb: [[torch.cat([r["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(nb)]
         ost, fst = ores["state"], fres["state"]
         odec = O.vl_decode(w, oc, vf(ores, B), ost.proto, ost.high_res, grid, ost.visual_pe)
