@@ -651,21 +651,32 @@ def main():
             line["single_batch_latency"] = lat
         if alt is not None:
             line["unmerged_decode"] = alt
+        def leg(key, fn):
+            """Side legs never take the headline down: a failure is recorded under the key instead of raised."""
+            try:
+                line[key] = fn()
+            except Exception as e:                                     # noqa: BLE001
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
+
         if world == 1 and not args.no_roofline and runner is not None:
-            roof, dec = insitu_leg(model, inp, args, cfg, run_steps, min(args.steps, 16))
-            roof.update(replay_leg(model, inp, args, cfg))
-            line["roofline"] = roof
-            line["roofline_decode"] = decode_alone_leg(model, inp, args, cfg, dec)
+            def roofs():
+                roof, dec = insitu_leg(model, inp, args, cfg, run_steps, min(args.steps, 16))
+                roof.update(replay_leg(model, inp, args, cfg))
+                line["roofline_decode"] = decode_alone_leg(model, inp, args, cfg, dec)
+                return roof
+            leg("roofline", roofs)
         if world == 1 and args.from_images and runner is not None:
-            line["from_images"] = from_images_leg(model, inp, args, grid_hw, min(args.steps, 24))
+            leg("from_images", lambda: from_images_leg(model, inp, args, grid_hw, min(args.steps, 24)))
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline_leg(cfg, args, inp, model)
-        if "cpu_baseline" in line:
+            leg("cpu_baseline", lambda: cpu_baseline_leg(cfg, args, inp, model))
+        if isinstance(line.get("cpu_baseline"), dict) and "parity" in line["cpu_baseline"]:
             line["parity_vs_oracle"] = line["cpu_baseline"]["parity"]      # top level too: the metric's "box IoU vs ref" read-out of this run
         if world == 1 and args.extras:
             del runner
             m3, model = model, None
-            line["extra_workloads"] = extra_workloads(args, device, m3, cfg, grid_hw)
+            leg("extra_workloads", lambda: extra_workloads(args, device, m3, cfg, grid_hw))
             del m3
         print(json.dumps(line), flush=True)
     if world > 1:

@@ -7,7 +7,9 @@
  *
  * Conventions
  *   - `stream` is a hipStream_t passed as void*; every call is asynchronous on it, allocates nothing and keeps no hidden
- *     state (work buffers are caller-provided; sizes from the *_workspace/_nblk query functions).
+ *     state (work buffers are caller-provided; sizes from the *_workspace/_nblk query functions).  The only process-wide
+ *     state lives behind two test / measurement surfaces that no product call path touches: padt_gemm_knobs (forced tile
+ *     dispatch variants) and padt_gemm_profile (in-kernel launch timing).
  *   - All pointers are device pointers.  bf16 = raw 16-bit brain floats.  Strides (`ld*`) are in ELEMENTS.
  *   - Return 0 on success, -1 for rejected arguments, -2 for a HIP launch error; text via padt_last_error().
  *   - Row-major everywhere; weights in nn.Linear layout [out_features][in_features].
