@@ -100,6 +100,19 @@ int padt_pack_rows(void* stream, const void* src, long ld_src, void* dst, long l
 int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias, void* C,
                          long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps, int split_k,
                          void* workspace, int act_packed);
+/* fp8 x fp8 MFMA GEMM at prompt length (BASELINE configs[4]: the 7B "fp8 MFMA weight path"; v_mfma_f32_16x16x128_f8f6f4, twice the bf16 MFMA
+ * rate): A8 = OCP e4m3 activations [M][K] with one fp32 scale per row (padt_quant_rows_fp8), W8 = e4m3 weights [N][K] in nn.Linear layout with
+ * one fp32 scale per weight row.  acc = A8 · W8^T in fp32 (the fp8 products are exact), then by `epilogue`:
+ *   0: C (bf16)  = row_scale[m] * col_scale[n] * acc + bias          2: X32 (fp32, in place) += row_scale * col_scale * acc; Xb = bf16(X32)
+ *   3: SwiGLU over gate16 | up16 interleaved weight rows → C (bf16, N / 2 columns)
+ * K % 128 == 0, N % 256 == 0, lda / ldw % 16 == 0, 16-byte aligned operands.  Same phase-pipelined 256-row tile kernel as padt_gemm_bf16
+ * (the LDS image of a 128-byte K-tile row is identical).  HF:630-633,545-553 (q/k/v/o, gate/up/down Linear) with W ≈ col_scale * W8 and
+ * x ≈ row_scale * A8. */
+int padt_gemm_fp8(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+                  const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue);
+/* x8[row] = e4m3(x[row] / s) with s = the smallest power of two >= amax(row) / 448; row_scale[row] = s, or s * rsqrt(mean(x^2) + eps) when
+ * norm_eps >= 0 (the row feeds a projection whose RMSNorm weight is folded into W: HF:727,744).  bf16 in, bytes out. */
+int padt_quant_rows_fp8(void* stream, const void* x, long ldx, void* x8, long ld8, void* row_scale_f32, long rows, long K, float norm_eps);
 /* Decode-step residual projection over the fp32 residual stream (o_proj / down_proj, HF:741,757 at one token per row):
  * X32[M,N] (fp32 row-major, in place) += scale?[n] * (A · W^T); Xb = bf16(X32) in the fragment-packed activation layout (required;
  * ldxb % 8 == 0) = the A operand of the next projection.  Wp bf16 fragment-packed, or with scales != null the fp8 image.  a_packed: A is

@@ -764,3 +764,54 @@ extern "C" int padt_pack_results(void* stream, void* out_i32, long words, int n,
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Per-row fp8 quantisation of activations for the fp8 x fp8 MFMA GEMM (padt_gemm_fp8): x8[row] = e4m3(x[row] / s), s = 2^ceil(log2(amax / 448))
+// (a power of two: the division is exact, the only rounding is the e4m3 one), rs[row] = s, or s * rsqrt(mean(x^2) + eps) when the row also
+// feeds a folded RMSNorm (norm_eps >= 0) — the GEMM scales its accumulator with rs[m] * weight_scale[n].  One wave per row, two passes (the
+// second one re-reads the row from L2).
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, unsigned char* __restrict__ y, long ldy,
+                                                             float* __restrict__ rs, int rows, int K, float norm_eps) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const bf16_t* xr = x + (long)row * ldx;
+    float amax = 0.f, ss = 0.f;
+    for (int c = lane * 8; c < K; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) { amax = fmaxf(amax, fabsf(f[i])); ss += f[i] * f[i]; }
+    }
+    amax = wave_max(amax);
+    ss = wave_sum(ss);
+    int e = 0;
+    (void)frexpf(amax * (1.0f / 448.0f), &e);                     // amax / 448 = m * 2^e, m in [0.5, 1)  →  2^e >= amax / 448
+    float scale = (amax > 0.f) ? ldexpf(1.0f, e) : 1.0f;
+    if (amax > 0.f && ldexpf(1.0f, e - 1) * 448.0f >= amax) scale = ldexpf(1.0f, e - 1);   // m == 0.5 exactly: the smaller power still covers amax
+    const float inv = 1.0f / scale;
+    unsigned char* yr = y + (long)row * ldy;
+    for (int c = lane * 8; c < K; c += 512) {
+        float f[8];
+        unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
+        int lo = 0, hi = 0;
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0] * inv, f[1] * inv, lo, false);
+        lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2] * inv, f[3] * inv, lo, true);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4] * inv, f[5] * inv, hi, false);
+        hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
+        *reinterpret_cast<u32x2*>(yr + c) = u32x2{(unsigned)lo, (unsigned)hi};
+    }
+    if (lane == 0) rs[row] = (norm_eps >= 0.f) ? scale * rsqrtf(ss / (float)K + norm_eps) : scale;
+}
+
+extern "C" int padt_quant_rows_fp8(void* stream, const void* x, long ldx, void* x8, long ld8, void* row_scale_f32, long rows, long K, float norm_eps) {
+    if (rows <= 0) return 0;
+    if ((K & 7) || (ldx & 7) || (ld8 & 7) || ((uintptr_t)x & 15) || ((uintptr_t)x8 & 7) || ld8 < K) {
+        padt_set_error("padt_quant_rows_fp8: K, ldx, ld8 multiples of 8, x 16-byte / x8 8-byte aligned, ld8 >= K");
+        return -1;
+    }
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                       (unsigned char*)x8, ld8, (float*)row_scale_f32, (int)rows, (int)K, norm_eps);
+    PADT_CHECK_LAUNCH("quant_rows_fp8");
+    return 0;
+}
+

@@ -844,3 +844,14 @@ extern "C" int padt_gemm_packed_resid32(void* stream, const void* A, long lda, c
     return gemm_packed_impl(stream, A, lda, Wp, Kp, nullptr, X32, ldx, X32, ldx, M, N, K, EPI_RESID, -1.0f, split_k, workspace, a_packed ? 1 : 0,
                             (const float*)scales, Xb, ldxb);
 }
+
+// fp8 x fp8 MFMA GEMM at prompt length (gemm256.hip, FP8 instantiations of the phase-pipelined kernel); takes a profile slot like every tile GEMM.
+extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+                                  const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue,
+                                  unsigned long long* prof);
+extern "C" int padt_gemm_fp8(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+                             const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue) {
+    return padt_gemm_fp8_impl(stream, A8, lda, W8, ldw, row_scale, col_scale, bias, C, ldc, X32, ldx, Xb, ldxb, M, N, K, epilogue,
+                              (M > 64) ? next_prof_slot() : nullptr);
+}
+

@@ -35,6 +35,7 @@ struct Gemm256Args {
     long lo_off;                    // bf16 output: also store lo = bf16(x - hi) at C + lo_off (padt_gemm_bf16_ex)
     bf16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
     unsigned long long* prof;       // optional {first block start, last block end} in 100 MHz wall-clock ticks (padt_gemm_profile)
+    const float* cs;                // optional per-output-column scale of the accumulator (fp8 weights: dequantisation scale of weight row n)
 };
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
@@ -50,7 +51,7 @@ PADT_DEV char* slot(char* smem, int parity, int is_b, int h) { return smem + ((p
 // Per-lane byte offsets (relative to the tile's first row at k = 0) of the two 1-KiB DMA pieces this wave issues for
 // half-tile (is_b, h): piece c = 2*wave + i covers local rows 8c..8c+7; LDS slot (lr, lane & 7) holds source chunk
 // (lane & 7) ^ (lr & 7).  Computed once per block; a K-step only moves the (wave-uniform) base pointer by 128 bytes.
-template <int MF>
+template <int MF, int ES>
 PADT_DEV unsigned piece_offset(int is_b, int h, int i, int wave, int lane, int row0, int nrows, long ld) {
     const int c = wave * 2 + i;
     const int lr = c * 8 + (lane >> 3);
@@ -61,7 +62,7 @@ PADT_DEV unsigned piece_offset(int is_b, int h, int i, int wave, int lane, int r
     const int lra = lr < 32 * MF ? lr : 32 * MF - 1;
     int g = is_b ? (lr >> 5) * 64 + h * 32 + (lr & 31) : (lra / (16 * MF)) * (32 * MF) + h * (16 * MF) + lra % (16 * MF);
     g = (row0 + g < nrows) ? g : nrows - 1 - row0;                // clamp to the last valid row (results are not stored)
-    return (unsigned)(((long)g * ld + j * 8) * 2);
+    return (unsigned)((long)g * ld * ES + j * 16);               // ES = bytes per element (2 bf16, 1 fp8); chunk j = 16 bytes of the row's K-tile
 }
 
 PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, int wave) {
@@ -73,6 +74,17 @@ PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, in
 
 PADT_DEV bf16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
 
+// fp8 (OCP e4m3) MFMA 16x16x128: a lane's operand is 32 consecutive K bytes = two 16-byte LDS chunks; both scale exponents 0 select the
+// unscaled v_mfma_f32_16x16x128_f8f6f4 (checked: tools/ubench/f8probe.hip).  2048 FLOP per cycle per SIMD: twice the bf16 16x16x32 rate.
+typedef __attribute__((ext_vector_type(8))) int i32x8;
+PADT_DEV f32x4 mfma_f8(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4 c) {
+    const u32x4 al = __builtin_bit_cast(u32x4, a_lo), ah = __builtin_bit_cast(u32x4, a_hi);
+    const u32x4 bl = __builtin_bit_cast(u32x4, b_lo), bh = __builtin_bit_cast(u32x4, b_hi);
+    const i32x8 a = {(int)al[0], (int)al[1], (int)al[2], (int)al[3], (int)ah[0], (int)ah[1], (int)ah[2], (int)ah[3]};
+    const i32x8 b = {(int)bl[0], (int)bl[1], (int)bl[2], (int)bl[3], (int)bh[0], (int)bh[1], (int)bh[2], (int)bh[3]};
+    return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
+}
+
 PADT_DEV void unpack4b(u32x2 v, float* f) {
     f[0] = __builtin_bit_cast(float, v[0] << 16);
     f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
@@ -83,9 +95,13 @@ PADT_DEV void unpack4b(u32x2 v, float* f) {
 
 // MF = 16-row MFMA blocks per wave per m-half: tile height 64*MF (256, 192 or 128 rows) x 256 columns.  The shorter tiles
 // exist for wave quantisation: 4616 prompt rows x 2048 columns are 152 tiles of 256^2 on 256 CUs but 200 of 192x256.
-template <int EPI, bool OUT_F32, int MF>
+// FP8: A and W are OCP e4m3 bytes (K-tile = 128 elements = the same 128 bytes per row: staging, LDS image and swizzle are unchanged); a
+// lane's MFMA operand is the 32 consecutive K bytes [32 fq, 32 fq + 32) = LDS chunks 2 fq and 2 fq + 1, one 16x16x128 MFMA per fragment
+// pair and K-tile instead of two 16x16x32; the accumulator is scaled by rs[m] * cs[n] (activation row scale x weight row scale).
+template <int EPI, bool OUT_F32, int MF, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     constexpr int TMV = 64 * MF;
+    constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -102,7 +118,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     const int tm = first_m + (id % per_group) % gsz, tn = (id % per_group) / gsz;
     const int m0 = tm * TMV, n0 = tn * TN;
     const int wr = wave >> 2, wc = wave & 3;
-    const int nk = (p.K + TK - 1) / TK;
+    const int nk = (p.K * ES + 2 * TK - 1) / (2 * TK);            // K-tiles of 128 bytes per row
 
     f32x4 acc[2 * MF][4];
 #pragma unroll
@@ -116,11 +132,11 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     for (int h = 0; h < 2; ++h)
 #pragma unroll
         for (int i = 0; i < 2; ++i) {
-            offA[h][i] = piece_offset<MF>(0, h, i, wave, lane, m0, p.M, p.lda);
-            offB[h][i] = piece_offset<MF>(1, h, i, wave, lane, n0, p.N, p.ldw);
+            offA[h][i] = piece_offset<MF, ES>(0, h, i, wave, lane, m0, p.M, p.lda);
+            offB[h][i] = piece_offset<MF, ES>(1, h, i, wave, lane, n0, p.N, p.ldw);
         }
-    const char* tileA = reinterpret_cast<const char*>(p.A + (long)m0 * p.lda);     // wave-uniform bases
-    const char* tileW = reinterpret_cast<const char*>(p.W + (long)n0 * p.ldw);
+    const char* tileA = reinterpret_cast<const char*>(p.A) + (long)m0 * p.lda * ES;     // wave-uniform bases
+    const char* tileW = reinterpret_cast<const char*>(p.W) + (long)n0 * p.ldw * ES;
     auto stage_half = [&](int t, int is_b, int h, char* dst) {    // K % 64 == 0 (dispatcher): no tail, no zero page
         if (is_b) dma2(tileW + (long)t * (TK * 2), offB[h][0], offB[h][1], dst, wave);
         else dma2(tileA + (long)t * (TK * 2), offA[h][0], offA[h][1], dst, wave);
@@ -164,8 +180,8 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
             for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int kk = 0; kk < 2; ++kk) {
-                    b0[i][kk] = rd(bh0, wc * 32 + i * 16 + frow, kk * 4 + fq);
-                    b1[i][kk] = rd(bh1, wc * 32 + i * 16 + frow, kk * 4 + fq);
+                    b0[i][kk] = rd(bh0, wc * 32 + i * 16 + frow, FP8 ? 2 * fq + kk : kk * 4 + fq);
+                    b1[i][kk] = rd(bh1, wc * 32 + i * 16 + frow, FP8 ? 2 * fq + kk : kk * 4 + fq);
                 }
         }
         {
@@ -173,7 +189,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
             for (int i = 0; i < MF; ++i)
 #pragma unroll
-                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, kk * 4 + fq);
+                for (int kk = 0; kk < 2; ++kk) af[i][kk] = rd(ah, wr * (16 * MF) + i * 16 + frow, FP8 ? 2 * fq + kk : kk * 4 + fq);
         }
         __builtin_amdgcn_sched_barrier(0);
         if (PH == 0) { if (STEADY || t + 1 < nk) stage_half(t + 1, 0, 1, slot(smem, par ^ 1, 0, 1)); }
@@ -189,6 +205,14 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
         for (int q = 0; q < 2; ++q) {                             // quadrant order (m0,n0) (m0,n1) | (m1,n1) (m1,n0)
             const int NHq = (PH == 0) ? q : 1 - q;
+            if (FP8) {
+#pragma unroll
+                for (int i = 0; i < MF; ++i)
+#pragma unroll
+                    for (int j = 0; j < 2; ++j)
+                        acc[PH * MF + i][NHq * 2 + j] = mfma_f8(NHq ? b1[j][0] : b0[j][0], NHq ? b1[j][1] : b0[j][1], af[i][0], af[i][1],
+                                                                acc[PH * MF + i][NHq * 2 + j]);
+            } else {
 #pragma unroll
             for (int kk = 0; kk < 2; ++kk)
 #pragma unroll
@@ -196,6 +220,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
                     for (int j = 0; j < 2; ++j)
                         acc[PH * MF + i][NHq * 2 + j] = mfma16(NHq ? b1[j][kk] : b0[j][kk], af[i][kk], acc[PH * MF + i][NHq * 2 + j]);
+            }
         }
         __builtin_amdgcn_s_setprio(0);
         if (STEADY) { if (PH == 0) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); }
@@ -236,6 +261,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         float bv[4][4];
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) unpack4b(*reinterpret_cast<const u32x2*>(p.bias ? p.bias + nb + ni * 16 : zpage), bv[ni]);
+        f32x4 csc[4];                                             // per-column scales (fp8 weights), folded into the accumulator with the row scale
+#pragma unroll
+        for (int ni = 0; ni < 4; ++ni) csc[ni] = f32x4{1.f, 1.f, 1.f, 1.f};
+        if (FP8 && p.cs) {
+#pragma unroll
+            for (int ni = 0; ni < 4; ++ni) csc[ni] = *reinterpret_cast<const f32x4*>(p.cs + nb + ni * 16);
+        }
         float rsc[2 * MF];
 #pragma unroll
         for (int mi = 0; mi < 2 * MF; ++mi) rsc[mi] = 1.0f;
@@ -282,7 +314,9 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                     for (int ni = 0; ni < 4; ni += 2) {
                         float o[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
+                        for (int r = 0; r < 4; ++r)
+                            o[r] = FP8 ? silu(acc[mi][ni][r] * (rsc[mi] * csc[ni][r]) + bv[ni][r]) * (acc[mi][ni + 1][r] * (rsc[mi] * csc[ni + 1][r]) + bv[ni + 1][r])
+                                       : silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
                         const int no = (n0 >> 1) + wc * 32 + (ni >> 1) * 16 + fq * 4;
                         if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                     }
@@ -291,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                     for (int ni = 0; ni < 4; ++ni) {
                         float o[4];
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) o[r] = acc[mi][ni][r] * rsc[mi] + bv[ni][r];
+                        for (int r = 0; r < 4; ++r) o[r] = FP8 ? acc[mi][ni][r] * (rsc[mi] * csc[ni][r]) + bv[ni][r] : acc[mi][ni][r] * rsc[mi] + bv[ni][r];
                         if (ROPE) {
                             const float c0 = keep[ni] != 0.f ? cc[b][ni].x : 1.0f, c1 = keep[ni] != 0.f ? cc[b][ni].y : 1.0f;
                             const float s0 = keep[ni] != 0.f ? ss[b][ni].x : 0.0f, s1 = keep[ni] != 0.f ? ss[b][ni].y : 0.0f;
@@ -437,13 +471,13 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     }
 }
 
-template <int EPI, bool F32, int MF>
+template <int EPI, bool F32, int MF, bool FP8 = false>
 static void launch256_mf(const Gemm256Args& a, hipStream_t s) {
     static PerDeviceOnce once;
-    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32, MF>),
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_tile256_kernel<EPI, F32, MF, FP8>),
                                             hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES); });
     const int ntm = (a.M + 64 * MF - 1) / (64 * MF), ntn = (a.N + TN - 1) / TN;
-    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32, MF>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
+    hipLaunchKernelGGL((gemm_tile256_kernel<EPI, F32, MF, FP8>), dim3(ntm * ntn), dim3(512), LDS_BYTES, s, a);
 }
 
 // Tile height by a wave-quantisation cost model: rounds of 256 co-resident tiles x tile height, with a penalty for the
@@ -557,7 +591,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     const int group_m = g_knobs.group_m;
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;
@@ -571,3 +605,51 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     }
     return 0;
 }
+
+// ---------------------------------------------------------------------------------------------------------------------
+// fp8 x fp8 MFMA GEMM (BASELINE configs[4], the 7B "fp8 MFMA weight path" at prompt length): A8 = e4m3 activations [M][K] with one fp32 scale
+// per row (padt_quant_rows_fp8: amax scaling, optionally x the RMSNorm rstd of the row), W8 = e4m3 weights [N][K] (nn.Linear layout) with one
+// fp32 scale per weight row.  C = epi(rs[m] * cs[n] * (A8 · W8^T) + bias): epilogue 0 → bf16 C; 3 → SwiGLU (W rows interleaved gate16 | up16),
+// bf16 C with N / 2 columns; 2 → the fp32 residual stream: X32 += ..., Xb = bf16(X32) (C unused).  The fp8 products are exact in fp32;
+// accumulation is fp32.  K % 128 == 0, N % 256 == 0, lda / ldw % 16 == 0, 16-byte aligned operands.
+extern "C" void padt_set_error(const char* msg);
+template <int EPI, bool F32>
+static void run256_fp8(const Gemm256Args& a, int mf, hipStream_t s) {
+    if (mf == 4) launch256_mf<EPI, F32, 4, true>(a, s);
+    else if (mf == 3) launch256_mf<EPI, F32, 3, true>(a, s);
+    else launch256_mf<EPI, F32, 2, true>(a, s);
+}
+
+extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+                             const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue,
+                             unsigned long long* prof) {
+    if (M <= 0 || N <= 0) return 0;
+    if (K <= 0 || (K & 127) || (N & 255) || (lda & 15) || (ldw & 15) || ((uintptr_t)A8 & 15) || ((uintptr_t)W8 & 15) || row_scale == nullptr ||
+        col_scale == nullptr || ((uintptr_t)col_scale & 15) || ((uintptr_t)bias & 7)) {
+        padt_set_error("padt_gemm_fp8: K % 128 == 0, N % 256 == 0, lda / ldw % 16 == 0, 16-byte aligned A8 / W8 / col_scale and both scale vectors required");
+        return -1;
+    }
+    RopeEpi norope{nullptr, nullptr, 0, 0, 0};
+    const Plan256 pl = plan256(M, N, K / 2, g_knobs.mf, false, false);      // cost model in K-tiles: a 128-element fp8 K-tile costs what 64 bf16 elements do
+    Gemm256Args a{(const bf16_t*)A8, lda, (const bf16_t*)W8, ldw, (const bf16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K,
+                  (const float*)row_scale, norope, g_knobs.group_m < 1 ? 1 : g_knobs.group_m, 0, 0, nullptr, 0, prof, (const float*)col_scale};
+    hipStream_t s = (hipStream_t)stream;
+    if (epilogue == EPI_NONE) {
+        if (C == nullptr || (ldc & 7) || ((uintptr_t)C & 15) || ldc < N) { padt_set_error("padt_gemm_fp8: bf16 C with ldc % 8 == 0, ldc >= N required"); return -1; }
+        run256_fp8<EPI_NONE, false>(a, pl.mf, s);
+    } else if (epilogue == EPI_SWIGLU) {
+        if (C == nullptr || (ldc & 7) || ((uintptr_t)C & 15) || ldc < N / 2) { padt_set_error("padt_gemm_fp8: SwiGLU needs bf16 C with ldc >= N / 2"); return -1; }
+        run256_fp8<EPI_SWIGLU, false>(a, pl.mf, s);
+    } else if (epilogue == EPI_RESID) {
+        if (X32 == nullptr || (ldx & 3) || ((uintptr_t)X32 & 15) || (Xb && ((ldxb & 7) || ((uintptr_t)Xb & 15)))) {
+            padt_set_error("padt_gemm_fp8: epilogue 2 updates the fp32 stream X32 (ldx % 4, 16-byte aligned) and writes the optional bf16 mirror Xb (ldxb % 8)");
+            return -1;
+        }
+        a.C = X32; a.ldc = ldx; a.R = (const bf16_t*)X32; a.ldr = ldx; a.r_f32 = 1; a.C2 = (bf16_t*)Xb; a.ldc2 = ldxb;
+        run256_fp8<EPI_RESID, true>(a, pl.mf, s);
+    } else { padt_set_error("padt_gemm_fp8: epilogue 0, 2 or 3"); return -1; }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+

@@ -159,6 +159,42 @@ def gemm_resid32(a, w, bias, x32, xb=None):
     return x32
 
 
+def quant_rows_fp8(x, norm_eps=None, out=None, rs=None):
+    """bf16 rows → (e4m3 bytes (M, K) uint8, fp32 row scales (M,)) for gemm_fp8; norm_eps: fold rsqrt(mean(x^2) + eps) into the row scale."""
+    _chk_bf16(x)
+    M, K = x.shape
+    if out is None:
+        out = torch.empty((M, K), device=x.device, dtype=torch.uint8)
+    if rs is None:
+        rs = torch.empty((M,), device=x.device, dtype=torch.float32)
+    _lib.check(_lib.load().padt_quant_rows_fp8(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), _p(rs), M, K,
+                                               -1.0 if norm_eps is None else float(norm_eps)), "padt_quant_rows_fp8")
+    return out, rs
+
+
+def gemm_fp8(a8, w8, col_scale, row_scale, bias=None, out=None, epilogue=EPI_NONE, x32=None, xb=None):
+    """fp8 x fp8 MFMA GEMM (padt_gemm_fp8): a8 (M, K) / w8 (N, K) uint8 e4m3, row_scale (M,) / col_scale (N,) fp32.
+    epilogue EPI_NONE / EPI_SWIGLU → bf16 `out`; EPI_RESID → x32 += ... in place (+ bf16 mirror xb)."""
+    lib = _lib.load()
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(-1) == 1 and w8.stride(-1) == 1
+    assert row_scale.dtype == torch.float32 and col_scale.dtype == torch.float32 and col_scale.is_contiguous()
+    _chk_bf16(bias, xb)
+    M, K = a8.shape
+    N = w8.shape[0]
+    if epilogue == EPI_RESID:
+        assert x32 is not None and x32.dtype == torch.float32 and x32.stride(-1) == 1
+    else:
+        n_out = N // 2 if epilogue == EPI_SWIGLU else N
+        if out is None:
+            out = torch.empty((M, n_out), device=a8.device, dtype=BF16)
+        _chk_bf16(out)
+    _tg_note("fp8", M, N, K)
+    _lib.check(lib.padt_gemm_fp8(_stream(), _p(a8), a8.stride(0), _p(w8), w8.stride(0), _p(row_scale), _p(col_scale), _p(bias), _p(out),
+                                 out.stride(0) if out is not None else 0, _p(x32), x32.stride(0) if x32 is not None else 0, _p(xb),
+                                 xb.stride(0) if xb is not None else 0, M, N, K, int(epilogue)), "padt_gemm_fp8")
+    return x32 if epilogue == EPI_RESID else out
+
+
 def gemm_knobs(mode256=-1, mf=-1, peel=-1, colsplit=-1, group_m=-1):
     """Dispatch knobs of the 256-row tile kernel (tests / tuning tools); -1 keeps a field.  Defaults: (1, 0, 1, 1, 8)."""
     _lib.check(_lib.load().padt_gemm_knobs(int(mode256), int(mf), int(peel), int(colsplit), int(group_m)), "padt_gemm_knobs")

@@ -983,3 +983,64 @@ def test_cast_bf16_f32_and_rmsnorm_f32(ops):
     w = rnd(1280, seed=99) * 0.1 + 1
     ref = x32 * torch.rsqrt(x32.pow(2).mean(-1, keepdim=True) + 1e-6) * w.float()
     close_bf16(ops.rmsnorm_f32(x32, w), ref, "rmsnorm_f32")
+
+
+# ------------------------------------------------------------------------------------------------ fp8 x fp8 MFMA GEMM
+def _dequant8(q, scale):
+    return q.view(torch.float8_e4m3fn).float() * scale[:, None]
+
+
+@pytest.mark.parametrize("M,K", [(77, 2048), (300, 18944), (16, 128)])
+def test_quant_rows_fp8_matches_the_host_statement(ops, M, K):
+    """padt_quant_rows_fp8 == ops.quantize_fp8_rows's rule applied to activation rows: power-of-two scale 2^ceil(log2(amax / 448)),
+    e4m3 codes bit for bit; with norm_eps the row scale carries rsqrt(mean(x^2) + eps)."""
+    x = rnd(M, K, seed=201)
+    x[3] *= 50
+    x[5] = 0
+    q_ref, sc_ref, _ = ops.quantize_fp8_rows(x)
+    sc_ref = torch.where(x.float().abs().amax(1) > 0, sc_ref, torch.ones_like(sc_ref))
+    q, rs = ops.quant_rows_fp8(x)
+    assert torch.equal(rs, sc_ref)
+    assert torch.equal(q[x.float().abs().amax(1) > 0], q_ref[x.float().abs().amax(1) > 0]) and ((q[5] & 0x7F) == 0).all()
+    q2, rs2 = ops.quant_rows_fp8(x, norm_eps=1e-6)
+    assert torch.equal(q2, q)
+    rstd = torch.rsqrt(x.float().pow(2).mean(-1) + 1e-6)
+    assert ((rs2 - sc_ref * rstd).abs() <= 2e-6 * (sc_ref * rstd).abs()).all()
+
+
+@pytest.mark.parametrize("M,N,K", [(1000, 512, 256), (4616, 2560, 2048), (577, 4608, 3584), (300, 768, 1280)])
+@pytest.mark.parametrize("mf", [0, 2, 3, 4])
+def test_gemm_fp8_mfma_against_fp32_on_the_dequantised_operands(ops, M, N, K, mf, knobs):
+    """padt_gemm_fp8 (v_mfma_f32_16x16x128_f8f6f4 in the 256-row tile kernel, every tile height) against the fp32 GEMM of the DEQUANTISED
+    operands — plain (+bias), SwiGLU, and the fp32 residual stream with its bf16 mirror.  The fp8 MFMA does not sum its 128 products in full
+    fp32: measured ≈2^-15 of the magnitude sum of a dot product (tools/ubench/f8probe.hip: 4e-4 at |c| = 11), so the fp32 output is held to
+    3e-5 x (|A| · |W|^T) element-wise; bf16 outputs to the usual one-rounding tolerance."""
+    if mf:
+        knobs(mf=mf)
+    x = rnd(M, K, seed=211)
+    w = rnd(N, K, scale=0.05, seed=212)
+    b = rnd(N, seed=213)
+    w[7] *= 30.0
+    a8, rs = ops.quant_rows_fp8(x)
+    w8, ws, _ = ops.quantize_fp8_rows(w)
+    ref = _dequant8(a8, rs) @ _dequant8(w8, ws).T
+    out = ops.gemm_fp8(a8, w8, ws, rs, bias=b)
+    close_bf16(out, ref + b.float(), f"fp8 plain {M}x{N}x{K}")
+    x32 = torch.randn(M, N, device="cuda", generator=torch.Generator(device="cuda").manual_seed(5))
+    x0 = x32.clone()
+    xb = torch.zeros(M, N, device="cuda", dtype=BF)
+    ops.gemm_fp8(a8, w8, ws, rs, epilogue=ops.EPI_RESID, x32=x32, xb=xb)
+    mag = _dequant8(a8, rs).abs() @ _dequant8(w8, ws).abs().T
+    bad = (x32 - (x0 + ref)).abs() > 3e-5 * mag + 1e-6
+    assert not bad.any(), f"fp8 resid32 {M}x{N}x{K}: {int(bad.sum())} outside 3e-5 of the magnitude sum, worst {((x32 - x0 - ref).abs() / (mag + 1e-9)).max().item():.2e}"
+    assert torch.equal(xb, x32.to(BF))
+    wi = interleave_gate_up(w[: N // 2].contiguous(), w[N // 2:].contiguous())
+    bi = interleave_gate_up(b[: N // 2].reshape(-1, 1), b[N // 2:].reshape(-1, 1)).view(-1)
+    wi8, wis, _ = ops.quantize_fp8_rows(wi)
+    a8n, rsn = ops.quant_rows_fp8(x, norm_eps=1e-6)
+    lin = (_dequant8(a8n, torch.ones_like(rsn)) @ _dequant8(wi8, wis).T) * rsn[:, None] + bi.float()
+    y = lin.view(M, N // 32, 2, 16)
+    close_bf16(ops.gemm_fp8(a8n, wi8, wis, rsn, bias=bi, epilogue=ops.EPI_SWIGLU), (torch.nn.functional.silu(y[:, :, 0]) * y[:, :, 1]).reshape(M, N // 2),
+               f"fp8 swiglu {M}x{N}x{K}")
+    with pytest.raises(Exception, match="padt_gemm_fp8"):
+        ops.gemm_fp8(a8[:, :64], w8[:, :64], ws, rs)
