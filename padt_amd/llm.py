@@ -331,20 +331,42 @@ class LanguageModel:
         att = torch.empty((T, Hq * hd), device=dev, dtype=bf)
         h = torch.empty((T, W.llm_ipad), device=dev, dtype=bf)
         mx = max(plan.lens)
+        f8 = W.fp8_prefill and x32 is not None
+        if f8:                                                       # e4m3 images of the three GEMM inputs of a layer + their row scales
+            x8 = torch.empty((T, cfg.hidden_size), device=dev, dtype=torch.uint8)
+            a8 = torch.empty((T, Hq * hd), device=dev, dtype=torch.uint8)
+            h8 = torch.empty((T, W.llm_ipad), device=dev, dtype=torch.uint8)
+            rs8 = torch.empty((T,), device=dev, dtype=torch.float32)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
-            ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)                # norm weight is folded into qkv.w
-            ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
+            # fp8 x fp8 MFMA path (llm_weights="fp8"): the GEMM input rows are quantised to e4m3 (power-of-two row scale x the folded norm's
+            # rstd) and multiplied with the e4m3 weight image; a projection whose shape the fp8 kernel does not take keeps the bf16 GEMM
+            if f8 and (p + "qkv.w8") in W:
+                ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
+                ops.gemm_fp8(x8, W[p + "qkv.w8"], W[p + "qkv.ws"], rs8, bias=W[p + "qkv.b"], out=qkv)
+            else:
+                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into qkv.w
+                ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
-            if x32 is not None:
+            if f8 and (p + "o.w8") in W:
+                ops.quant_rows_fp8(att, out=a8, rs=rs8)
+                ops.gemm_fp8(a8, W[p + "o.w8"], W[p + "o.ws"], rs8, epilogue=ops.EPI_RESID, x32=x32, xb=x)
+            elif x32 is not None:
                 ops.gemm_resid32(att, W[p + "o.w"], None, x32, x)
             else:
                 ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
-            ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)                # norm weight is folded into gu.w
-            ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
-            if x32 is not None:
+            if f8 and (p + "gu.w8") in W:
+                ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
+                ops.gemm_fp8(x8, W[p + "gu.w8"], W[p + "gu.ws"], rs8, out=h, epilogue=ops.EPI_SWIGLU)
+            else:
+                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into gu.w
+                ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
+            if f8 and (p + "down.w8") in W:
+                ops.quant_rows_fp8(h, out=h8, rs=rs8)
+                ops.gemm_fp8(h8, W[p + "down.w8"], W[p + "down.ws"], rs8, epilogue=ops.EPI_RESID, x32=x32, xb=x)
+            elif x32 is not None:
                 ops.gemm_resid32(h, W[p + "down.w"], None, x32, x)
             else:
                 ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)

@@ -197,6 +197,11 @@ def _pad_cols(t: torch.Tensor, n: int) -> torch.Tensor:
     return out
 
 
+def fp8_gemm_ok(n: int, k: int) -> bool:
+    """Shapes padt_gemm_fp8 takes: whole 256-column tiles and whole 128-element K-tiles."""
+    return n % 256 == 0 and k % 128 == 0
+
+
 class PreparedWeights(dict):
     """name → bf16 device tensor (kernel layout).  Plain dict plus a few derived sizes."""
     vit_ipad: int
@@ -205,6 +210,7 @@ class PreparedWeights(dict):
     dec_hp: bool = False
     llm_weights: str = "bf16"
     resid_f32: bool = True
+    fp8_prefill: bool = False
 
 
 def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16") -> PreparedWeights:
@@ -219,6 +225,10 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
     # fp32 residual streams in the ViT and the LLM (default; PADT_RESID_F32=0 keeps the round-2 bf16 streams for A/B runs): the
     # residual GEMMs' epilogues update an fp32 stream in place and emit its bf16 mirror for the next projection
     W.resid_f32 = os.environ.get("PADT_RESID_F32", "1") != "0"
+    # llm_weights = "fp8": at prompt length the LLM projections run as fp8 x fp8 MFMA GEMMs (activation rows quantised to e4m3 on the fly,
+    # v_mfma_f32_16x16x128_f8f6f4: 1.6x the bf16 tile GEMM on the 7B shapes) wherever the shape allows; PADT_FP8_PREFILL=0 keeps the
+    # prompt pass on the bf16 image of the quantised weights (round-2 behaviour).  Needs the fp32 residual streams.
+    W.fp8_prefill = llm_weights == "fp8" and W.resid_f32 and os.environ.get("PADT_FP8_PREFILL", "1") != "0"
 
     def put(name, t):
         W[name] = t.to(device=dev, dtype=BF16).contiguous()
@@ -289,6 +299,8 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
                 W[d + nm + ".w"] = deq                           # prefill: bf16 image of the quantised matrix (exact)
                 W[d + nm + ".wq"] = pack_weight_fp8(q)           # decode: fp8 fragment-packed image + per-row scales
                 W[d + nm + ".ws"] = sc
+                if W.fp8_prefill and fp8_gemm_ok(q.shape[0], q.shape[1]):
+                    W[d + nm + ".w8"] = q.contiguous()           # prefill: row-major e4m3 image for the fp8 x fp8 MFMA GEMM (padt_gemm_fp8)
             else:
                 W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
     # fragment-packed copy of the head table for the decode-step logit head (+0.62 GB at 3B; the row-major table stays: it is

@@ -137,3 +137,73 @@ class bf16_operand_floor:
         for k, v in self._saved.items():
             setattr(O, k, v)
         return False
+
+
+# ------------------------------------------------------------------------------------------------ fp8 x fp8 prompt pass
+def fake_quant_rows_e4m3(t):
+    """What padt_quant_rows_fp8 + the fp8 MFMA see of a row: bf16 storage first, then e4m3 codes under the power-of-two row scale
+    2^ceil(log2(amax / 448)) — returned de-quantised (fp32)."""
+    t = t.to(torch.bfloat16).to(torch.float32)
+    amax = t.abs().amax(dim=-1, keepdim=True)
+    scale = torch.where(amax > 0, torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-30) / 448.0))), torch.ones_like(amax))
+    return (t / scale).to(torch.float8_e4m3fn).to(torch.float32) * scale
+
+
+class fp8_prefill_hooks:
+    """Context manager for models built with llm_weights="fp8" and the fp8 x fp8 MFMA prompt pass (model.W.fp8_prefill): inside it the
+    oracle's LLM layer quantises, AT PROMPT LENGTH ONLY (Lq > 1 — decode steps multiply bf16 activations with the fp8 weights), the input
+    rows of exactly those projections the HIP path runs through padt_gemm_fp8, the way padt_quant_rows_fp8 does.  Use together with
+    effective_llm_weights (dequantised matrices, norm weights folded): the oracle then computes the same function of the input as the HIP
+    path, up to accumulation order and the occasional e4m3 code that flips because the two sides' bf16 roundings of an activation differ."""
+
+    def __init__(self, model):
+        W = model.W
+        self.on = bool(getattr(W, "fp8_prefill", False))
+        self.use = {nm: ("llm.0.%s.w8" % nm) in W for nm in ("qkv", "o", "gu", "down")}
+
+    def __enter__(self):
+        import torch.nn.functional as F
+        self._saved = O.llm_layer
+        if not self.on:
+            return self
+        use = self.use
+        fq = fake_quant_rows_e4m3
+
+        def llm_layer(w, pfx, cfg, h, cos, sin, attn_bias, cache, li):
+            B, Lq, _ = h.shape
+            if Lq == 1:
+                return self._saved(w, pfx, cfg, h, cos, sin, attn_bias, cache, li)
+
+            def normed(x, wn, on):
+                if not on:
+                    return O.rms_norm(x, wn, cfg.rms_eps)
+                xb = x.to(torch.bfloat16).to(torch.float32)          # the bf16 mirror the quantiser reads (statistics from it too)
+                return wn * (fq(x) * torch.rsqrt(xb.pow(2).mean(-1, keepdim=True) + cfg.rms_eps))
+            n = normed(h, w[pfx + "input_layernorm.weight"], use["qkv"])
+            q = O.linear(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"]).view(B, Lq, cfg.num_heads, cfg.head_dim)
+            k = O.linear(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            v = O.linear(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            c, s = cos.unsqueeze(2), sin.unsqueeze(2)
+            q = q * c + O.rotate_half(q) * s
+            k = k * c + O.rotate_half(k) * s
+            if cache is not None:
+                k, v = cache.update(li, k, v)
+            rep = cfg.num_heads // cfg.num_kv_heads
+            qh = q.transpose(1, 2).float()
+            kh = k.transpose(1, 2).repeat_interleave(rep, 1).float()
+            vh = v.transpose(1, 2).repeat_interleave(rep, 1).float()
+            sc = torch.matmul(qh, kh.transpose(2, 3)) * (cfg.head_dim ** -0.5) + attn_bias
+            a = torch.matmul(torch.softmax(sc, dim=-1), vh).transpose(1, 2).reshape(B, Lq, -1)
+            h = h + O.linear(fq(a) if use["o"] else a, w[pfx + "self_attn.o_proj.weight"])
+            n = normed(h, w[pfx + "post_attention_layernorm.weight"], use["gu"])
+            g = O.linear(n, w[pfx + "mlp.gate_proj.weight"])
+            u = O.linear(n, w[pfx + "mlp.up_proj.weight"])
+            m = F.silu(g) * u
+            return h + O.linear(fq(m) if use["down"] else m, w[pfx + "mlp.down_proj.weight"])
+
+        O.llm_layer = llm_layer
+        return self
+
+    def __exit__(self, *exc):
+        O.llm_layer = self._saved
+        return False

@@ -562,6 +562,7 @@ def test_fp8_llm_weights_against_oracle_on_dequantised_weights():
     w = U.bf16_weights(cfg, seed=19, std=0.05)
     model = PaDTForConditionalGeneration(cfg, w, device="cuda", llm_weights="fp8")
     assert model.W.llm_weights == "fp8" and "llm.0.qkv.wq" in model.W and "llm.0.qkv.wp" not in model.W
+    assert model.W.fp8_prefill and "llm.0.qkv.w8" in model.W and "llm.0.o.w8" in model.W      # 512-wide: qkv and o take the fp8 MFMA GEMM
     wo = U.effective_llm_weights(model, w)
     oc = U.oracle_config(cfg)
     grids = [[1, 8, 8], [1, 10, 12]]
@@ -572,7 +573,8 @@ def test_fp8_llm_weights_against_oracle_on_dequantised_weights():
                          schedule=sched)
     L = ids.shape[1]
     toks = out.sequences.cpu()[:, L:]
-    ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    with U.fp8_prefill_hooks(model):                             # prompt pass: e4m3 activation rows into the fp8 x fp8 MFMA GEMMs
+        ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
     n_tie = 0
     for t in range(T):
         lg = ores["logits"][t]

@@ -495,8 +495,10 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     untied 152 064-row lm_head next to the embedding table, real 1280-wide ViT blocks and the real 98 M-parameter decoder — with the depth cut
     to 2 LLM layers / 2 ViT blocks so that the fp32 oracle runs in seconds.  Two ragged images, a RIC-shaped completion (caption text with
     4 interleaved runs of 5 VRTs, src/preprocess/process_ric.py:147,150 templates) through generate → parse → vl_decode:
-    ids by the margin rule, per-step hidden rows, object grouping of the parser, boxes.  bf16 weights, and the fp8 e4m3 weight path
-    (decode steps stream the fp8 image; the oracle runs the dequantised matrices, parity_util.effective_llm_weights)."""
+    ids by the margin rule, per-step hidden rows, object grouping of the parser, boxes.  bf16 weights, and the fp8 e4m3 path: the prompt
+    pass runs fp8 x fp8 MFMA GEMMs (activation rows quantised to e4m3 on the fly), the decode steps stream the fp8 weight image against
+    bf16 activations; the oracle runs the dequantised matrices (parity_util.effective_llm_weights) and quantises the same activation
+    rows at prompt length (parity_util.fp8_prefill_hooks)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import padt_amd
@@ -523,7 +525,9 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     seq = out.sequences.cpu()
     toks = seq[:, L:]
     assert toks.shape == (2, T) and (toks[:, -1] == cfg.eos_token_id).all()
-    with torch.no_grad():
+    if llm_weights == "fp8":
+        assert model.W.fp8_prefill and all(f"llm.0.{nm}.w8" in model.W for nm in ("qkv", "o", "gu", "down"))     # every 7B projection takes padt_gemm_fp8
+    with torch.no_grad(), U.fp8_prefill_hooks(model):              # (no-op for bf16 weights) prompt pass with e4m3 activation rows
         ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
     n_tie = 0
     for t in range(T):
