@@ -549,7 +549,11 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     for t in range(T):
         mx, rms = rel(hid[t], ores["hidden"][t][:, -1])
         worst = max(worst, rms)
-        assert rms < 1.5e-2, f"hidden step {t}: rel rms {rms:.3e}"
+        # fp8: e4m3 activation rows at prompt length make the pass discontinuous (a one-bf16-ulp upstream difference flips e4m3 codes by a full
+        # 12.5 % step), so after the first fp8 GEMM the two sides' quantisation errors (3.6 % rms per GEMM each) decorrelate: agreement with the
+        # oracle that quantises the same rows is the fp8 noise level itself — measured 9.4e-2 on the prompt's last row after 2 layers x 4 GEMMs
+        # at 7B width, 1-1.5e-2 on the decode-step rows (bf16 activations over the fp8-prefilled KV)
+        assert rms < (1.5e-1 if llm_weights == "fp8" else 1.5e-2), f"hidden step {t}: rel rms {rms:.3e}"
     # ---- parser: 4 interleaved VRT runs per sample → 4 objects of 5 VRT features each; decoder on both sides
     n_m = [g[1] * g[2] // 4 for g in grids]
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, max(n_m)), 2)
@@ -567,7 +571,7 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
     mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
     print(f"\n[7B geometry, {llm_weights}] ties {n_tie}/{2 * T}; hidden rel rms worst {worst:.3e}; {2 * n_obj} objects: box |d|max {db:.3e}, mask rel max {mx:.3e} rms {rms:.3e}")
-    assert db < 2e-3 and mx < 3e-2
+    assert (db < 5e-3 and mx < 5e-2) if llm_weights == "fp8" else (db < 2e-3 and mx < 3e-2)   # measured: fp8 1.6e-3 / 1.3e-2, bf16 6.6e-4 / 8.3e-3
 
 
 def test_padt_decoder_ovd_shape_seven_objects_per_image():
