@@ -441,8 +441,9 @@ def extra_workloads(args, device, model3b, cfg3b, grid3b):
         steps = 16
         r = short_run(model, inp, a, steps)
         alg = alg_tflop_per_image(cfg, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
-        r.update({"workload": "%s %s, batch=%d/GPU, L=%d, T_new=%d, %d obj x %d VRT per image, %s LLM weights in the decode steps" % (
-            {"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)"}[a.model], a.task.upper(), a.batch, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], a.weights),
+        r.update({"workload": "%s %s, batch=%d/GPU, L=%d, T_new=%d, %d obj x %d VRT per image, %s LLM weights%s" % (
+            {"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)"}[a.model], a.task.upper(), a.batch, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], a.weights,
+            " (fp8 x fp8 MFMA prompt pass, fp8 weight streaming in the decode steps)" if a.weights == "fp8" else ""),
             "alg_tflop_per_image": round(alg, 3), "mfma_frac_e2e": round(r["value"] * alg / MFMA_BF16_PEAK_TFLOPS, 4)})
         out[key] = r
         del model, inp
@@ -627,7 +628,7 @@ def main():
         value = n_img / elapsed
         alg_tf = alg_tflop_per_image(cfg, inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
         fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 MFMA operands, fp32 "
-               "residual streams in ViT / LLM, split-precision PaDT decoder" + (", fp8 e4m3 LLM weights in the decode steps" if args.weights == "fp8" else "") +
+               "residual streams in ViT / LLM, split-precision PaDT decoder" + (", fp8 e4m3 LLM weights: fp8 x fp8 MFMA prompt pass + fp8 weight streaming in the decode steps" if args.weights == "fp8" else "") +
                ", random-init weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps of %d consecutive "
                "batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
         wl = fmt % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
