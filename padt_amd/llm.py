@@ -333,7 +333,7 @@ class LanguageModel:
         mx = max(plan.lens)
         D = cfg.hidden_size
         # row statistics of the stream come from the residual GEMMs' epilogues (fp32 streams): one row_rstd pass in front of layer 0 only
-        ssq = torch.empty(((D + 63) // 64, T), device=dev, dtype=torch.float32) if (x32 is not None and W.epi_ssq) else None
+        ssq = torch.empty(((D + 63) // 64, T), device=dev, dtype=torch.float32) if x32 is not None else None
         have_rstd = False
         f8 = W.fp8_prefill and x32 is not None
         if f8:                                                       # e4m3 images of the three GEMM inputs of a layer + their row scales
@@ -362,7 +362,7 @@ class LanguageModel:
                 have_rstd = False
             elif x32 is not None:
                 ops.gemm_resid32(att, W[p + "o.w"], None, x32, x, ssq=ssq)
-                have_rstd = ssq is not None
+                have_rstd = True
             else:
                 ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
             if f8 and (p + "gu.w8") in W:
@@ -382,9 +382,8 @@ class LanguageModel:
                 have_rstd = False
             elif x32 is not None:
                 ops.gemm_resid32(h, W[p + "down.w"], None, x32, x, ssq=ssq)
-                if ssq is not None:
-                    ops.rstd_from_partials(ssq, D, T, eps=cfg.rms_norm_eps, out=rstd)   # the next layer's input-norm statistics
-                have_rstd = ssq is not None
+                ops.rstd_from_partials(ssq, D, T, eps=cfg.rms_norm_eps, out=rstd)       # the next layer's input-norm statistics
+                have_rstd = True
             else:
                 ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
         if x32 is not None:

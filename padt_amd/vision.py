@@ -156,7 +156,7 @@ class VisionEncoder:
         qkv = torch.empty((P, 3 * vh), device=x.device, dtype=x.dtype)
         att = torch.empty_like(x)
         hbuf = torch.empty((P, W.vit_ipad), device=x.device, dtype=x.dtype)
-        ssq = torch.empty(((vh + 63) // 64, P), device=x.device, dtype=torch.float32) if (f32 and W.epi_ssq) else None
+        ssq = torch.empty(((vh + 63) // 64, P), device=x.device, dtype=torch.float32) if f32 else None
         for i in range(v.depth):
             self.block(i, x, plan, rstd, qkv, att, hbuf, x32=x32, ssq=ssq, have_rstd=(ssq is not None and i > 0))
         high = x32 if f32 else x                                               # the PaDT decoder reads fp32 or bf16 rows

@@ -211,7 +211,6 @@ class PreparedWeights(dict):
     llm_weights: str = "bf16"
     resid_f32: bool = True
     fp8_prefill: bool = False
-    epi_ssq: bool = True
 
 
 def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16") -> PreparedWeights:
@@ -230,8 +229,6 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
     # v_mfma_f32_16x16x128_f8f6f4: 1.6x the bf16 tile GEMM on the 7B shapes) wherever the shape allows; PADT_FP8_PREFILL=0 keeps the
     # prompt pass on the bf16 image of the quantised weights (round-2 behaviour).  Needs the fp32 residual streams.
     W.fp8_prefill = llm_weights == "fp8" and W.resid_f32 and os.environ.get("PADT_FP8_PREFILL", "1") != "0"
-    # row statistics of the fp32 streams from the residual GEMMs' epilogues (PADT_EPI_SSQ=0: a row_rstd pass in front of every folded norm)
-    W.epi_ssq = W.resid_f32 and os.environ.get("PADT_EPI_SSQ", "1") != "0"
 
     def put(name, t):
         W[name] = t.to(device=dev, dtype=BF16).contiguous()

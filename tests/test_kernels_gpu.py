@@ -957,9 +957,7 @@ def test_gemm_resid32_stream_and_mirror(ops, M, N, K, knobs):
     assert ((rstd - ref_rstd).abs() <= 3e-6 * ref_rstd).all()
     z2 = x32.clone()
     ops.gemm_resid32(a, w, b, z2[:, :N], None)
-    body = M - M % 256 if M == 2 * 256 + 24 else M                 # (with the partials a forced / chosen tail peel is off: those rows take the tile kernel)
-    assert torch.equal(z2[:body, :N], z[:body, :N]), "the stream must not depend on whether the partials are requested"
-    close_f32(z2[:, :N], z[:, :N], "peeled tail rows vs tile-kernel rows", rel=3e-5)
+    assert torch.equal(z2[:, :N], z[:, :N]), "the stream must not depend on whether the partials are requested"
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 2048, 2048), (64, 2048, 11008), (21, 704, 512), (128, 3584, 3584)])
