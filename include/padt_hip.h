@@ -51,14 +51,9 @@ int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const void* W, lo
 /* fp32 RESIDUAL STREAM: X32[M,N] (fp32, in place) += A[M,K] · W[N,K]^T + bias, and Xb = bf16(X32) (row-major mirror, ldxb % 8 == 0; may be
  * null).  The residual adds of a ViT block (HF:318-320: x + attn.proj(..), x + mlp.down_proj(..)) and of an LLM layer at prompt length
  * (HF:741,757) with the stream carried in fp32 between kernels — what the reference's fp32 CPU path does — while the same epilogue emits the
- * bf16 A operand of the next projection.  Every tile kernel of padt_gemm_bf16 serves it.
- * ssq_partials (optional, fp32 [ceil(N / 64)][ld_ssq], ld_ssq >= M): the epilogue also leaves per-row partial sums of squares of the NEW stream
- * values, one per 64-column block — padt_rstd_from_partials turns them into the next folded RMSNorm's rstd without another pass over the stream
- * (HF:74-79 statistics of the value HF:318-320 / 741,757 just produced). */
+ * bf16 A operand of the next projection.  Every tile kernel of padt_gemm_bf16 serves it. */
 int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx, void* Xb,
-                      long ldxb, long M, long N, long K, void* ssq_partials, long ld_ssq);
-/* rstd[m] = rsqrt(sum_q ssq_partials[q][m] / D + eps), q < ceil(D / 64), summed in index order. */
-int padt_rstd_from_partials(void* stream, const void* ssq_partials, long ld_ssq, long D, void* rstd_f32, long rows, float eps);
+                      long ldxb, long M, long N, long K);
 /* Dispatch knobs of the 256-row tile kernel (tests force every tile variant; tools A/B them): mode256 0 off / 1 auto / 2 forced,
  * mf 0 auto / 2..4 tile height in 64-row units, peel 0 never / 1 cost model / 2 always, colsplit 0 never / 1 cost model / n columns,
  * group_m rasterisation patch height.  -1 keeps a field.  The defaults are read once from PADT_GEMM256 / PADT_GEMM_MF / PADT_GEMM_PEEL /

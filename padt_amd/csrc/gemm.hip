@@ -525,7 +525,7 @@ extern "C" void padt_set_error(const char* msg);
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
-                                void* C2, long ldc2, unsigned long long* prof, float* ssq, long ld_ssq);
+                                void* C2, long ldc2, unsigned long long* prof);
 
 // Measurement surface: while a slot array is registered, every tile-GEMM call (M > 64) of this process takes the next {start, end} slot
 // (host-side counter) and its kernels record their first block start / last block end in 100 MHz ticks.  The caller initialises the slots
@@ -605,34 +605,14 @@ static void dispatch_norm(const GemmArgs& a, float eps, hipStream_t s) {
     else launch_skinny<4, EPI, false, true>(a, eps, s);
 }
 
-// Fallback producer of the Σx² partials for shapes the 256-row kernel does not take (small models, ragged column tiles): partial 0 = the whole
-// row's sum of squares of the updated fp32 stream, partials 1 .. N/64-1 = 0 — the consumer (padt_rstd_from_partials) sums them either way.
-__global__ __launch_bounds__(256) void row_ssq_f32_kernel(const float* __restrict__ x, long ldx, float* __restrict__ ssq, long ld_ssq, int rows, int N, int P) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
-    if (row >= rows) return;
-    const float* xr = x + (long)row * ldx;
-    float s = 0.f;
-    for (int c = lane; c < N; c += 64) s = __builtin_fmaf(xr[c], xr[c], s);
-    s = wave_sum(s);
-    for (int q = lane; q < P; q += 64) ssq[(long)q * ld_ssq + row] = q == 0 ? s : 0.f;
-}
-static void launch_row_ssq(hipStream_t s, const float* x, long ldx, float* ssq, long ld_ssq, long rows, long N) {
-    hipLaunchKernelGGL(row_ssq_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, s, x, ldx, ssq, ld_ssq, (int)rows, (int)N, (int)((N + 63) / 64));
-}
-
 static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                           long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
-                          const void* row_scale, const RopeEpi& rope, int resid_f32 = 0, long lo_off = 0, void* C2 = nullptr, long ldc2 = 0,
-                          float* ssq = nullptr, long ld_ssq = 0) {
+                          const void* row_scale, const RopeEpi& rope, int resid_f32 = 0, long lo_off = 0, void* C2 = nullptr, long ldc2 = 0) {
     if (M <= 0 || N <= 0) return 0;
-    void* const C0 = C;                                           // (the peeling below advances C / M)
-    const long M0 = M;
     if (K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
         padt_set_error("padt_gemm_bf16: K, lda, ldw must be multiples of 8 and A, W 16-byte aligned");
         return -1;
     }
-    if (ssq && (!resid_f32 || ld_ssq < M)) { padt_set_error("padt_gemm_resid32: Σx² partials need the fp32 stream epilogue and ld_ssq >= M"); return -1; }
     const long out_n = (epilogue == EPI_SWIGLU) ? N / 2 : N;
     if ((ldc & 3) || ((uintptr_t)C & 15) || (epilogue == EPI_SWIGLU && ((N & 31) || out_f32)) ||
         (epilogue == EPI_RESID && (R == nullptr || (ldr & 3) || ((uintptr_t)R & 7))) || ((uintptr_t)bias & 7) || ldc < out_n) {
@@ -656,10 +636,7 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         return -1;
     }
     unsigned long long* prof = (M > 64) ? next_prof_slot() : nullptr;
-    const bool ssq_fast = ssq != nullptr && (N & 255) == 0;       // the 256-row kernel's fast epilogue writes the partials (no ragged column tile)
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof,
-                                   ssq_fast ? ssq : nullptr, ld_ssq) == 0) {
-        if (ssq && !ssq_fast) launch_row_ssq((hipStream_t)stream, (const float*)C, ldc, ssq, ld_ssq, M, N);
+    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -694,7 +671,6 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         case 6: dispatch_m<EPI_SWIGLU, false>(a, s); break;
         default: padt_set_error("padt_gemm_bf16: unsupported epilogue/out combination"); return -1;
     }
-    if (ssq) launch_row_ssq(s, (const float*)C0, ldc, ssq, ld_ssq, M0, N);   // shapes the 256-row kernel does not take: statistics from the updated stream
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;
@@ -721,28 +697,9 @@ extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const vo
 // adds of the ViT block (HF:318-320) and the LLM layer (HF:741,757) with the stream kept in fp32 between kernels and the next projection's
 // bf16 A operand produced by the same epilogue.
 extern "C" int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx,
-                                 void* Xb, long ldxb, long M, long N, long K, void* ssq_partials, long ld_ssq) {
+                                 void* Xb, long ldxb, long M, long N, long K) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, X32, ldx, X32, ldx, M, N, K, EPI_RESID, 1, nullptr,
-                          RopeEpi{nullptr, nullptr, 0, 0, 0}, 1, 0, Xb, ldxb, (float*)ssq_partials, ld_ssq);
-}
-
-// rstd[m] = rsqrt(Σ_q ssq[q][m] / D + eps) over the P = ceil(D / 64) partials padt_gemm_resid32 left: the statistics half of the NEXT folded RMSNorm
-// (row_scale of the qkv / gate-up GEMM) without another pass over the stream.  Partials are summed in index order (deterministic).
-__global__ __launch_bounds__(256) void rstd_from_partials_kernel(const float* __restrict__ ssq, long ld, int P, float* __restrict__ out, int rows, float inv_d, float eps) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
-    if (m >= rows) return;
-    float s = 0.f;
-    for (int q = 0; q < P; ++q) s += ssq[(long)q * ld + m];
-    out[m] = rsqrtf(s * inv_d + eps);
-}
-extern "C" int padt_rstd_from_partials(void* stream, const void* ssq_partials, long ld_ssq, long D, void* rstd_f32, long rows, float eps) {
-    if (rows <= 0) return 0;
-    if (D <= 0 || ld_ssq < rows) { padt_set_error("padt_rstd_from_partials: D > 0 and ld_ssq >= rows required"); return -1; }
-    hipLaunchKernelGGL(rstd_from_partials_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (const float*)ssq_partials, ld_ssq,
-                       (int)((D + 63) / 64), (float*)rstd_f32, (int)rows, 1.0f / (float)D, eps);
-    hipError_t e = hipGetLastError();
-    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
-    return 0;
+                          RopeEpi{nullptr, nullptr, 0, 0, 0}, 1, 0, Xb, ldxb);
 }
 
 // C = rope(row_scale[m] * (A · W^T) + bias): the rotate-half RoPE of the leading `rope_cols` output columns fused into the

@@ -36,8 +36,7 @@ struct Gemm256Args {
     bf16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
     unsigned long long* prof;       // optional {first block start, last block end} in 100 MHz wall-clock ticks (padt_gemm_profile)
     const float* cs;                // optional per-output-column scale of the accumulator (fp8 weights: dequantisation scale of weight row n)
-    float* ssq; long ld_ssq; int ssq_col0;   // optional (fp32 stream epilogue): per-row partial sums of squares of the NEW stream values, one per 64-column
-};                                  //   block: ssq[(ssq_col0 + (n0 >> 6) + wc) * ld_ssq + m] — the next RMSNorm's statistics without re-reading the stream
+};
 
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
 
@@ -322,7 +321,6 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
                     }
                 } else {
-                    float sq = 0.f;                               // Σ of this lane's 16 new stream values squared (RF32 only)
 #pragma unroll
                     for (int ni = 0; ni < 4; ++ni) {
                         float o[4];
@@ -349,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         }
                         if (EPI == EPI_RESID && RF32) {
 #pragma unroll
-                            for (int r = 0; r < 4; ++r) { o[r] += rr32[RF32 ? b : 0][ni][r]; sq = __builtin_fmaf(o[r], o[r], sq); }
+                            for (int r = 0; r < 4; ++r) o[r] += rr32[RF32 ? b : 0][ni][r];
                         }
                         const long off = (long)m * p.ldc + nb + ni * 16;
                         if (OUT_F32) {
@@ -369,11 +367,6 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                                 *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2bf(o[0] - hv[0], o[1] - hv[1]), pack2bf(o[2] - hv[2], o[3] - hv[3])};
                             }
                         }
-                    }
-                    if (EPI == EPI_RESID && RF32 && p.ssq != nullptr) {   // wave-uniform branch: 64-column partial of row m (fixed order: deterministic)
-                        sq += __shfl_xor(sq, 16, 64);
-                        sq += __shfl_xor(sq, 32, 64);
-                        if (fq == 0 && live) p.ssq[(long)(p.ssq_col0 + (n0 >> 6) + wc) * p.ld_ssq + m] = sq;
                     }
                 }
             }
@@ -543,8 +536,8 @@ static void run256(Gemm256Args a, int mf, hipStream_t s) {
 template <int EPI, bool F32>
 static long launch256(Gemm256Args a, hipStream_t s) {
     const int force = g_knobs.mf;
-    const bool allow_peel = g_knobs.peel != 0 && a.ssq == nullptr;   // 0 never, 1 cost model (default), 2 always when a tail exists (tests); the Σx² partials
-    const bool force_peel = g_knobs.peel == 2 && a.ssq == nullptr;   //   come from this kernel's epilogue only: no rows are handed to the skinny kernel
+    const bool allow_peel = g_knobs.peel != 0;                    // 0 never, 1 cost model (default), 2 always when a tail exists (tests)
+    const bool force_peel = g_knobs.peel == 2;
     const int colsplit = g_knobs.colsplit;                        // 0 never, 1 cost model (default), >= 2: always peel that many tile columns (tests)
     const long ntn = (a.N + TN - 1) / TN;
     const Plan256 whole = plan256(a.M, a.N, a.K, force, allow_peel, force_peel);
@@ -575,7 +568,6 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((bf16_t*)a.C + c1);
     if (a.R) a2.R = a.r_f32 ? (const bf16_t*)((const float*)a.R + c1) : a.R + c1;
     if (a.C2) a2.C2 = a.C2 + c1;
-    a2.ssq_col0 = a.ssq_col0 + (int)(n1 >> 6);
     run256<EPI, F32>(a1, pm.mf, s);
     run256<EPI, F32>(a2, pr.mf, s);
     return a.M;
@@ -587,7 +579,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
-                                void* C2, long ldc2, unsigned long long* prof, float* ssq, long ld_ssq) {
+                                void* C2, long ldc2, unsigned long long* prof) {
     const int mode = g_knobs.mode;                                // 0 off, 1 auto, 2 force
     if (mode == 0) return 1;
     if (mode == 1) {
@@ -599,7 +591,7 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     const int group_m = g_knobs.group_m;
     Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof, nullptr, ssq, ld_ssq, 0};
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;
@@ -640,7 +632,7 @@ extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const 
     RopeEpi norope{nullptr, nullptr, 0, 0, 0};
     const Plan256 pl = plan256(M, N, K / 2, g_knobs.mf, false, false);      // cost model in K-tiles: a 128-element fp8 K-tile costs what 64 bf16 elements do
     Gemm256Args a{(const bf16_t*)A8, lda, (const bf16_t*)W8, ldw, (const bf16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K,
-                  (const float*)row_scale, norope, g_knobs.group_m < 1 ? 1 : g_knobs.group_m, 0, 0, nullptr, 0, prof, (const float*)col_scale, nullptr, 0, 0};
+                  (const float*)row_scale, norope, g_knobs.group_m < 1 ? 1 : g_knobs.group_m, 0, 0, nullptr, 0, prof, (const float*)col_scale};
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_NONE) {
         if (C == nullptr || (ldc & 7) || ((uintptr_t)C & 15) || ldc < N) { padt_set_error("padt_gemm_fp8: bf16 C with ldc % 8 == 0, ldc >= N required"); return -1; }

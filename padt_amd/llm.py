@@ -331,10 +331,6 @@ class LanguageModel:
         att = torch.empty((T, Hq * hd), device=dev, dtype=bf)
         h = torch.empty((T, W.llm_ipad), device=dev, dtype=bf)
         mx = max(plan.lens)
-        D = cfg.hidden_size
-        # row statistics of the stream come from the residual GEMMs' epilogues (fp32 streams): one row_rstd pass in front of layer 0 only
-        ssq = torch.empty(((D + 63) // 64, T), device=dev, dtype=torch.float32) if x32 is not None else None
-        have_rstd = False
         f8 = W.fp8_prefill and x32 is not None
         if f8:                                                       # e4m3 images of the three GEMM inputs of a layer + their row scales
             x8 = torch.empty((T, cfg.hidden_size), device=dev, dtype=torch.uint8)
@@ -349,41 +345,29 @@ class LanguageModel:
                 ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
                 ops.gemm_fp8(x8, W[p + "qkv.w8"], W[p + "qkv.ws"], rs8, bias=W[p + "qkv.b"], out=qkv)
             else:
-                if not have_rstd:
-                    ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)        # norm weight is folded into qkv.w
+                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into qkv.w
                 ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
-            have_rstd = False                                              # (statistics are consumed exactly once)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
             if f8 and (p + "o.w8") in W:
                 ops.quant_rows_fp8(att, out=a8, rs=rs8)
                 ops.gemm_fp8(a8, W[p + "o.w8"], W[p + "o.ws"], rs8, epilogue=ops.EPI_RESID, x32=x32, xb=x)
-                have_rstd = False
             elif x32 is not None:
-                ops.gemm_resid32(att, W[p + "o.w"], None, x32, x, ssq=ssq)
-                have_rstd = True
+                ops.gemm_resid32(att, W[p + "o.w"], None, x32, x)
             else:
                 ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
             if f8 and (p + "gu.w8") in W:
                 ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
                 ops.gemm_fp8(x8, W[p + "gu.w8"], W[p + "gu.ws"], rs8, out=h, epilogue=ops.EPI_SWIGLU)
-                have_rstd = False
             else:
-                if have_rstd:
-                    ops.rstd_from_partials(ssq, D, T, eps=cfg.rms_norm_eps, out=rstd)   # post-attention norm statistics, from the o-proj epilogue
-                else:
-                    ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)        # norm weight is folded into gu.w
-                have_rstd = False
+                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into gu.w
                 ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
             if f8 and (p + "down.w8") in W:
                 ops.quant_rows_fp8(h, out=h8, rs=rs8)
                 ops.gemm_fp8(h8, W[p + "down.w8"], W[p + "down.ws"], rs8, epilogue=ops.EPI_RESID, x32=x32, xb=x)
-                have_rstd = False
             elif x32 is not None:
-                ops.gemm_resid32(h, W[p + "down.w"], None, x32, x, ssq=ssq)
-                ops.rstd_from_partials(ssq, D, T, eps=cfg.rms_norm_eps, out=rstd)       # the next layer's input-norm statistics
-                have_rstd = True
+                ops.gemm_resid32(h, W[p + "down.w"], None, x32, x)
             else:
                 ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
         if x32 is not None:

@@ -144,9 +144,8 @@ def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=Fa
     return out
 
 
-def gemm_resid32(a, w, bias, x32, xb=None, ssq=None):
-    """fp32 residual stream: x32[M,N] += a @ w^T + bias (in place); xb = bf16(x32) is the next projection's A operand.
-    ssq: optional fp32 (ceil(N/64), >= M) buffer → per-row partial sums of squares of the new stream values (rstd_from_partials)."""
+def gemm_resid32(a, w, bias, x32, xb=None):
+    """fp32 residual stream: x32[M,N] += a @ w^T + bias (in place); xb = bf16(x32) is the next projection's A operand."""
     lib = _lib.load()
     _chk_bf16(a, w, bias, xb)
     M, K = a.shape
@@ -154,21 +153,10 @@ def gemm_resid32(a, w, bias, x32, xb=None, ssq=None):
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and x32.shape[0] >= M and x32.shape[1] >= N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("r32", a, w, bias, x32, xb))
-    if ssq is not None:
-        assert ssq.dtype == torch.float32 and ssq.dim() == 2 and ssq.stride(1) == 1 and ssq.shape[0] >= (N + 63) // 64 and ssq.stride(0) >= M
     _tg_note("r32", M, N, K)
     _lib.check(lib.padt_gemm_resid32(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
-                                     xb.stride(0) if xb is not None else 0, M, N, K, _p(ssq), ssq.stride(0) if ssq is not None else 0),
-               "padt_gemm_resid32")
+                                     xb.stride(0) if xb is not None else 0, M, N, K), "padt_gemm_resid32")
     return x32
-
-
-def rstd_from_partials(ssq, D, rows, eps=1e-6, out=None):
-    """rstd[m] = rsqrt(sum of the ceil(D/64) partials gemm_resid32 left / D + eps): the next folded RMSNorm's row_scale."""
-    if out is None:
-        out = torch.empty((rows,), device=ssq.device, dtype=torch.float32)
-    _lib.check(_lib.load().padt_rstd_from_partials(_stream(), _p(ssq), ssq.stride(0), int(D), _p(out), int(rows), float(eps)), "padt_rstd_from_partials")
-    return out
 
 
 def quant_rows_fp8(x, norm_eps=None, out=None, rs=None):

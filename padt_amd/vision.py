@@ -92,13 +92,11 @@ class VisionEncoder:
             torch.cuda.current_stream().synchronize()        # tables are shared by every stream that runs this grid later
         return self._plans[key]
 
-    def block(self, i: int, x, plan: VisionPlan, rstd, qkv, att, hbuf, force_full=None, x32=None, ssq=None, have_rstd=False):
+    def block(self, i: int, x, plan: VisionPlan, rstd, qkv, att, hbuf, force_full=None, x32=None):
         """One ViT block in place on x (P, vh): x += proj(attn(rope(qkv(RMSNorm(x))))); x += down(SwiGLU(RMSNorm(x)))
         (HF:297-321).  Window segments except for the full-attention layers (padt.py:89-93).
         x32 given: the residual stream is the fp32 tensor x32, updated in place by the residual GEMMs' epilogues, and x is its bf16
-        mirror (the A operand of the qkv / gate-up GEMMs), rewritten by the same epilogues.  With `ssq` (fp32 (vh/64, P) scratch) those
-        epilogues also leave the row statistics of the value they wrote, so the only row_rstd pass of the stack is the one in front of block 0
-        (have_rstd: `rstd` already holds norm1's statistics of x — left by the previous block's down projection)."""
+        mirror (the A operand of the qkv / gate-up GEMMs), rewritten by the same epilogues."""
         cfg, W = self.cfg, self.W
         v = cfg.vision_config
         vh, H = v.hidden_size, v.num_heads
@@ -106,8 +104,7 @@ class VisionEncoder:
         p = f"vit.{i}."
         full = (i in v.fullatt_block_indexes) if force_full is None else force_full
         cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
-        if not have_rstd:
-            ops.row_rstd(x, out=rstd)                                      # RMSNorm = rstd x (weight folded into qkv.w)
+        ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
         # qkv projection with the rotary embedding applied in its epilogue (q / k columns are pair-interleaved per head by
         # prepare_weights): no separate pass over q and k
         if W.vit_rope_fused:
@@ -116,22 +113,16 @@ class VisionEncoder:
             ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.rope_half_(qkv, plan.cos, plan.sin, 2 * H, hd)
         ops.attn_varlen(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:], att, cu, cu, mx, H, H, hd)
-        P = x.shape[0]
         if x32 is not None:
-            ops.gemm_resid32(att, W[p + "proj.w"], W[p + "proj.b"], x32, x, ssq=ssq)
+            ops.gemm_resid32(att, W[p + "proj.w"], W[p + "proj.b"], x32, x)
         else:
             ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
-        if ssq is not None:
-            ops.rstd_from_partials(ssq, vh, P, out=rstd)                   # norm2's statistics, from the proj epilogue
-        else:
-            ops.row_rstd(x, out=rstd)
+        ops.row_rstd(x, out=rstd)
         ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
         if x32 is not None:
-            ops.gemm_resid32(hbuf, W[p + "down.w"], W[p + "down.b"], x32, x, ssq=ssq)
+            ops.gemm_resid32(hbuf, W[p + "down.w"], W[p + "down.b"], x32, x)
         else:
             ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
-        if ssq is not None:
-            ops.rstd_from_partials(ssq, vh, P, out=rstd)                   # the NEXT block's norm1 statistics, from the down epilogue
 
     def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):
         """pixel_values (P, C*T*p*p) fp32 or bf16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
@@ -156,9 +147,8 @@ class VisionEncoder:
         qkv = torch.empty((P, 3 * vh), device=x.device, dtype=x.dtype)
         att = torch.empty_like(x)
         hbuf = torch.empty((P, W.vit_ipad), device=x.device, dtype=x.dtype)
-        ssq = torch.empty(((vh + 63) // 64, P), device=x.device, dtype=torch.float32) if f32 else None
         for i in range(v.depth):
-            self.block(i, x, plan, rstd, qkv, att, hbuf, x32=x32, ssq=ssq, have_rstd=(ssq is not None and i > 0))
+            self.block(i, x, plan, rstd, qkv, att, hbuf, x32=x32)
         high = x32 if f32 else x                                               # the PaDT decoder reads fp32 or bf16 rows
         if f32:
             ops.rmsnorm_f32(x32, W["vit.merger.ln_q"], out=n)

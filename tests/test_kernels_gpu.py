@@ -943,21 +943,6 @@ def test_gemm_resid32_stream_and_mirror(ops, M, N, K, knobs):
     y = x32.clone()
     ops.gemm_resid32(a, w, None, y[:, :N], None)                       # no mirror, no bias
     close_f32(y[:, :N], x32[:, :N] + a.float() @ w.float().T, "resid32 without mirror", rel=3e-5)
-    # row statistics of the value just written, from the same epilogue (256-row kernel: one partial per 64 columns; other kernels: fallback)
-    P = (N + 63) // 64
-    ssq = torch.full((P, M + 8), 123.0, device="cuda")
-    z = x32.clone()
-    ops.gemm_resid32(a, w, b, z[:, :N], xb[:, :N], ssq=ssq)
-    tot = ssq[:, :M].sum(0)
-    ref_ss = z[:, :N].double().pow(2).sum(-1).float()
-    assert ((tot - ref_ss).abs() <= 2e-5 * ref_ss + 1e-6).all(), f"Σx² partials {M}x{N}x{K}: worst rel {((tot - ref_ss).abs() / ref_ss).max().item():.2e}"
-    assert (ssq[:, M:] == 123.0).all(), "partials written past row M"
-    rstd = ops.rstd_from_partials(ssq, N, M, eps=1e-6)
-    ref_rstd = torch.rsqrt(z[:, :N].pow(2).mean(-1) + 1e-6)
-    assert ((rstd - ref_rstd).abs() <= 3e-6 * ref_rstd).all()
-    z2 = x32.clone()
-    ops.gemm_resid32(a, w, b, z2[:, :N], None)
-    assert torch.equal(z2[:, :N], z[:, :N]), "the stream must not depend on whether the partials are requested"
 
 
 @pytest.mark.parametrize("M,N,K", [(8, 2048, 2048), (64, 2048, 11008), (21, 704, 512), (128, 3584, 3584)])
