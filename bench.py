@@ -72,8 +72,9 @@ def parse_args():
     ap.add_argument("--cap", type=int, default=0, help="object capacity of the per-batch result record (default: 2 x the scheduled objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
-    ap.add_argument("--merge", type=int, default=8, help="consecutive batches of 8 whose decode steps share one session "
-                    "(in-flight batching; 1 = every batch decodes alone)")
+    ap.add_argument("--merge", type=int, default=0, help="consecutive batches of 8 whose decode steps share one session (in-flight batching; "
+                    "1 = every batch decodes alone); default 8 for REC (28 new tokens), 16 for the decode-heavy OVD / RIC shapes (120 / 150 new tokens: "
+                    "128-row steps cost 24 %% less per image; same-call OVD 66.1 → 69.3 images/s)")
     ap.add_argument("--no-graph", action="store_true", help="sequential mode only: launch decode steps eagerly (profiling aid)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
     ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
@@ -87,6 +88,8 @@ def parse_args():
     a = ap.parse_args()
     if a.model != "3b" or a.task != "rec" or a.weights != "bf16":
         a.extras = False                                               # the extra keys belong to the headline line only
+    if a.merge <= 0:
+        a.merge = 8 if a.task == "rec" else 16
     return a
 
 
@@ -432,6 +435,7 @@ def extra_workloads(args, device, model3b, cfg3b, grid3b):
         for k, v in over.items():
             setattr(a, k, v)
         a.cap = 0
+        a.merge = 16                                                   # decode-heavy shapes: 128-row decode steps (see --merge)
         if key == "ovd_3b":
             cfg, model, grid_hw = cfg3b, model3b, grid3b
             model3b = None
