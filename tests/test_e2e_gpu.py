@@ -192,6 +192,35 @@ def test_pipelined_runner_matches_sequential(setup, depth, merge):
         assert torch.equal(d0["pred_score"], d1["pred_score"])
 
 
+def test_pipelined_runner_128_row_decode_groups(setup):
+    """Decode groups of 16 batches of 8 (128-row decode steps: what bench.py runs for the decode-heavy OVD / RIC shapes) — 18 batches, so one
+    full group and a partially filled one — bit-identical to one rec_batch call per batch."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    T = 12
+    sched = U.rec_schedule(T, vrt_at=range(4, 8))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = []
+    for s_ in range(18):
+        g = [[1, 8, 8] if (s_ + i) % 3 else [1, 6, 10] for i in range(8)]
+        grid, pix, ids, am = U.synthetic_batch(cfg, g, n_pre=5 + s_ % 2, n_post=7, seed=300 + s_, ragged=True)
+        batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=16)
+    got = []
+    for b in batches:
+        got += runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+    got += runner.flush()
+    assert len(got) == len(batches)
+    for i in (0, 7, 15, 16, 17):
+        b = batches[i]
+        d0, c0, l0, v0 = pipeline.rec_batch(model, proc, b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+        d1, c1, l1, v1 = got[i]
+        assert c0 == c1 and v0 == v1, f"batch {i}: tokens differ in a 128-row decode group"
+        assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"]) and torch.equal(d0["pred_score"], d1["pred_score"])
+
+
 @pytest.mark.parametrize("variant", ["untied_head_gqa2_multi_object", "no_prototype_projection_no_mask_head"])
 def test_generate_config_variants(variant):
     """The other configurations the reference ships (BASELINE.json configs 3-5): untied lm_head + a GQA group of 2 with an
