@@ -442,7 +442,7 @@ def extra_workloads(args, device, model3b, cfg3b, grid3b):
         else:
             cfg, model, grid_hw = build_model(a, device)
         inp = make_inputs(cfg, a, grid_hw, device, seed=4321)
-        steps = 16
+        steps = 48                                                     # three decode groups of 16 batches after the priming pass
         r = short_run(model, inp, a, steps)
         alg = alg_tflop_per_image(cfg, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
         r.update({"workload": "%s %s, batch=%d/GPU, L=%d, T_new=%d, %d obj x %d VRT per image, %s LLM weights%s" % (
