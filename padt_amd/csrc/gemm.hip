@@ -510,7 +510,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             for (int i = 0; i < NT; ++i) sum[q][i] *= rstd;
         }
         if (EPI == EPI_SWIGLU) {
-            store_swiglu(p, m, n0 + fq * 4, sum[q][0], sum[q][NT - 1]);
+#pragma unroll
+            for (int i = 0; i < NT; i += 2) store_swiglu(p, m, n0 + i * 16 + fq * 4, sum[q][i], sum[q][i + 1]);
         } else {
 #pragma unroll
             for (int i = 0; i < NT; ++i) store_frag<EPI, OUT_F32>(p, m, n0 + i * 16 + fq * 4, sum[q][i]);
@@ -560,9 +561,8 @@ static void launch_tile(const GemmArgs& a, hipStream_t s) {
     else launch_tile_bk<EPI, F32, 64>(a, s);
 }
 
-template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false, int WQ = 0>
-static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
-    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+template <int MT, int NT, int NW, int EPI, bool F32, bool NORM, bool PACKED, int WQ>
+static void launch_skinny_nt(const GemmArgs& a, float eps, hipStream_t s) {
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int split = (a.ws && !NORM) ? a.split : 1;
     constexpr int lds = NW * NT * MT * 64 * 16 + NW * MT * 16 * 4;      // red + ssq (gemm_skinny_kernel)
@@ -572,6 +572,27 @@ static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
                                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
     }
     hipLaunchKernelGGL((gemm_skinny_kernel<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>), dim3(nb, split), dim3(NW * 64), lds, s, a, eps);
+}
+
+// Wide row blocks at 64 decode rows (round 3).  A wave loads MT = 4 activation fragments (L2 hits) per weight fragment there, and that
+// L2 → register traffic — 176 MB next to 90 MB of gate/up weights — not the weight stream, sets the launch time
+// (profiles/r03_decode_experiments.md §3).  Twice the weight fragments per wave and K-step (NT = 4: two gate/up pairs) halve the activation
+// loads per weight byte IN REGISTERS, the only sharing that removes load instructions: gate/up 26.4 → 24.0 us.  NT changes neither the
+// K-step → wave map nor the cross-wave summation order, so every output bit is the narrow launch's (NW comes from the narrow block count).
+// Taken only where the halved grid still covers the chip (>= 256 blocks); measured and NOT taken: 128 rows (NT x MT = 32 accumulator
+// fragments: one wave per SIMD, 42.5 → 47.7 us), qkv / o (80 / 64 blocks left: 8.9 → 10.5, 7.6 → 10.9 us), 4 K-step pairs in flight (24.9 us);
+// down with twice the split: 20.3 → 19.7 us, not worth a different split at 8 rows.  PADT_SKINNY_WIDE=0 is the A/B switch.
+template <int MT, int NW, int EPI, bool F32, bool NORM, bool PACKED = false, int WQ = 0>
+static void launch_skinny_nw(const GemmArgs& a, float eps, hipStream_t s) {
+    constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
+    if constexpr (PACKED && MT == 4 && EPI == EPI_SWIGLU && NW == 4) {
+        static const int wide = getenv("PADT_SKINNY_WIDE") ? atoi(getenv("PADT_SKINNY_WIDE")) : 1;
+        if (wide && a.N % (32 * NT) == 0 && a.N / (32 * NT) >= 256) {
+            launch_skinny_nt<MT, 2 * NT, NW, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
+            return;
+        }
+    }
+    launch_skinny_nt<MT, NT, NW, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
 }
 
 // waves per block: enough waves chip-wide (>= ~2048) to keep HBM busy even when N/16 < #CUs

@@ -44,11 +44,17 @@ def timeit_graph(fn, n):
 
 def main():
     B = int(os.environ.get("B", 8))
-    x = torch.randn(B, 2048, device="cuda").to(BF)
-    h = torch.randn(B, 11008, device="cuda").to(BF)
+    g7 = os.environ.get("GEOM") == "7b"                            # PaDT_Pro_7B projections (default: 3B); FP8=1: the fp8 weight images
+    fp8 = bool(os.environ.get("FP8"))
+    D, I, QKV = (3584, 18944, 4608) if g7 else (2048, 11008, 2560)
+    x = torch.randn(B, D, device="cuda").to(BF)
+    h = torch.randn(B, I, device="cuda").to(BF)
     res = {}
-    for name, N, K, epi, a in (("qkv", 2560, 2048, 0, x), ("o", 2048, 2048, 2, x), ("gu", 22016, 2048, 3, x), ("down", 2048, 11008, 2, h)):
+    for name, N, K, epi, a in (("qkv", QKV, D, 0, x), ("o", D, D, 2, x), ("gu", 2 * I, D, 3, x), ("down", D, I, 2, h)):
         ws = [torch.randn(N, K, device="cuda").to(BF) * 0.02 for _ in range(int(os.environ.get('ROT', 6)))]   # rotate weights: defeat L2/MALL reuse
+        if fp8:                                                   # timing only: random bytes stand in for the e4m3 image
+            ws = [torch.randint(0, 120, (N, (K + 63) // 64 * 64), device="cuda", dtype=torch.uint8) for _ in ws]
+            sc = torch.ones(N, device="cuda")
         out = torch.zeros(B, N // 2 if epi == 3 else N, device="cuda", dtype=BF)
         i = [0]
         B16 = (B + 15) // 16 * 16
@@ -66,6 +72,13 @@ def main():
                     ops.gemm(a, w, out=out, epilogue=2, residual=out)
                 else:
                     ops.gemm_rmsnorm(a, w, out=out, epilogue=epi)
+            elif fp8:
+                if epi == 2:
+                    ops.gemm_packed_fp8(a_pk, w, sc, N, out=out_pk, epilogue=2, residual=out_pk, split_k=split, workspace=ws_split,
+                                        a_packed=True, c_packed=True, rows=B)
+                else:
+                    ops.gemm_packed_fp8(a_pk, w, sc, N, out=out_pk if epi == 3 else out, epilogue=epi, norm_eps=1e-6, a_packed=True,
+                                        c_packed=(epi == 3), rows=B)
             elif os.environ.get("PACK"):                          # fragment-packed activations, as the decode step runs them
                 if epi == 2:
                     ops.gemm_packed(a_pk, w, N, out=out_pk, epilogue=2, residual=out_pk, split_k=split, workspace=ws_split,
@@ -78,8 +91,10 @@ def main():
             else:
                 ops.gemm_packed(a, w, N, out=out, epilogue=epi, norm_eps=1e-6)
         t = timeit(f)
-        mb = N * K * 2 / 1e6
+        mb = N * K * (1 if fp8 else 2) / 1e6
         print(f"{name:5s} N={N:6d} K={K:6d}: {t:7.2f} us  {mb / t * 1e-3 * 1e3:8.1f} GB/s ({mb:.1f} MB)")
+    if os.environ.get("GEMMS_ONLY"):
+        return
     # decode attention (rope + append + split attention + merge), Pro_3B heads, ~600 cached tokens
     Hq, Hkv, D, S_max = 16, 2, 128, 640
     qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device="cuda").to(BF)
