@@ -272,7 +272,10 @@ class DecodeSession:
             self.step_kernels()                              # real step; also pays every one-time kernel attribute call
             n -= 1
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
+            # thread_local: only THIS thread's calls are checked during capture.  With world > 1 the process group's watchdog thread polls
+            # the events of an in-flight result gather (pipeline.ResultExchange) while a later lane captures its graph; under the default
+            # global mode such a query from another thread invalidates the capture.
+            with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.step_kernels()
             self.graphs[self.do_sample] = g
         t = ops.STEP_TIMER
