@@ -20,6 +20,8 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work: the host driver only supports dmabuf IPC (RCCL needs it)
+
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
