@@ -367,7 +367,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = j * 16 + frow;
-        xok[j] = p.a_pack ? true : (m < p.M);
+        xok[j] = p.a_pack ? (j * 16 < p.M) : (m < p.M);          // packed: a row block past the last valid row is not in the buffer (M = 96 → 6 of MT = 8)
         xrow[j] = p.a_pack ? p.A + (long)j * 16 * p.lda + lane * 8 : p.A + (long)(xok[j] ? m : 0) * p.lda + fq * 8;
     }
 

@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = j * 16 + frow;
-        xok[j] = PACKED ? true : (m < p.B);
+        xok[j] = PACKED ? (j * 16 < p.B) : (m < p.B);             // packed: row blocks past the last valid row are not in the buffer
         xrow[j] = PACKED ? p.h + (long)j * 16 * p.ldh + lane * 8 : p.h + (long)(m < p.B ? m : 0) * p.ldh + fq * 8;
     }
     const int xstep = PACKED ? 512 : 32;

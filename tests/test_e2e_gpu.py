@@ -221,6 +221,38 @@ def test_pipelined_runner_128_row_decode_groups(setup):
         assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"]) and torch.equal(d0["pred_score"], d1["pred_score"])
 
 
+@pytest.mark.parametrize("merge", [5, 12])
+def test_pipelined_runner_group_sizes_that_do_not_fill_the_row_blocks(setup, merge):
+    """Decode groups of 5 / 12 batches of 8: 40- / 96-row steps, i.e. 3 of 4 / 6 of 8 sixteen-row blocks of the decode kernels' launch shape.
+    The fragment-packed activation buffers hold exactly ceil(rows / 16) blocks; the kernels must not touch the blocks past them (a 96-row
+    step of PaDT_Pro_3B read 2 x 16 rows x 11008 past the end of the MLP activation buffer and faulted before the guard in gemm_skinny_kernel /
+    vrt_head_kernel).  Bit-identical to one rec_batch call per batch."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    T = 10
+    sched = U.rec_schedule(T, vrt_at=range(3, 7))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = []
+    for s_ in range(merge + 2):
+        g = [[1, 8, 8] if (s_ + i) % 3 else [1, 6, 10] for i in range(8)]
+        grid, pix, ids, am = U.synthetic_batch(cfg, g, n_pre=5 + s_ % 2, n_post=7, seed=900 + s_, ragged=True)
+        batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=merge)
+    got = []
+    for b in batches:
+        got += runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+    got += runner.flush()
+    assert len(got) == len(batches)
+    for i in (0, merge - 1, merge, merge + 1):
+        b = batches[i]
+        d0, c0, l0, v0 = pipeline.rec_batch(model, proc, b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+        d1, c1, l1, v1 = got[i]
+        assert c0 == c1 and v0 == v1, f"batch {i}: tokens differ in a decode group of {merge} batches"
+        assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"]) and torch.equal(d0["pred_score"], d1["pred_score"])
+
+
 @pytest.mark.parametrize("variant", ["untied_head_gqa2_multi_object", "no_prototype_projection_no_mask_head"])
 def test_generate_config_variants(variant):
     """The other configurations the reference ships (BASELINE.json configs 3-5): untied lm_head + a GQA group of 2 with an

@@ -204,6 +204,33 @@ def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi,
             close_bf16(un, ref, f"{name} at 128 rows", ulps=2)
 
 
+@pytest.mark.parametrize("B", [40, 72, 96])
+def test_decode_projection_reads_only_the_row_blocks_it_was_given(ops, B):
+    """40 / 72 / 96 decode rows run the 64- / 128-row launch shapes with 3 of 4 / 5 of 8 / 6 of 8 sixteen-row blocks present.  The packed
+    activation buffer holds ceil(B / 16) blocks and what follows it in memory is NaN: the rows that exist must come out as the 128-row
+    launch computes them, bit for bit (gate/up with the fused norm).  (The kernels skip the absent blocks — gemm_skinny_kernel's xok[];
+    an out-of-buffer read cannot be observed from here, the e2e group-size test is what faulted without the guard.)"""
+    N, K = 1024, 512
+    w = rnd(N, K, scale=0.05, seed=401)
+    wp = ops.pack_weight(w)
+    x = rnd(128, K, seed=402)
+    B16 = (B + 15) // 16 * 16
+    ref_x = torch.zeros(128, K, device="cuda", dtype=BF)
+    ops.pack_rows(x, ref_x, 128, to_packed=True)
+    ref = torch.zeros(128, N // 2, device="cuda", dtype=BF)
+    ops.gemm_packed(ref_x, wp, N, out=ref, epilogue=3, norm_eps=1e-6, a_packed=True, c_packed=True, rows=128)
+    back = torch.full((B16 + 64, K), float("nan"), device="cuda", dtype=BF)
+    xp = back[:B16]
+    xp.zero_()
+    ops.pack_rows(x[:B].contiguous(), xp, B, to_packed=True)
+    out = torch.zeros(B16, N // 2, device="cuda", dtype=BF)
+    ops.gemm_packed(xp, wp, N, out=out, epilogue=3, norm_eps=1e-6, a_packed=True, c_packed=True, rows=B)
+    a, b = torch.zeros(B, N // 2, device="cuda", dtype=BF), torch.zeros(128, N // 2, device="cuda", dtype=BF)
+    ops.pack_rows(out, a, B, to_packed=False)
+    ops.pack_rows(ref, b, 128, to_packed=False)
+    assert torch.isfinite(a.float()).all() and torch.equal(a, b[:B])
+
+
 @pytest.mark.parametrize("M,K", [(1000, 640), (40, 256), (2 * 256 + 24, 512), (300, 136)])
 def test_gemm_rope_epilogue(ops, M, K, knobs):
     """qkv projection with RoPE fused into the epilogue (pair-interleaved q/k rows) vs Linear → rotate-half RoPE in fp32 on the
