@@ -481,18 +481,27 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
         }
         __syncthreads();
         if (!flag) return;
+        // partials are added in split order 0, 1, ..., S - 1 whichever block finishes (its own comes from registers): with S > 2 an
+        // "own first" order would make the fp32 sum depend on the arrival order
 #pragma unroll
         for (int q = 0; q < JW; ++q) {
             const int jw = wave + q * NW;
             if (jw < MT) {
+                f32x4 tot[NT];
                 for (int y = 0; y < S; ++y) {
-                    if (y == (int)blockIdx.y) continue;
-                    const float* other = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
+                    const float* part = p.ws + (((long)(blockIdx.x * S + y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                    for (int i = 0; i < NT; ++i)
+                    for (int i = 0; i < NT; ++i) {
+                        f32x4 v = sum[q][i];
+                        if (y != (int)blockIdx.y) {
 #pragma unroll
-                        for (int r = 0; r < 4; ++r) sum[q][i][r] += ld_agent(other + (i * MT + jw) * 256 + r);
+                            for (int r = 0; r < 4; ++r) v[r] = ld_agent(part + (i * MT + jw) * 256 + r);
+                        }
+                        tot[i] = (y == 0) ? v : tot[i] + v;
+                    }
                 }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) sum[q][i] = tot[i];
             }
         }
     }

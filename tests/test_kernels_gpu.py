@@ -204,6 +204,24 @@ def test_decode_projection_rows_do_not_depend_on_the_batch(ops, name, N, K, epi,
             close_bf16(un, ref, f"{name} at 128 rows", ulps=2)
 
 
+@pytest.mark.parametrize("split", [2, 4, 8])
+def test_split_k_sum_does_not_depend_on_which_block_finishes(ops, split):
+    """split-K partials are combined by whichever block arrives last; the fp32 sum must not depend on who that is (partials are added in
+    split order) — 40 launches of the 3B down-projection shape at 64 rows, all bit-identical."""
+    M, N, K = 64, 2048, 11008
+    x, w, r = rnd(M, K, seed=501), rnd(N, K, scale=0.02, seed=502), rnd(M, N, seed=503)
+    wp = ops.pack_weight(w)
+    ws = ops.new_splitk_workspace(N, split, "cuda")
+    first = None
+    for _ in range(40):
+        o = r.clone()
+        ops.gemm_packed(x, wp, N, out=o, epilogue=ops.EPI_RESID, residual=o, split_k=split, workspace=ws)
+        if first is None:
+            first = o
+            close_bf16(o, x.float() @ w.float().T + r.float(), f"split-{split}", ulps=2)
+        assert torch.equal(o, first)
+
+
 @pytest.mark.parametrize("B", [40, 72, 96])
 def test_decode_projection_reads_only_the_row_blocks_it_was_given(ops, B):
     """40 / 72 / 96 decode rows run the 64- / 128-row launch shapes with 3 of 4 / 5 of 8 / 6 of 8 sixteen-row blocks present.  The packed
