@@ -101,7 +101,6 @@ def coco_eval_bbox(gt_anns: Iterable[Dict], dt_anns: Iterable[Dict], img_ids: Se
     T, R, K, A, M = len(IOU_THRS), len(REC_THRS), len(cat_ids), len(AREA_RNG), len(MAX_DETS)
     precision = -np.ones((T, R, K, A, M))
     recall = -np.ones((T, K, A, M))
-    imgset = set(img_ids)
     for ki, cat in enumerate(cat_ids):
         cells = []                                                    # per image: (gts, dts sorted, ious)
         for img in img_ids:

@@ -102,3 +102,57 @@ def test_score_coco_assembly_follows_eval_coco_py():
     # shift the dog box by 10 % of its width: IoU = 90 / 110 = 0.818 → matched at thresholds <= 0.8 only → dog AP = 0.7, mAP = 0.85
     preds[2]["bbox"] = [210, 100, 100, 100]
     assert score_coco(preds, data, cats, images)["mAP"] == pytest.approx(0.85)
+
+
+def test_random_scenes_against_a_direct_statement_of_ap_at_one_threshold():
+    """Randomised cross-check of the cell the other 11 numbers are built from: one category, no crowds, area range 'all', maxDets 100.
+    AP at IoU t stated directly — per image the detections by falling score take the best still-free ground truth with IoU >= t; all
+    detections merged by score; precision made monotone from the right and read at the first position whose recall reaches 0, .01, ..., 1
+    (0 where it never does) — against precision[t, :, 0, 0, 2] of coco_eval_bbox, for t = .5, .75, .95 on 20 random scenes."""
+    from padt_amd.coco_eval import IOU_THRS, REC_THRS, coco_eval_bbox
+    rng = np.random.default_rng(7)
+
+    def iou(a, b):
+        w = min(a[0] + a[2], b[0] + b[2]) - max(a[0], b[0])
+        h = min(a[1] + a[3], b[1] + b[3]) - max(a[1], b[1])
+        inter = w * h if w > 0 and h > 0 else 0.0
+        return inter / (a[2] * a[3] + b[2] * b[3] - inter)
+
+    for scene in range(20):
+        gts, dts = [], []
+        for img in range(1, 5):
+            for _ in range(rng.integers(0, 5)):
+                x, y, w, h = rng.uniform(0, 200), rng.uniform(0, 200), rng.uniform(20, 120), rng.uniform(20, 120)
+                gts.append({"id": len(gts) + 1, "image_id": img, "category_id": 1, "bbox": [x, y, w, h], "area": w * h, "iscrowd": 0})
+                for _ in range(rng.integers(0, 3)):                  # detections near a ground truth, of varying quality
+                    j = rng.normal(0, 12, 4)
+                    dts.append({"image_id": img, "category_id": 1, "bbox": [x + j[0], y + j[1], max(5.0, w + j[2]), max(5.0, h + j[3])],
+                                "score": float(rng.uniform(0, 1))})
+            for _ in range(rng.integers(0, 3)):                      # stray detections
+                dts.append({"image_id": img, "category_id": 1, "bbox": [rng.uniform(0, 250), rng.uniform(0, 250), 40.0, 40.0],
+                            "score": float(rng.uniform(0, 1))})
+        if not gts:
+            continue
+        res = coco_eval_bbox(gts, dts, [1, 2, 3, 4], [1])
+        for t in (0.5, 0.75, 0.95):
+            flagged = []                                             # (score, is true positive)
+            for img in range(1, 5):
+                g = [x for x in gts if x["image_id"] == img]
+                taken = [False] * len(g)
+                for d in sorted((x for x in dts if x["image_id"] == img), key=lambda x: -x["score"]):
+                    cand = [(iou(d["bbox"], g[k]["bbox"]), k) for k in range(len(g)) if not taken[k]]
+                    cand = [c for c in cand if c[0] >= t]
+                    if cand:
+                        taken[max(cand)[1]] = True
+                    flagged.append((d["score"], bool(cand)))
+            flagged.sort(key=lambda x: -x[0])
+            tp = np.cumsum([f[1] for f in flagged]) if flagged else np.zeros(0)
+            fp = np.cumsum([not f[1] for f in flagged]) if flagged else np.zeros(0)
+            rc = tp / len(gts)
+            pr = tp / np.maximum(tp + fp, 1)
+            for i in range(len(pr) - 2, -1, -1):
+                pr[i] = max(pr[i], pr[i + 1])
+            want = [next((pr[i] for i in range(len(rc)) if rc[i] >= r), 0.0) for r in REC_THRS]
+            ti = int(np.where(np.isclose(IOU_THRS, t))[0][0])
+            got = res["precision"][ti, :, 0, 0, 2]
+            assert np.allclose(got, want, atol=1e-12), (scene, t)
