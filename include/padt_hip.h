@@ -64,7 +64,8 @@ int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m);
  * wall-clock ticks — no event packets, no serialisation of the stream.  slots = NULL stops.  Returns the number of calls recorded since the
  * previous registration.  Process-wide, not thread-safe. */
 long padt_gemm_profile(void* slots_u64, long capacity);
-/* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above). */
+/* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above): Qwen2RMSNorm.forward's
+ * variance / rsqrt (HF:80-85 ViT blocks, HF:727,744 LLM layers); the weight multiply lives in W. */
 int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 
 /* Decode-sized (M <= 64) projection with the preceding RMSNorm fused into the prologue:
@@ -253,7 +254,8 @@ int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, 
  * (value, index) pair per row in padt_greedy_step's partial layout (nblk = 1). */
 int  padt_sample_token(void* stream, const void* logits_f32, long ld_logits, long n_rows_table, const void* gen_cfg, const int* step,
                        void* part_val, void* part_idx, long batch);
-/* seen[rows[i]] |= bit(ids[i]) for the prompt tokens of a generate call (ids global in the session's table). */
+/* seen[rows[i]] |= bit(ids[i]) for the prompt tokens of a generate call (ids global in the session's table): the `input_ids` HF's
+ * RepetitionPenaltyLogitsProcessor gathers over (generation/logits_process.py, reached from padt.py:717) — prompt and padding ids included. */
 int  padt_seen_init(void* stream, const long* ids, const int* rows, long n, void* seen, long seen_words);
 
 /* ---- caller-side post-processing --------------------------------------------------------------- */
