@@ -65,7 +65,7 @@ int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m);
  * previous registration.  Process-wide, not thread-safe. */
 long padt_gemm_profile(void* slots_u64, long capacity);
 /* out[row] = rsqrt(mean(x[row]^2) + eps), fp32 — the statistics half of a folded RMSNorm (see row_scale above): Qwen2RMSNorm.forward's
- * variance / rsqrt (HF:80-85 ViT blocks, HF:727,744 LLM layers); the weight multiply lives in W. */
+ * variance / rsqrt in front of the ViT block's two sub-layers (HF:318-320) and the LLM layer's (HF:727,744); the weight multiply lives in W. */
 int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps);
 
 /* Decode-sized (M <= 64) projection with the preceding RMSNorm fused into the prologue:
