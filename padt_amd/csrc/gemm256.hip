@@ -41,7 +41,7 @@ struct Gemm256Args {
 __device__ __attribute__((aligned(16))) unsigned int g_zero_page256[64];
 
 namespace {
-constexpr int TM = 256, TN = 256, TK = 64;
+constexpr int TN = 256, TK = 64;                    // tile width and K-tile depth; the height is 64 * MF rows (MF = 2..4)
 constexpr int HALF_BYTES = 128 * TK * 2;            // 16 KiB: 128 rows x 128 B
 constexpr int OUT_PITCH = 512 + 32;                 // epilogue staging of a bf16 output tile: 256 columns + 32 B (ds_write_b64 of 16 rows x 32 B: 2-way conflicts)
 constexpr int LDS_BYTES = 256 * OUT_PITCH;          // >= 8 * HALF_BYTES: 2 K-tiles x {A0, A1, B0, B1} in the main loop
