@@ -6,7 +6,7 @@ learned-query "pos" on the query side; query_pos is always the INITIAL query ten
 The per-object replication of image memory (padt.py:365-373) is a row gather; the input projection of the low-res
 memory is computed once per image and then replicated (identical rows in, identical rows out).
 """
-from typing import List, Tuple
+from typing import List
 
 import torch
 

@@ -11,7 +11,7 @@ libpadt_hip.so.  Differences from the reference's control flow that do not chang
     per-step hidden-state stash all happen on device, the host syncs once per `sync_every` steps.
 """
 from dataclasses import dataclass
-from typing import List, Optional, Sequence, Tuple
+from typing import List, Optional
 
 import os
 

@@ -13,7 +13,7 @@ libpadt_hip.so (see vision.py / llm.py / decoder.py) and fail loudly if that lib
 import json
 import os
 from types import SimpleNamespace
-from typing import List, Optional, Sequence
+from typing import Optional, Sequence
 
 import torch
 

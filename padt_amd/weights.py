@@ -10,11 +10,9 @@ the kernels in libpadt_hip.so:
   * SwiGLU gate/up interleaved in 16-row blocks ([gate16 | up16] ...) so one GEMM tile holds matching gate/up columns
     and the activation is fused into the epilogue; MLP intermediates zero-padded to a multiple of 64 (3420 → 3456).
 """
-import json
-import math
 import os
 import zlib
-from typing import Dict, Optional
+from typing import Dict
 
 import torch
 

@@ -1,6 +1,5 @@
 """CPU-side checks of the C-ABI boundary: the in-tree library loads, exports every symbol include/padt_hip.h declares,
 and rejects malformed arguments before touching a device (no compute calls without a GPU)."""
-import ctypes
 import os
 
 import pytest

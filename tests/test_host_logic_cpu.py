@@ -7,7 +7,7 @@ import torch
 
 import padt_amd
 from padt_amd import pipeline
-from padt_amd.llm import plan_prompt, rope_index_packed
+from padt_amd.llm import plan_prompt
 from padt_amd.vision import vision_position_ids, window_index
 from padt_amd.weights import interleave16, prepare_weights, synthetic_state_dict, weight_shapes
 
