@@ -11,6 +11,13 @@
  *     state lives behind two test / measurement surfaces that no product call path touches: padt_gemm_knobs (forced tile
  *     dispatch variants) and padt_gemm_profile (in-kernel launch timing).
  *   - All pointers are device pointers.  bf16 = raw 16-bit brain floats.  Strides (`ld*`) are in ELEMENTS.
+ *   - OPERAND TYPES.  This header declares the bf16 instantiation of the library.  Every entry point below that reads or writes 16-bit
+ *     floats exists a second time for IEEE fp16 operands (`v_mfma_f32_16x16x32_f16`: same rate, 3 more mantissa bits — the default
+ *     ViT / LLM operand type since round 4): same arguments, name suffixed `_f16` (`padt_gemm_bf16` → `padt_gemm_f16`,
+ *     `padt_row_rstd` → `padt_row_rstd_f16`), declared in the generated `include/padt_hip_f16.h`.  Entry points that only MOVE 16-bit
+ *     words (padt_gather_rows, padt_pack_rows, padt_embed_tokens, padt_greedy_step's hidden-row stash) serve both types.  The one
+ *     numerical difference: the fp16 instantiation writes the 16-bit mirror of an fp32 residual stream (padt_gemm_resid32,
+ *     padt_gemm_packed_resid32, padt_gemm_fp8 epilogue 2) scaled by PADT_F16_STREAM_SCALE — see there.
  *   - Return 0 on success, -1 for rejected arguments, -2 for a HIP launch error; text via padt_last_error().
  *   - Row-major everywhere; weights in nn.Linear layout [out_features][in_features].
  */
@@ -21,7 +28,12 @@ extern "C" {
 #endif
 
 /* ---- plumbing --------------------------------------------------------------------------------------------------- */
-int         padt_abi_version(void);
+int         padt_abi_version(void);                                  /* 2: round 4 (fp16 twins, padt_cast_f32_bf16 scale) */
+/* The fp16 instantiation stores mirror = fp16(PADT_F16_STREAM_SCALE * X32): a residual stream is un-normalised (checkpoints carry "massive
+ * activations" of 1e3-1e4 in a few channels), fp16 ends at 65504, and every consumer of a mirror is scale-invariant — padt_row_rstd_f16 and the
+ * fused RMSNorm statistics of padt_gemm_packed_f16 / padt_quant_rows_fp8_f16 return rstd / scale when called with eps * scale^2, which the
+ * projection's row scale then applies to (scale * x) · W.  Returns the bf16 instantiation's factor (1) for f16 = 0, 2^-4 for f16 = 1. */
+float       padt_stream_scale(int f16);
 const char* padt_last_error(void);
 int         padt_device_info(int device, char* name, int name_len, int* n_cu, long* hbm_bytes);
 int         padt_memset(void* stream, void* dst, int value, long bytes);
@@ -169,8 +181,9 @@ int padt_gather_rows_f32(void* stream, const void* src, long ld_src, const int* 
 /* y = a + b[row % b_rows].  padt_decoder.py:30-31 (additive positional queries), :202 (vp_embedding). */
 int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y, long ldy, long n,
                   long D);
-/* fp32 → bf16 with zero-padded row tail (pixel_values.type(visual.dtype), padt.py:184). */
-int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad);
+/* y = bf16(scale * x), fp32 → bf16 with zero-padded row tail (pixel_values.type(visual.dtype), padt.py:184: scale 1; the first mirror of an
+ * fp32 residual stream: scale = padt_stream_scale()). */
+int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad, float scale);
 /* bf16 → fp32 rows (token embeddings entering the fp32 residual stream; padt.py:212-219 feed HF:790-872). */
 int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D);
 /* y(bf16) = w * x * rsqrt(mean(x^2)+eps) for fp32 rows x: the norms that read the fp32 residual stream (ViT merger ln_q HF:141-148,

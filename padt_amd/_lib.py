@@ -1,4 +1,5 @@
-"""ctypes binding of libpadt_hip.so, generated from ``include/padt_hip.h`` (single source of truth for the C ABI).
+"""ctypes binding of libpadt_hip.so, generated from ``include/padt_hip.h`` and its generated fp16 twin ``include/padt_hip_f16.h``
+(single source of truth for the C ABI).
 
 The product path has NO fallback: if the shared library is missing or does not load, importing the ops fails loudly
 with instructions to build it (``python -m padt_amd.build``).
@@ -9,6 +10,7 @@ import re
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(HERE), "include", "padt_hip.h")
+HEADER_F16 = os.path.join(os.path.dirname(HERE), "include", "padt_hip_f16.h")
 LIB_PATH = os.environ.get("PADT_HIP_LIB") or os.path.join(HERE, "libpadt_hip.so")
 
 _CTYPE = {"int": ctypes.c_int, "long": ctypes.c_long, "float": ctypes.c_float}
@@ -61,7 +63,7 @@ def load():
         lib = ctypes.CDLL(LIB_PATH)
     except OSError as e:  # pragma: no cover
         raise PaDTHipError(f"failed to load {LIB_PATH}: {e}") from e
-    for name, (restype, argtypes, _) in parse_header().items():
+    for name, (restype, argtypes, _) in {**parse_header(), **parse_header(HEADER_F16)}.items():
         fn = getattr(lib, name)           # AttributeError if the .so lacks a declared symbol
         fn.restype = restype
         fn.argtypes = argtypes

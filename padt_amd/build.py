@@ -12,6 +12,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpadt_hip.so")
 SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip", "decoder_hp.hip", "resize.hip"]
+# Translation units written against the 16-bit operand type X of csrc/common.h: compiled a second time with X = fp16 (-DPADT_OP16_F16=1;
+# own namespace, entry points suffixed _f16: include/padt_hip_f16.h) and linked into the same library.
+TWIN_SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip"]
 FLAGS = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-Wno-unused-result"]
 # Per-source extras (dropped with a warning if this hipcc does not know them).  -amdgpu-mfma-vgpr-form: MFMA results land in ordinary
 # VGPRs instead of AccVGPRs.  hipcc's default keeps the attention kernels' score / output tiles in AccVGPRs and moves every value to a
@@ -43,13 +46,15 @@ def build(force=False, verbose=True):
     objdir = os.path.join(HERE, "build")
     os.makedirs(objdir, exist_ok=True)
 
-    def compile_one(src):
-        obj = os.path.join(objdir, src.replace(".hip", ".o"))
-        cmd = [hipcc, *FLAGS, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
+    def compile_one(job):
+        src, f16 = job
+        obj = os.path.join(objdir, src.replace(".hip", "_f16.o" if f16 else ".o"))
+        defs = ["-DPADT_OP16_F16=1"] if f16 else []
+        cmd = [hipcc, *FLAGS, *defs, *EXTRA_FLAGS.get(src, []), "-c", os.path.join(CSRC, src), "-o", obj]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0 and src in EXTRA_FLAGS:
             print(f"[padt_amd.build] {src}: extra flags {EXTRA_FLAGS[src]} rejected, compiling without them", file=sys.stderr)
-            cmd = [hipcc, *FLAGS, "-c", os.path.join(CSRC, src), "-o", obj]
+            cmd = [hipcc, *FLAGS, *defs, "-c", os.path.join(CSRC, src), "-o", obj]
             r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
@@ -57,8 +62,10 @@ def build(force=False, verbose=True):
             print(r.stderr, file=sys.stderr)
         return obj
 
-    with ThreadPoolExecutor(max_workers=min(8, len(SOURCES))) as ex:
-        objs = list(ex.map(compile_one, SOURCES))
+    jobs = [(s, False) for s in SOURCES] + [(s, True) for s in TWIN_SOURCES]
+    jobs.sort(key=lambda j: j[0] not in ("gemm256.hip", "gemm.hip", "attention.hip"))      # longest compiles first
+    with ThreadPoolExecutor(max_workers=min(os.cpu_count() or 8, len(jobs))) as ex:
+        objs = list(ex.map(compile_one, jobs))
     r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", LIB], capture_output=True, text=True)
     if r.returncode != 0:
         raise RuntimeError(f"link failed:\n{r.stdout}\n{r.stderr}")

@@ -15,14 +15,18 @@
 #include <cstdlib>
 #include <cstdint>
 
+extern "C" void padt_set_error(const char* msg);
+
+namespace PADT_NS {
+
 typedef short v4s_t __attribute__((ext_vector_type(4)));
 typedef v4s_t __attribute__((address_space(3))) v4s_lds;
 
 struct AttnArgs {
-    const bf16_t* q; long ldq;      // token stride (elements); head h at +h*D
-    const bf16_t* k; long ldk;      // kv head g at +g*D
-    const bf16_t* v; long ldv;
-    bf16_t* o; long ldo;
+    const x16_t* q; long ldq;      // token stride (elements); head h at +h*D
+    const x16_t* k; long ldk;      // kv head g at +g*D
+    const x16_t* v; long ldv;
+    x16_t* o; long ldo;
     const int* cu_q; const int* cu_k;
     int group;                      // q heads per kv head
     float scale_log2;               // softmax scale * log2(e)
@@ -65,8 +69,8 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     using C = AttnCfg<D>;
     constexpr int HALF = D / 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);
-    bf16_t* Vt = reinterpret_cast<bf16_t*>(smem + C::K_BYTES);
+    x16_t* Ks = reinterpret_cast<x16_t*>(smem);
+    x16_t* Vt = reinterpret_cast<x16_t*>(smem + C::K_BYTES);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int frow = lane & 15, fq = lane >> 4;
@@ -89,7 +93,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
     const int w_tok1 = GQA ? tile * TPB + (wr0 + 16 * QR - 1) / G : tile * TQ + wr0 + 16 * QR - 1;
 
     // ---- Q fragments (B operand): column = query row
-    bf16x8 qf[QR][C::KQ];
+    x16x8 qf[QR][C::KQ];
 #pragma unroll
     for (int rb = 0; rb < QR; ++rb)
 #pragma unroll
@@ -100,7 +104,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             qf[rb][kk] = (live(r) && d < D) ? ld_frag(p.q + (long)(q_beg + qrow) * p.ldq + hq * D + d) : zero_frag();
             if (ROPE && qrow < Lq && d < D) {
                 const bool lo = d < HALF;
-                const bf16_t* qp = p.q + (long)(q_beg + qrow) * p.ldq + h * D + (lo ? d + HALF : d - HALF);
+                const x16_t* qp = p.q + (long)(q_beg + qrow) * p.ldq + h * D + (lo ? d + HALF : d - HALF);
                 const long ci = (long)(q_beg + qrow) * p.ld_cs + (lo ? d : d - HALF);
                 float x[8], y[8], c[8], sn[8];
                 unpack8(__builtin_bit_cast(u32x4, qf[rb][kk]), x);
@@ -111,7 +115,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
                 *reinterpret_cast<f32x4*>(sn + 4) = *reinterpret_cast<const f32x4*>(p.rsin + ci + 4);
 #pragma unroll
                 for (int e = 0; e < 8; ++e) x[e] = lo ? rope_lo(x[e], y[e], c[e], sn[e]) : rope_hi(y[e], x[e], c[e], sn[e]);
-                qf[rb][kk] = __builtin_bit_cast(bf16x8, pack8(x));
+                qf[rb][kk] = __builtin_bit_cast(x16x8, pack8(x));
             }
         }
 
@@ -196,8 +200,8 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this wave's pieces of tile kt have landed
             __syncthreads();                                      // everyone's have; everyone is done with the other buffer (tile kt - 1)
             if (kt + 1 < nkt) issue(kt + 1, (kt + 1) & 1);
-            Ks = reinterpret_cast<bf16_t*>(smem + (kt & 1) * C::LDS);
-            Vt = reinterpret_cast<bf16_t*>(smem + (kt & 1) * C::LDS + C::K_BYTES);
+            Ks = reinterpret_cast<x16_t*>(smem + (kt & 1) * C::LDS);
+            Vt = reinterpret_cast<x16_t*>(smem + (kt & 1) * C::LDS + C::K_BYTES);
         } else {
         __syncthreads();                                          // previous tile fully consumed
 #pragma unroll
@@ -216,7 +220,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
                 const int idx = it * 256 + tid;
                 if (idx < 64 * (C::CPR / 2)) {
                     const int row = idx / (C::CPR / 2), c = idx % (C::CPR / 2);
-                    bf16_t* k1 = Ks + row * C::KROW + c * 8;
+                    x16_t* k1 = Ks + row * C::KROW + c * 8;
                     float x1[8], x2[8], o1[8], o2[8];
                     unpack8(*reinterpret_cast<const u32x4*>(k1), x1);
                     unpack8(*reinterpret_cast<const u32x4*>(k1 + HALF), x2);
@@ -244,7 +248,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 #pragma unroll
             for (int kk = 0; kk < C::KQ; ++kk) {
                 const int d = kk * 32 + fq * 8;
-                const bf16x8 kf = (d < D) ? ld_frag(Ks + (kb * 16 + frow) * C::KROW + d) : zero_frag();
+                const x16x8 kf = (d < D) ? ld_frag(Ks + (kb * 16 + frow) * C::KROW + d) : zero_frag();
 #pragma unroll
                 for (int rb = 0; rb < QR; ++rb) s[rb][kb] = mfma16(kf, qf[rb][kk], s[rb][kb]);
             }
@@ -265,7 +269,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
                     }
             }
         }
-        bf16x8 pf[QR][2];
+        x16x8 pf[QR][2];
 #pragma unroll
         for (int rb = 0; rb < QR; ++rb) {
             float m = -INFINITY;
@@ -293,7 +297,7 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
             l_run[rb] = l_run[rb] * alpha + lsum;                  // per-lane partial (this lane's 16 keys per tile)
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks)
-                pf[rb][ks] = __builtin_bit_cast(bf16x8, pack8(pv + ks * 8));
+                pf[rb][ks] = __builtin_bit_cast(x16x8, pack8(pv + ks * 8));
             // the running max rarely moves after the first tiles: skip the O rescale for the whole wave when alpha == 1
             // in every lane (multiplying by exactly 1.0f is the identity, so results do not depend on the shortcut)
             if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
@@ -310,11 +314,11 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 #pragma unroll
             for (int i = 0; i < C::NB; ++i) {
                 // chunk handed in by this lane: key 32ks + 4fq + (frow >> 2) (second read: + 16), d = 16i + 4(frow & 3)
-                const bf16_t* vp = Vt + (ks * 32 + fq * 4 + (frow >> 2)) * C::VROW + i * 16 + (frow & 3) * 4;
+                const x16_t* vp = Vt + (ks * 32 + fq * 4 + (frow >> 2)) * C::VROW + i * 16 + (frow & 3) * 4;
                 const u32x2 lo = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_lds*)(vp)));
                 const u32x2 hi = __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4s_lds*)(vp + 16 * C::VROW)));
                 const u32x4 vv = {lo[0], lo[1], hi[0], hi[1]};
-                const bf16x8 vf = __builtin_bit_cast(bf16x8, vv);
+                const x16x8 vf = __builtin_bit_cast(x16x8, vv);
 #pragma unroll
                 for (int rb = 0; rb < QR; ++rb) o[rb][i] = mfma16(vf, pf[rb][ks], o[rb][i]);
             }
@@ -330,12 +334,12 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
         const int qi = tok_of(r);
         if (!live(r)) continue;
         const float inv = l > 0.f ? 1.0f / l : 0.f;
-        bf16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + head_of(r) * D + fq * 4;
+        x16_t* dst = p.o + (long)(q_beg + qi) * p.ldo + head_of(r) * D + fq * 4;
 #pragma unroll
         for (int i = 0; i < C::NB; ++i) {
             u32x2 w;
-            w[0] = pack2bf(o[rb][i][0] * inv, o[rb][i][1] * inv);
-            w[1] = pack2bf(o[rb][i][2] * inv, o[rb][i][3] * inv);
+            w[0] = pack2x(o[rb][i][0] * inv, o[rb][i][1] * inv);
+            w[1] = pack2x(o[rb][i][2] * inv, o[rb][i][3] * inv);
             *reinterpret_cast<u32x2*>(dst + i * 16) = w;
         }
     }
@@ -344,13 +348,13 @@ __global__ __launch_bounds__(256) void attn_varlen_kernel(AttnArgs p) {
 // ---------------------------------------------------------------------------------------------------------------------
 // Decode attention, head_dim D (multiple of 32), one new token per sample.
 struct DecodeArgs {
-    const bf16_t* q;        // [B][Hq*D]
-    const bf16_t* kc;       // K cache [B][Hkv][S_max][D]
-    const bf16_t* vtc;      // V^T cache [B][Hkv][D][S_max]
+    const x16_t* q;        // [B][Hq*D]
+    const x16_t* kc;       // K cache [B][Hkv][S_max][D]
+    const x16_t* vtc;      // V^T cache [B][Hkv][D][S_max]
     const int* lens;        // [B] number of valid keys (including the token just appended)
     float* part_o;          // [B][Hkv][nsplit][16][D]
     float* part_ml;         // [B][Hkv][nsplit][16][2]
-    bf16_t* out;            // [B][Hq*D]
+    x16_t* out;            // [B][Hq*D]
     int Hq, Hkv, S_max, nsplit;
     float scale_log2;
     int out_packed = 0;     // out in the 16-row fragment-packed activation layout (row length Hq*D)
@@ -358,7 +362,7 @@ struct DecodeArgs {
 
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
-    __shared__ __attribute__((aligned(16))) bf16_t Pw[16 * 72];
+    __shared__ __attribute__((aligned(16))) x16_t Pw[16 * 72];
     const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
     const int group = p.Hq / p.Hkv;
@@ -371,13 +375,13 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
         if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
         return;
     }
-    bf16x8 qf[KQ];
+    x16x8 qf[KQ];
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk)
         qf[kk] = (frow < group) ? ld_frag(p.q + (long)b * p.Hq * D + (g * group + frow) * D + kk * 32 + fq * 8) : zero_frag();
 
-    const bf16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
-    const bf16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+    const x16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    const x16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
 
     f32x4 s[4];
 #pragma unroll
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
         for (int r = 0; r < 4; ++r) {
             const float pv = exp2f(s[kb][r] - mrow[r]);
             lrow[r] += pv;
-            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2bf(pv);
+            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2x(pv);
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -433,7 +437,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
     for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
+        const x16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
         int kk0 = k0 + ks * 32 + fq * 8;                          // 8 keys, 16-byte aligned in the V^T row
         kk0 = (kk0 + 8 <= p.S_max) ? kk0 : p.S_max - 8;           // (S_max % 64 == 0, so this never actually clamps)
 #pragma unroll
@@ -489,7 +493,7 @@ __global__ void decode_combine_kernel(DecodeArgs p) {
     const long ld = (long)p.Hq * D;
     const int n = hq * D + d;
     const long o = p.out_packed ? (long)(b >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (b & 15)) * 8 + (n & 7) : (long)b * ld + n;
-    p.out[o] = f2bf(L > 0.f ? acc / L : 0.f);
+    p.out[o] = f2x(L > 0.f ? acc / L : 0.f);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -501,10 +505,10 @@ __global__ void decode_combine_kernel(DecodeArgs p) {
 // taken from LDS, never read back from global, so no block depends on another block's (or its own) fresh stores.
 // HF:557-599 (mRoPE), :665-666 (cache update), :641-689 (attention with Lq == 1).
 struct DecodeRopeArgs {
-    const bf16_t* qkv; long ld_qkv;   // [B][(Hq + 2 Hkv) * D], bias already added
+    const x16_t* qkv; long ld_qkv;   // [B][(Hq + 2 Hkv) * D], bias already added
     const float* rope_cs;             // [B][D/2][2] cos, sin of this step's position (sections already resolved)
     const int* slot;                  // [B] append index; valid keys afterwards = slot + 1
-    bf16_t* kc; bf16_t* vtc;
+    x16_t* kc; x16_t* vtc;
     float* part_o; float* part_ml;
     int B, Hq, Hkv, S_max, nsplit;
     float scale_log2;
@@ -513,11 +517,11 @@ struct DecodeRopeArgs {
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) {
     constexpr int QROW = D + 8, KQ = D / 32, NB = D / 16, HALF = D / 2;
-    __shared__ __attribute__((aligned(16))) bf16_t Qs[16 * QROW];
-    __shared__ __attribute__((aligned(16))) bf16_t Knew[D];
-    __shared__ __attribute__((aligned(16))) bf16_t Vnew[D];
-    __shared__ __attribute__((aligned(16))) bf16_t Pw[16 * 72];
-    __shared__ __attribute__((aligned(16))) bf16_t Raw[18 * D];
+    __shared__ __attribute__((aligned(16))) x16_t Qs[16 * QROW];
+    __shared__ __attribute__((aligned(16))) x16_t Knew[D];
+    __shared__ __attribute__((aligned(16))) x16_t Vnew[D];
+    __shared__ __attribute__((aligned(16))) x16_t Pw[16 * 72];
+    __shared__ __attribute__((aligned(16))) x16_t Raw[18 * D];
     __shared__ __attribute__((aligned(16))) float Cs[D];
     const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
@@ -530,9 +534,9 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         if (lane < 16) { p.part_ml[(pbase + lane) * 2] = -INFINITY; p.part_ml[(pbase + lane) * 2 + 1] = 0.f; }
         return;
     }
-    const bf16_t* row = p.qkv + (long)b * p.ld_qkv;
-    bf16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
-    bf16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+    const x16_t* row = p.qkv + (long)b * p.ld_qkv;
+    x16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    x16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
     const bool owner = (slot >= k0) && (slot < k0 + 64);
     const float* cs = p.rope_cs + (long)b * HALF * 2;
 
@@ -548,7 +552,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     for (int it = 0; it < RAW_IT; ++it) {
         const int c = it * 64 + lane;
         const int hh = c / CPH, cc = c % CPH;
-        const bf16_t* src = hh < group ? row + (long)(g * group + hh) * D
+        const x16_t* src = hh < group ? row + (long)(g * group + hh) * D
                                        : (hh == group ? row + (long)(p.Hq + g) * D : row + (long)(p.Hq + p.Hkv + g) * D);
         raw[it] = (c < n_raw) ? *reinterpret_cast<const u32x4*>(src + cc * 8) : u32x4{0u, 0u, 0u, 0u};
     }
@@ -587,8 +591,8 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     for (int i = lane; i < (group + 1) * HALF; i += 64) {
         const int hh = i / HALF, d = i % HALF;
         const float c = Cs[2 * d], sn = Cs[2 * d + 1];
-        const float x1 = bf2f(Raw[hh * D + d]), x2 = bf2f(Raw[hh * D + d + HALF]);
-        const bf16_t o1 = f2bf(rope_lo(x1, x2, c, sn)), o2 = f2bf(rope_hi(x1, x2, c, sn));
+        const float x1 = x2f(Raw[hh * D + d]), x2 = x2f(Raw[hh * D + d + HALF]);
+        const x16_t o1 = f2x(rope_lo(x1, x2, c, sn)), o2 = f2x(rope_hi(x1, x2, c, sn));
         if (hh < group) {
             Qs[hh * QROW + d] = o1; Qs[hh * QROW + d + HALF] = o2;
         } else {
@@ -597,13 +601,13 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         }
     }
     for (int d = lane; d < D; d += 64) {
-        const bf16_t v = Raw[(group + 1) * D + d];
+        const x16_t v = Raw[(group + 1) * D + d];
         Vnew[d] = v;
         if (owner) vbase[(long)d * p.S_max + slot] = v;
     }
     __syncthreads();
 
-    bf16x8 qf[KQ];
+    x16x8 qf[KQ];
 #pragma unroll
     for (int kk = 0; kk < KQ; ++kk) qf[kk] = ld_frag(Qs + frow * QROW + kk * 32 + fq * 8);
     f32x4 s[4];
@@ -613,8 +617,8 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         const int key = k0 + kb * 16 + frow;
 #pragma unroll
         for (int kk = 0; kk < KQ; ++kk) {
-            const bf16x8 kn = ld_frag(Knew + kk * 32 + fq * 8);
-            const bf16x8 kf = (key == slot) ? kn : __builtin_bit_cast(bf16x8, kraw[kb][kk]);
+            const x16x8 kn = ld_frag(Knew + kk * 32 + fq * 8);
+            const x16x8 kf = (key == slot) ? kn : __builtin_bit_cast(x16x8, kraw[kb][kk]);
             s[kb] = mfma16(qf[kk], kf, s[kb]);
         }
     }
@@ -646,7 +650,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         for (int r = 0; r < 4; ++r) {
             const float pv = exp2f(s[kb][r] - mrow[r]);
             lrow[r] += pv;
-            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2bf(pv);
+            Pw[(fq * 4 + r) * 72 + kb * 16 + frow] = f2x(pv);
         }
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
@@ -663,7 +667,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
     for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-        const bf16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
+        const x16x8 pf = ld_frag(Pw + frow * 72 + ks * 32 + fq * 8);
         const int kk0 = k0 + ks * 32 + fq * 8;                     // 8 consecutive keys of the V^T row
         const int j = slot - kk0;                                  // position of the fresh token inside this fragment
 #pragma unroll
@@ -676,11 +680,11 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
 #pragma unroll
                 for (int w2 = 0; w2 < 4; ++w2) {
                     const unsigned cur = vv[w2];
-                    const unsigned pat = (j & 1) ? ((cur & 0x0000ffffu) | (nv << 16)) : ((cur & 0xffff0000u) | nv);
+                    const unsigned pat = (j & 1) ? ((cur & 0x0000ffffu) | (nv << 16)) : ((cur & 0xffff0000u) | nv);   // 16-bit lane insert: type-agnostic
                     vv[w2] = (w2 == wsel) ? pat : cur;
                 }
             }
-            o[i] = mfma16(pf, __builtin_bit_cast(bf16x8, vv), o[i]);
+            o[i] = mfma16(pf, __builtin_bit_cast(x16x8, vv), o[i]);
         }
     }
 #pragma unroll
@@ -694,8 +698,6 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
-extern "C" void padt_set_error(const char* msg);
-
 template <int D, bool CAUSAL, int QR, bool ROPE, bool GQA>
 static void launch_attn_k(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int lds = ROPE ? AttnCfg<D>::LDS : AttnCfg<D>::LDS2;             // the LDS-DMA path double-buffers the K / V tiles
@@ -736,7 +738,7 @@ static void launch_attn(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hi
     else launch_attn_qr<D, CAUSAL, 1>(a, max_seqlen_q, H, nseg, s);
 }
 
-extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
+extern "C" int PADT_TWIN(padt_attn_varlen)(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv,
                                 void* o, long ldo, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q,
                                 int n_heads, int n_kv_heads, int head_dim, float scale, int causal, const void* rope_cos,
                                 const void* rope_sin, long ld_cs) {
@@ -750,7 +752,7 @@ extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const voi
         padt_set_error("padt_attn_varlen: strides must be multiples of 8 elements; heads % kv_heads == 0");
         return -1;
     }
-    AttnArgs a{(const bf16_t*)q, ldq, (const bf16_t*)k, ldk, (const bf16_t*)v, ldv, (bf16_t*)o, ldo, cu_q, cu_k,
+    AttnArgs a{(const x16_t*)q, ldq, (const x16_t*)k, ldk, (const x16_t*)v, ldv, (x16_t*)o, ldo, cu_q, cu_k,
                n_heads / n_kv_heads, scale * 1.4426950408889634f, (const float*)rope_cos, (const float*)rope_sin, ld_cs};
     hipStream_t s = (hipStream_t)stream;
 #define PADT_ATTN_CASE(DD)                                                         \
@@ -771,12 +773,14 @@ extern "C" int padt_attn_varlen(void* stream, const void* q, long ldq, const voi
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent: compiled once
 extern "C" long padt_decode_attn_workspace(int batch, int n_kv_heads, int head_dim, int s_max) {
     const long nsplit = (s_max + 63) / 64;
     return (long)batch * n_kv_heads * nsplit * 16 * (head_dim + 2) * (long)sizeof(float);
 }
+#endif
 
-extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens,
+extern "C" int PADT_TWIN(padt_decode_attn)(void* stream, const void* q, const void* k_cache, const void* vt_cache, const int* lens,
                                 void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,
                                 int s_max, int max_len, float scale) {
     if (batch <= 0) return 0;
@@ -785,8 +789,8 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
         return -1;
     }
     DecodeArgs a;
-    a.q = (const bf16_t*)q; a.kc = (const bf16_t*)k_cache; a.vtc = (const bf16_t*)vt_cache; a.lens = lens;
-    a.out = (bf16_t*)out; a.Hq = n_heads; a.Hkv = n_kv_heads; a.S_max = s_max;
+    a.q = (const x16_t*)q; a.kc = (const x16_t*)k_cache; a.vtc = (const x16_t*)vt_cache; a.lens = lens;
+    a.out = (x16_t*)out; a.Hq = n_heads; a.Hkv = n_kv_heads; a.S_max = s_max;
     a.nsplit = (max_len + 63) / 64;
     a.part_o = (float*)workspace;
     a.part_ml = a.part_o + (long)batch * n_kv_heads * a.nsplit * 16 * head_dim;
@@ -808,7 +812,7 @@ extern "C" int padt_decode_attn(void* stream, const void* q, const void* k_cache
     return 0;
 }
 
-extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot,
+extern "C" int PADT_TWIN(padt_decode_attn_rope)(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot,
                                      void* k_cache, void* vt_cache, void* out, void* workspace, int batch, int n_heads,
                                      int n_kv_heads, int head_dim, int s_max, int max_len, float scale, int out_packed) {
     if (batch <= 0) return 0;
@@ -817,7 +821,7 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
         return -1;
     }
     const int nsplit = (max_len + 63) / 64;
-    DecodeRopeArgs a{(const bf16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (bf16_t*)k_cache, (bf16_t*)vt_cache,
+    DecodeRopeArgs a{(const x16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (x16_t*)k_cache, (x16_t*)vt_cache,
                      (float*)workspace, nullptr, batch, n_heads, n_kv_heads, s_max, nsplit, scale * 1.4426950408889634f};
     a.part_ml = a.part_o + (long)batch * n_kv_heads * nsplit * 16 * head_dim;
     hipStream_t s = (hipStream_t)stream;
@@ -825,7 +829,7 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
     // cross-XCD partial stores / loads cost 28 us per call against 12.7 us for the two launches below.
     DecodeArgs c;                                              // the merge reads the same partial layout
     c.q = nullptr; c.kc = nullptr; c.vtc = nullptr; c.lens = nullptr; c.part_o = a.part_o; c.part_ml = a.part_ml;
-    c.out = (bf16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
+    c.out = (x16_t*)out; c.Hq = n_heads; c.Hkv = n_kv_heads; c.S_max = s_max; c.nsplit = nsplit; c.scale_log2 = a.scale_log2;
     c.out_packed = out_packed;
     switch (head_dim) {
         case 32:
@@ -843,6 +847,7 @@ extern "C" int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv,
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent: compiled once
 // fp32 cos/sin table of one decode step: rope_cs[b][d] = (cos, sin)(pos3[axis(d)][b] * inv_freq[d]), d < D/2.
 __global__ void rope_table_kernel(const int* __restrict__ pos3, const float* __restrict__ inv_freq, float* __restrict__ cs,
                                   int B, int half, int sec0, int sec1) {
@@ -865,3 +870,6 @@ extern "C" int padt_rope_table(void* stream, const int* pos3, const void* inv_fr
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;
 }
+#endif
+
+}  // namespace PADT_NS

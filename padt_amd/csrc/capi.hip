@@ -11,7 +11,9 @@ extern "C" void padt_set_error(const char* msg) {
 
 extern "C" const char* padt_last_error(void) { return g_err; }
 
-extern "C" int padt_abi_version(void) { return 1; }
+extern "C" int padt_abi_version(void) { return 2; }
+// common.h PADT_STREAM_SCALE of the two operand-type instantiations
+extern "C" float padt_stream_scale(int f16) { return f16 ? 0.0625f : 1.0f; }
 
 // Returns 0 and fills name (<= 255 chars) / CU count when a gfx950 device is present; -1 otherwise.
 extern "C" int padt_device_info(int device, char* name, int name_len, int* n_cu, long* hbm_bytes) {

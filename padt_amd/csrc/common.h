@@ -1,14 +1,56 @@
 // Device-side helpers shared by every kernel file.  gfx950 (MI355X, CDNA4) only: wave = 64 lanes,
-// MFMA 16x16x32 bf16 fragments, LDS-DMA (global_load_lds_dwordx4).
+// MFMA 16x16x32 fragments of a 16-bit operand type (bf16 or fp16, below), LDS-DMA (global_load_lds_dwordx4).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-typedef unsigned short bf16_t;                                   // raw bf16 bits in memory
-typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;       // one MFMA A/B fragment (4 VGPRs)
+// ---- the 16-bit operand type X of this translation unit ---------------------------------------------------------------------
+// Every kernel that touches 16-bit activations / weights is written against x16_t (raw bits in memory), x16x8 (one MFMA A/B fragment),
+// x2f / f2x / pack2x / unpack8 / pack8 (conversions, round-to-nearest-even) and mfma16 — and build.py compiles those translation units
+// TWICE into the one library: X = bf16 (8 mantissa bits, fp32 range; the split-precision PaDT decoder's (hi, lo) pairs, and the A/B
+// fallback for ViT / LLM) and X = IEEE fp16 (11 mantissa bits; `v_mfma_f32_16x16x32_f16` runs at the bf16 rate on gfx950 and the LDS
+// image, DMA pieces and `ds_read_b64_tr_b16` are type-agnostic) — the default ViT / LLM operand type since round 4: the same kernels
+// land 8x closer to the fp32 reference (tests/studies/operand_attribution.py).  An instantiation lives in its own namespace and exports
+// its C entry points under its own names: padt_gemm_bf16 / padt_gemm_f16, padt_row_rstd / padt_row_rstd_f16 (include/padt_hip_f16.h).
+#ifndef PADT_OP16_F16
+#define PADT_OP16_F16 0
+#endif
+#define PADT_CAT_(a, b) a##b
+#define PADT_CAT(a, b) PADT_CAT_(a, b)
+#define PADT_CAT3(a, b, c) PADT_CAT(PADT_CAT(a, b), c)
+#if PADT_OP16_F16
+#define PADT_T16 f16
+#define PADT_NS padt_x_f16
+#define PADT_TWIN(name) name##_f16                       // padt_row_rstd → padt_row_rstd_f16
+#else
+#define PADT_T16 bf16
+#define PADT_NS padt_x_bf16
+#define PADT_TWIN(name) name                             // padt_row_rstd
+#endif
+#define PADT_SYM(pre, post) PADT_CAT3(pre, PADT_T16, post)   // PADT_SYM(padt_gemm_, ) → padt_gemm_bf16 / padt_gemm_f16
+
+typedef unsigned short x16_t;                                    // raw 16-bit float bits in memory (bf16 or fp16, see above)
+#if PADT_OP16_F16
+typedef _Float16 x16n_t;                                         // the native scalar type
+#else
+typedef __bf16 x16n_t;
+#endif
+typedef __attribute__((ext_vector_type(8))) x16n_t x16x8;        // one MFMA A/B fragment (4 VGPRs)
+typedef __attribute__((ext_vector_type(2))) x16n_t x16x2;
 typedef __attribute__((ext_vector_type(4))) float f32x4;         // one 16x16 MFMA C/D fragment
 typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;  // 16 bytes
 typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;  // 8 bytes
+
+// fp32 residual stream → its 16-bit MIRROR (the A operand of the next projection, padt_gemm_resid32 and friends): the mirror holds
+// X(STREAM_SCALE * x32).  A residual stream is un-normalised — real checkpoints carry "massive activations" of 1e3-1e4 in a few channels —
+// and every consumer of a mirror is scale-invariant (row_rstd / the fused RMSNorm statistics divide the factor out again, given
+// eps * STREAM_SCALE^2), so the fp16 instantiation stores it 2^-4 down: 16x head room above fp16's 65504 at no cost in precision for the
+// elements that matter (|x| < 1e-3 falls into fp16 subnormals: absolute error 5e-7).  bf16 has fp32's range: factor 1.
+#if PADT_OP16_F16
+#define PADT_STREAM_SCALE 0.0625f
+#else
+#define PADT_STREAM_SCALE 1.0f
+#endif
 
 #define PADT_DEV __device__ __forceinline__
 
@@ -40,33 +82,54 @@ struct ProfScope {
     }
 };
 
-PADT_DEV float bf2f(bf16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
-
-// round-to-nearest-even via the gfx950 hardware conversion (v_cvt_pk_bf16_f32); NaN stays NaN, +-inf stays +-inf
-typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
-PADT_DEV bf16_t f2bf(float f) { return __builtin_bit_cast(bf16_t, (__bf16)f); }
-PADT_DEV unsigned pack2bf(float lo, float hi) {
-    bf16x2 v = {(__bf16)lo, (__bf16)hi};
+// round-to-nearest-even via the hardware conversions (v_cvt_pk_bf16_f32 / v_cvt_f16_f32); NaN stays NaN, +-inf stays +-inf; fp16
+// overflows to +-inf above 65504 (a NaN downstream, never a silently wrong number)
+#if PADT_OP16_F16
+PADT_DEV float x2f(x16_t v) { return (float)__builtin_bit_cast(_Float16, v); }
+PADT_DEV void unpack2x(unsigned v, float& lo, float& hi) {
+    const x16x2 h = __builtin_bit_cast(x16x2, v);
+    lo = (float)h[0];
+    hi = (float)h[1];
+}
+#else
+PADT_DEV float x2f(x16_t v) { return __builtin_bit_cast(float, (unsigned)v << 16); }
+PADT_DEV void unpack2x(unsigned v, float& lo, float& hi) {
+    lo = __builtin_bit_cast(float, v << 16);
+    hi = __builtin_bit_cast(float, v & 0xffff0000u);
+}
+#endif
+PADT_DEV x16_t f2x(float f) { return __builtin_bit_cast(x16_t, (x16n_t)f); }
+PADT_DEV unsigned pack2x(float lo, float hi) {
+    x16x2 v = {(x16n_t)lo, (x16n_t)hi};
     return __builtin_bit_cast(unsigned, v);
 }
-
-PADT_DEV bf16x8 ld_frag(const void* p) { return *reinterpret_cast<const bf16x8*>(p); }
-
-PADT_DEV bf16x8 zero_frag() {
-    u32x4 z = {0u, 0u, 0u, 0u};
-    return __builtin_bit_cast(bf16x8, z);
+// 4 values of one 8-byte vector
+PADT_DEV void unpack4x(u32x2 v, float* f) {
+    unpack2x(v[0], f[0], f[1]);
+    unpack2x(v[1], f[2], f[3]);
 }
 
-// 8 OCP e4m3 bytes (two dwords, element j = byte j) → one bf16 MFMA fragment; exact (e4m3 ⊂ bf16): v_cvt_pk_f32_fp8 + v_cvt_pk_bf16_f32
+PADT_DEV x16x8 ld_frag(const void* p) { return *reinterpret_cast<const x16x8*>(p); }
+
+PADT_DEV x16x8 zero_frag() {
+    u32x4 z = {0u, 0u, 0u, 0u};
+    return __builtin_bit_cast(x16x8, z);
+}
+
+// 8 OCP e4m3 bytes (two dwords, element j = byte j) → one MFMA fragment; exact (e4m3 ⊂ bf16, ⊂ fp16): v_cvt_pk_f32_fp8 + the pack above
 typedef __attribute__((ext_vector_type(2))) float f32x2;
-PADT_DEV bf16x8 fp8x8_to_bf16x8(unsigned lo, unsigned hi) {
+PADT_DEV x16x8 fp8x8_to_x16x8(unsigned lo, unsigned hi) {
     const f32x2 a = __builtin_amdgcn_cvt_pk_f32_fp8(lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8(lo, true);
     const f32x2 c = __builtin_amdgcn_cvt_pk_f32_fp8(hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8(hi, true);
-    const u32x4 r = {pack2bf(a[0], a[1]), pack2bf(b[0], b[1]), pack2bf(c[0], c[1]), pack2bf(d[0], d[1])};
-    return __builtin_bit_cast(bf16x8, r);
+    const u32x4 r = {pack2x(a[0], a[1]), pack2x(b[0], b[1]), pack2x(c[0], c[1]), pack2x(d[0], d[1])};
+    return __builtin_bit_cast(x16x8, r);
 }
 
-PADT_DEV f32x4 mfma16(bf16x8 a, bf16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#if PADT_OP16_F16
+PADT_DEV f32x4 mfma16(x16x8 a, x16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b, c, 0, 0, 0); }
+#else
+PADT_DEV f32x4 mfma16(x16x8 a, x16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+#endif
 
 // Cross-block hand-off inside one kernel (split-K / split-KV "last block reduces"): the 8 XCDs have separate L2s, so
 // partials are written and read with agent-scope relaxed atomics (sc1: served at the device coherence point) instead
@@ -119,18 +182,15 @@ PADT_DEV float gelu_erf(float x) { return 0.5f * x * (1.0f + erff(x * 0.70710678
 // lane per tile and the division's ~10-instruction sequence was a third of that epilogue (profiles/r02_gemm256_experiments.md)
 PADT_DEV float silu(float x) { return x * __builtin_amdgcn_rcpf(1.0f + __expf(-x)); }
 
-// unpack 8 bf16 (one 16-byte vector) to floats
+// unpack 8 X values (one 16-byte vector) to floats
 PADT_DEV void unpack8(const u32x4& v, float* f) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        f[2 * i] = __builtin_bit_cast(float, v[i] << 16);
-        f[2 * i + 1] = __builtin_bit_cast(float, v[i] & 0xffff0000u);
-    }
+    for (int i = 0; i < 4; ++i) unpack2x(v[i], f[2 * i], f[2 * i + 1]);
 }
 PADT_DEV u32x4 pack8(const float* f) {
     u32x4 v;
 #pragma unroll
-    for (int i = 0; i < 4; ++i) v[i] = pack2bf(f[2 * i], f[2 * i + 1]);
+    for (int i = 0; i < 4; ++i) v[i] = pack2x(f[2 * i], f[2 * i + 1]);
     return v;
 }
 

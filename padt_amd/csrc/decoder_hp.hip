@@ -26,21 +26,16 @@ extern "C" void padt_set_error(const char* msg);
 
 namespace {
 
-PADT_DEV void unpack4h(u32x2 v, float* f) {
-    f[0] = __builtin_bit_cast(float, v[0] << 16);
-    f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
-    f[2] = __builtin_bit_cast(float, v[1] << 16);
-    f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
-}
+PADT_DEV void unpack4h(u32x2 v, float* f) { unpack4x(v, f); }   // this file is compiled for X = bf16 only (the (hi, lo) pairs)
 
 // 4 consecutive columns c..c+3 of one row → hi at [(c / chunk) * 2 * chunk + c % chunk], lo `chunk` elements further
-PADT_DEV void split_store4(bf16_t* y, long row_off, int c, int chunk, const float* v) {
-    bf16_t* dst = y + row_off + (long)(c / chunk) * 2 * chunk + (c % chunk);
-    const u32x2 hi = u32x2{pack2bf(v[0], v[1]), pack2bf(v[2], v[3])};
+PADT_DEV void split_store4(x16_t* y, long row_off, int c, int chunk, const float* v) {
+    x16_t* dst = y + row_off + (long)(c / chunk) * 2 * chunk + (c % chunk);
+    const u32x2 hi = u32x2{pack2x(v[0], v[1]), pack2x(v[2], v[3])};
     float h[4];
     unpack4h(hi, h);
     *reinterpret_cast<u32x2*>(dst) = hi;
-    *reinterpret_cast<u32x2*>(dst + chunk) = u32x2{pack2bf(v[0] - h[0], v[1] - h[1]), pack2bf(v[2] - h[2], v[3] - h[3])};
+    *reinterpret_cast<u32x2*>(dst + chunk) = u32x2{pack2x(v[0] - h[0], v[1] - h[1]), pack2x(v[2] - h[2], v[3] - h[3])};
 }
 
 enum { OUT_NONE = 0, OUT_F32 = 1, OUT_SPLIT = 2 };
@@ -49,7 +44,7 @@ struct NormSplitArgs {
     const void* x; long ldx; int x_f32;          // input rows, bf16 or fp32
     const int* idx;                              // optional row gather: x row of output row r = idx[r]
     const float* a; long lda; int a_div;         // optional pre-norm add: x + a[r / a_div]   (padt_decoder.py:220)
-    const bf16_t* w; float eps; int act;         // RMSNorm weight (null: no normalisation); act 1 = exact-erf GELU after it
+    const x16_t* w; float eps; int act;         // RMSNorm weight (null: no normalisation); act 1 = exact-erf GELU after it
     const float* pos; long ld_pos; long pos_rows;  // optional post-norm add for the SECOND output: y + pos[r % pos_rows]
     void* y0; long ld_y0; int y0_mode;           // first output:  y
     void* y1; long ld_y1; int y1_mode;           // second output: y + pos
@@ -68,7 +63,7 @@ __global__ __launch_bounds__(256) void norm_split_kernel(NormSplitArgs p) {
             const f32x4 v = *reinterpret_cast<const f32x4*>(reinterpret_cast<const float*>(p.x) + sr * p.ldx + c);
             f[0] = v[0]; f[1] = v[1]; f[2] = v[2]; f[3] = v[3];
         } else {
-            unpack4h(*reinterpret_cast<const u32x2*>(reinterpret_cast<const bf16_t*>(p.x) + sr * p.ldx + c), f);
+            unpack4h(*reinterpret_cast<const u32x2*>(reinterpret_cast<const x16_t*>(p.x) + sr * p.ldx + c), f);
         }
         if (ar) {
             const f32x4 g = *reinterpret_cast<const f32x4*>(ar + c);
@@ -100,14 +95,14 @@ __global__ __launch_bounds__(256) void norm_split_kernel(NormSplitArgs p) {
             }
         }
         if (p.y0_mode == OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y0) + (long)row * p.ld_y0 + c) = f32x4{f[0], f[1], f[2], f[3]};
-        else if (p.y0_mode == OUT_SPLIT) split_store4(reinterpret_cast<bf16_t*>(p.y0), (long)row * p.ld_y0, c, p.chunk, f);
+        else if (p.y0_mode == OUT_SPLIT) split_store4(reinterpret_cast<x16_t*>(p.y0), (long)row * p.ld_y0, c, p.chunk, f);
         if (p.y1_mode != OUT_NONE) {
             if (pr) {
                 const f32x4 g = *reinterpret_cast<const f32x4*>(pr + c);
                 f[0] += g[0]; f[1] += g[1]; f[2] += g[2]; f[3] += g[3];
             }
             if (p.y1_mode == OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.y1) + (long)row * p.ld_y1 + c) = f32x4{f[0], f[1], f[2], f[3]};
-            else split_store4(reinterpret_cast<bf16_t*>(p.y1), (long)row * p.ld_y1, c, p.chunk, f);
+            else split_store4(reinterpret_cast<x16_t*>(p.y1), (long)row * p.ld_y1, c, p.chunk, f);
         }
     }
 }
@@ -134,7 +129,7 @@ struct AttnF32Args {
     const float* q; long ldq;
     const float* k; long ldk;
     const float* v; long ldv;
-    bf16_t* out; long ldo; int chunk;             // split rows: element (t, h*D + d)
+    x16_t* out; long ldo; int chunk;             // split rows: element (t, h*D + d)
     const int* cu_q; const int* cu_k;
     float scale;
 };
@@ -371,7 +366,7 @@ extern "C" int padt_norm_split(void* stream, const void* x, long ldx, int x_f32,
         padt_set_error("padt_norm_split: D, chunk and strides must be multiples of 4 (D % chunk == 0), pointers 16-byte aligned, modes in 0..2");
         return -1;
     }
-    NormSplitArgs a{x, ldx, x_f32, idx, (const float*)add_f32, ld_add, add_div, (const bf16_t*)w, eps, act, (const float*)pos_f32, ld_pos,
+    NormSplitArgs a{x, ldx, x_f32, idx, (const float*)add_f32, ld_add, add_div, (const x16_t*)w, eps, act, (const float*)pos_f32, ld_pos,
                     pos_rows, y0, ld_y0, y0_mode, y1, ld_y1, y1_mode, (int)rows, (int)D, (int)chunk};
     hipLaunchKernelGGL(norm_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     PADT_CHECK_LAUNCH("norm_split");
@@ -410,7 +405,7 @@ extern "C" int padt_attn_f32(void* stream, const void* q, long ldq, const void* 
         padt_set_error("padt_attn_f32: strides / chunk multiples of 4, 16-byte aligned q/k/v, nseg and n_heads <= 65535");
         return -1;
     }
-    AttnF32Args a{(const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (bf16_t*)out_split, ldo, (int)chunk, cu_q, cu_k, scale};
+    AttnF32Args a{(const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (x16_t*)out_split, ldo, (int)chunk, cu_q, cu_k, scale};
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 32: launch_attn_f32<32>(a, nseg, max_seqlen_q, max_seqlen_k, n_heads, s); break;

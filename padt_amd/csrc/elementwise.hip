@@ -5,6 +5,8 @@
 
 extern "C" void padt_set_error(const char* msg);
 
+namespace PADT_NS {
+
 #define PADT_CHECK_LAUNCH(name)                                          \
     do {                                                                 \
         hipError_t e_ = hipGetLastError();                               \
@@ -16,15 +18,15 @@ extern "C" void padt_set_error(const char* msg);
 // fp32 accumulate, single rounding on the way out (act = 1 applies exact-erf GELU after the weight: the
 // Linear→RMSNorm→GELU of mask_output_upscaling1, padt_decoder.py:168-172).  Optional fused "add" input: y = norm(x + a[row / a_div]) which
 // implements padt_decoder.py:220  high = RMSNorm(repeat4(low) + high)  with a_div = 4.
-__global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ a,
-                                                      long lda, int a_div, const bf16_t* __restrict__ w,
-                                                      bf16_t* __restrict__ y, long ldy, int rows, int D, float eps,
+__global__ __launch_bounds__(256) void rmsnorm_kernel(const x16_t* __restrict__ x, long ldx, const x16_t* __restrict__ a,
+                                                      long lda, int a_div, const x16_t* __restrict__ w,
+                                                      x16_t* __restrict__ y, long ldy, int rows, int D, float eps,
                                                       int act) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * ldx;
-    const bf16_t* ar = a ? a + (long)(row / a_div) * lda : nullptr;
+    const x16_t* xr = x + (long)row * ldx;
+    const x16_t* ar = a ? a + (long)(row / a_div) * lda : nullptr;
     float ss = 0.f;
     for (int c = lane * 8; c < D; c += 512) {
         float f[8];
@@ -40,7 +42,7 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);
-    bf16_t* yr = y + (long)row * ldy;
+    x16_t* yr = y + (long)row * ldy;
     for (int c = lane * 8; c < D; c += 512) {
         float f[8], g[8], wv[8];
         unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
@@ -59,27 +61,27 @@ __global__ __launch_bounds__(256) void rmsnorm_kernel(const bf16_t* __restrict__
     }
 }
 
-extern "C" int padt_rmsnorm(void* stream, const void* x, long ldx, const void* add, long ld_add, int add_div,
+extern "C" int PADT_TWIN(padt_rmsnorm)(void* stream, const void* x, long ldx, const void* add, long ld_add, int add_div,
                             const void* w, void* y, long ldy, long rows, long D, float eps, int act) {
     if (rows <= 0) return 0;
     if ((D & 7) || (ldx & 7) || (ldy & 7) || (add && (ld_add & 7)) || add_div <= 0) {
         padt_set_error("padt_rmsnorm: D and strides must be multiples of 8");
         return -1;
     }
-    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)add, ld_add, add_div, (const bf16_t*)w, (bf16_t*)y, ldy, (int)rows, (int)D, eps, act);
+    hipLaunchKernelGGL(rmsnorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const x16_t*)x, ldx,
+                       (const x16_t*)add, ld_add, add_div, (const x16_t*)w, (x16_t*)y, ldy, (int)rows, (int)D, eps, act);
     PADT_CHECK_LAUNCH("rmsnorm");
     return 0;
 }
 
 // LayerNorm with mean centring (vis_norm, padt.py:121,188; eps 1e-5, weight + bias).
-__global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict__ x, long ldx, const bf16_t* __restrict__ w,
-                                                        const bf16_t* __restrict__ b, bf16_t* __restrict__ y, long ldy,
+__global__ __launch_bounds__(256) void layernorm_kernel(const x16_t* __restrict__ x, long ldx, const x16_t* __restrict__ w,
+                                                        const x16_t* __restrict__ b, x16_t* __restrict__ y, long ldy,
                                                         int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * ldx;
+    const x16_t* xr = x + (long)row * ldx;
     float s = 0.f;
     for (int c = lane * 8; c < D; c += 512) {
         float f[8];
@@ -96,7 +98,7 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
         for (int i = 0; i < 8; ++i) { const float d = f[i] - mean; v += d * d; }
     }
     const float rstd = rsqrtf(wave_sum(v) / (float)D + eps);
-    bf16_t* yr = y + (long)row * ldy;
+    x16_t* yr = y + (long)row * ldy;
     for (int c = lane * 8; c < D; c += 512) {
         float f[8], wv[8], bv[8];
         unpack8(*reinterpret_cast<const u32x4*>(xr + c), f);
@@ -108,12 +110,12 @@ __global__ __launch_bounds__(256) void layernorm_kernel(const bf16_t* __restrict
     }
 }
 
-extern "C" int padt_layernorm(void* stream, const void* x, long ldx, const void* w, const void* b, void* y, long ldy,
+extern "C" int PADT_TWIN(padt_layernorm)(void* stream, const void* x, long ldx, const void* w, const void* b, void* y, long ldy,
                               long rows, long D, float eps) {
     if (rows <= 0) return 0;
     if ((D & 7) || (ldx & 7) || (ldy & 7)) { padt_set_error("padt_layernorm: D and strides must be multiples of 8"); return -1; }
-    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-                       (const bf16_t*)w, (const bf16_t*)b, (bf16_t*)y, ldy, (int)rows, (int)D, eps);
+    hipLaunchKernelGGL(layernorm_kernel, dim3((rows + 3) / 4), dim3(256), 0, (hipStream_t)stream, (const x16_t*)x, ldx,
+                       (const x16_t*)w, (const x16_t*)b, (x16_t*)y, ldy, (int)rows, (int)D, eps);
     PADT_CHECK_LAUNCH("layernorm");
     return 0;
 }
@@ -122,7 +124,7 @@ extern "C" int padt_layernorm(void* stream, const void* x, long ldx, const void*
 // Rotate-half rotary in place over `nh` consecutive heads of width D per token, fp32 math, cos/sin tables fp32 [T][ld_cs]
 // (first D/2 columns used).  ViT q,k (HF apply_rotary_pos_emb_vision :160-171; q and k are adjacent in the fused qkv
 // row so one launch covers both) and the PaDT decoder's image-side q or k (padt_decoder.py:38-51).
-__global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
+__global__ __launch_bounds__(256) void rope_half_kernel(x16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
                                                         const float* __restrict__ sn, long ld_cs, long T, int nh, int D) {
     const int half = D >> 1;
     const long total = T * nh * half;
@@ -131,16 +133,16 @@ __global__ __launch_bounds__(256) void rope_half_kernel(bf16_t* __restrict__ x, 
         const long th = i / half;
         const int h = (int)(th % nh);
         const long t = th / nh;
-        bf16_t* p = x + t * ldx + (long)h * D;
+        x16_t* p = x + t * ldx + (long)h * D;
         const float c = cs[t * ld_cs + d], s = sn[t * ld_cs + d];
-        const float x1 = bf2f(p[d]), x2 = bf2f(p[d + half]);
-        p[d] = f2bf(rope_lo(x1, x2, c, s));
-        p[d + half] = f2bf(rope_hi(x1, x2, c, s));
+        const float x1 = x2f(p[d]), x2 = x2f(p[d + half]);
+        p[d] = f2x(rope_lo(x1, x2, c, s));
+        p[d + half] = f2x(rope_hi(x1, x2, c, s));
     }
 }
 
 // 16-byte path (D/2 and every stride a multiple of 8): a lane rotates 8 (d, d + D/2) pairs of one (token, head).
-__global__ __launch_bounds__(256) void rope_half_vec_kernel(bf16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
+__global__ __launch_bounds__(256) void rope_half_vec_kernel(x16_t* __restrict__ x, long ldx, const float* __restrict__ cs,
                                                             const float* __restrict__ sn, long ld_cs, long T, int nh, int D) {
     const int half = D >> 1, cph = half >> 3;                     // 8-wide chunks per half head
     const long total = T * nh * cph;
@@ -149,7 +151,7 @@ __global__ __launch_bounds__(256) void rope_half_vec_kernel(bf16_t* __restrict__
         const long th = i / cph;
         const int h = (int)(th % nh);
         const long t = th / nh;
-        bf16_t* p = x + t * ldx + (long)h * D + c * 8;
+        x16_t* p = x + t * ldx + (long)h * D + c * 8;
         const u32x4 r1 = *reinterpret_cast<const u32x4*>(p), r2 = *reinterpret_cast<const u32x4*>(p + half);
         const f32x4 c0 = *reinterpret_cast<const f32x4*>(cs + t * ld_cs + c * 8), c1 = *reinterpret_cast<const f32x4*>(cs + t * ld_cs + c * 8 + 4);
         const f32x4 s0 = *reinterpret_cast<const f32x4*>(sn + t * ld_cs + c * 8), s1 = *reinterpret_cast<const f32x4*>(sn + t * ld_cs + c * 8 + 4);
@@ -167,7 +169,7 @@ __global__ __launch_bounds__(256) void rope_half_vec_kernel(bf16_t* __restrict__
     }
 }
 
-extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T,
+extern "C" int PADT_TWIN(padt_rope_half)(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T,
                               int n_heads, int head_dim) {
     if (T <= 0) return 0;
     if (head_dim & 1) { padt_set_error("padt_rope_half: head_dim must be even"); return -1; }
@@ -176,7 +178,7 @@ extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t
         const long tv = T * n_heads * (head_dim / 16);
         long bv = (tv + 255) / 256;
         if (bv > 32768) bv = 32768;
-        hipLaunchKernelGGL(rope_half_vec_kernel, dim3((unsigned)bv), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+        hipLaunchKernelGGL(rope_half_vec_kernel, dim3((unsigned)bv), dim3(256), 0, (hipStream_t)stream, (x16_t*)x, ldx,
                            (const float*)cos_t, (const float*)sin_t, ld_cs, T, n_heads, head_dim);
         PADT_CHECK_LAUNCH("rope_half");
         return 0;
@@ -184,7 +186,7 @@ extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t
     const long total = T * n_heads * (head_dim / 2);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (bf16_t*)x, ldx,
+    hipLaunchKernelGGL(rope_half_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (x16_t*)x, ldx,
                        (const float*)cos_t, (const float*)sin_t, ld_cs, T, n_heads, head_dim);
     PADT_CHECK_LAUNCH("rope_half");
     return 0;
@@ -194,12 +196,12 @@ extern "C" int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t
 // rstd[row] = rsqrt(mean(x[row]^2) + eps): the statistics half of an RMSNorm whose weight is folded into the following
 // projection (y = rstd[m] * (x @ (W·diag(g))^T)[m] + b) — the GEMM then reads x itself and scales its accumulator
 // (padt_gemm_bf16 row_scale), so the normalised copy of x is never written or re-read.  One wave per row.
-__global__ __launch_bounds__(256) void row_rstd_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ out, int rows,
+__global__ __launch_bounds__(256) void row_rstd_kernel(const x16_t* __restrict__ x, long ldx, float* __restrict__ out, int rows,
                                                        int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * ldx;
+    const x16_t* xr = x + (long)row * ldx;
     float ss = 0.f;
     for (int c = lane * 8; c < D; c += 512) {
         float f[8];
@@ -211,20 +213,21 @@ __global__ __launch_bounds__(256) void row_rstd_kernel(const bf16_t* __restrict_
     if (lane == 0) out[row] = rsqrtf(ss / (float)D + eps);
 }
 
-extern "C" int padt_row_rstd(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps) {
+extern "C" int PADT_TWIN(padt_row_rstd)(void* stream, const void* x, long ldx, void* out_f32, long rows, long D, float eps) {
     if (rows <= 0) return 0;
     if ((D & 7) || (ldx & 7) || ((uintptr_t)x & 15)) { padt_set_error("padt_row_rstd: D, ldx multiples of 8, x 16-byte aligned"); return -1; }
-    hipLaunchKernelGGL(row_rstd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+    hipLaunchKernelGGL(row_rstd_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const x16_t*)x, ldx,
                        (float*)out_f32, (int)rows, (int)D, eps);
     PADT_CHECK_LAUNCH("row_rstd");
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent (or bf16-decoder-only): compiled once
 // ---------------------------------------------------------------------------------------------------------------------
 // Row-major [M][K] <-> 16-row fragment-packed activation layout (padt_hip.h), 16-byte chunks.  Once per decode step on each
 // side of the layer loop (embedding output in, final hidden state out); inside the loop the projections read and write the
 // packed form directly.
-__global__ __launch_bounds__(256) void pack_rows_kernel(const bf16_t* __restrict__ src, long ld_src, bf16_t* __restrict__ dst,
+__global__ __launch_bounds__(256) void pack_rows_kernel(const x16_t* __restrict__ src, long ld_src, x16_t* __restrict__ dst,
                                                         long ld_dst, int M, int chunks, int to_packed) {
     const long total = (long)M * chunks;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -245,8 +248,8 @@ extern "C" int padt_pack_rows(void* stream, const void* src, long ld_src, void* 
     const long total = M * (K / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src, ld_src,
-                       (bf16_t*)dst, ld_dst, (int)M, (int)(K / 8), to_packed);
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const x16_t*)src, ld_src,
+                       (x16_t*)dst, ld_dst, (int)M, (int)(K / 8), to_packed);
     PADT_CHECK_LAUNCH("pack_rows");
     return 0;
 }
@@ -254,8 +257,8 @@ extern "C" int padt_pack_rows(void* stream, const void* src, long ld_src, void* 
 // ---------------------------------------------------------------------------------------------------------------------
 // dst[i] = src[idx[i]]  (16-byte vectors).  ViT window permutation (padt.py:70-75), un-permutation of the merger output
 // (padt.py:103-104), per-object replication of image memory (padt.py:365-373).
-__global__ __launch_bounds__(256) void gather_rows_kernel(const bf16_t* __restrict__ src, long ld_src,
-                                                          const int* __restrict__ idx, bf16_t* __restrict__ dst,
+__global__ __launch_bounds__(256) void gather_rows_kernel(const x16_t* __restrict__ src, long ld_src,
+                                                          const int* __restrict__ idx, x16_t* __restrict__ dst,
                                                           long ld_dst, long n, int vec_per_row) {
     const long total = n * vec_per_row;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -272,8 +275,8 @@ extern "C" int padt_gather_rows(void* stream, const void* src, long ld_src, cons
     const long total = n * (D / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
-                       ld_src, idx, (bf16_t*)dst, ld_dst, n, (int)(D / 8));
+    hipLaunchKernelGGL(gather_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const x16_t*)src,
+                       ld_src, idx, (x16_t*)dst, ld_dst, n, (int)(D / 8));
     PADT_CHECK_LAUNCH("gather_rows");
     return 0;
 }
@@ -301,9 +304,11 @@ extern "C" int padt_gather_rows_f32(void* stream, const void* src, long ld_src, 
     return 0;
 }
 
+#endif
+
 // y = a + b[row % b_rows]   (decoder: key/query + positional query, padt_decoder.py:30-31; b_rows == rows → plain add)
-__global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict__ a, long lda, const bf16_t* __restrict__ b,
-                                                       long ldb, long b_rows, bf16_t* __restrict__ y, long ldy, long n,
+__global__ __launch_bounds__(256) void add_rows_kernel(const x16_t* __restrict__ a, long lda, const x16_t* __restrict__ b,
+                                                       long ldb, long b_rows, x16_t* __restrict__ y, long ldy, long n,
                                                        int vec_per_row) {
     const long total = n * vec_per_row;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -318,42 +323,42 @@ __global__ __launch_bounds__(256) void add_rows_kernel(const bf16_t* __restrict_
     }
 }
 
-extern "C" int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y,
+extern "C" int PADT_TWIN(padt_add_rows)(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y,
                              long ldy, long n, long D) {
     if (n <= 0) return 0;
     if ((D & 7) || (lda & 7) || (ldb & 7) || (ldy & 7) || b_rows <= 0) { padt_set_error("padt_add_rows: bad arguments"); return -1; }
     const long total = n * (D / 8);
     long blocks = (total + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)a, lda,
-                       (const bf16_t*)b, ldb, b_rows, (bf16_t*)y, ldy, n, (int)(D / 8));
+    hipLaunchKernelGGL(add_rows_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const x16_t*)a, lda,
+                       (const x16_t*)b, ldb, b_rows, (x16_t*)y, ldy, n, (int)(D / 8));
     PADT_CHECK_LAUNCH("add_rows");
     return 0;
 }
 
 // fp32 → bf16 cast (pixel_values.type(self.visual.dtype), padt.py:184) with optional zero padding of the row tail.
-__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, long ldx, bf16_t* __restrict__ y,
-                                                            long ldy, long rows, int D, int D_pad) {
+__global__ __launch_bounds__(256) void cast_f32_bf16_kernel(const float* __restrict__ x, long ldx, x16_t* __restrict__ y,
+                                                            long ldy, long rows, int D, int D_pad, float scale) {
     const long total = rows * D_pad;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / D_pad;
         const int c = (int)(i % D_pad);
-        y[r * ldy + c] = c < D ? f2bf(x[r * ldx + c]) : (bf16_t)0;
+        y[r * ldy + c] = c < D ? f2x(x[r * ldx + c] * scale) : (x16_t)0;
     }
 }
 
-extern "C" int padt_cast_f32_bf16(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad) {
+extern "C" int PADT_SYM(padt_cast_f32_, )(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D, long D_pad, float scale) {
     if (rows <= 0) return 0;
     long blocks = (rows * D_pad + 255) / 256;
     if (blocks > 32768) blocks = 32768;
     hipLaunchKernelGGL(cast_f32_bf16_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)x,
-                       ldx, (bf16_t*)y, ldy, rows, (int)D, (int)D_pad);
+                       ldx, (x16_t*)y, ldy, rows, (int)D, (int)D_pad, scale);
     PADT_CHECK_LAUNCH("cast_f32_bf16");
     return 0;
 }
 
 // bf16 → fp32 (16-byte loads): the token embeddings entering the fp32 residual stream of the LLM (padt_gemm_resid32).
-__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int vec) {
+__global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const x16_t* __restrict__ x, long ldx, float* __restrict__ y, long ldy, long rows, int vec) {
     const long total = rows * vec;
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
         const long r = i / vec;
@@ -366,7 +371,7 @@ __global__ __launch_bounds__(256) void cast_bf16_f32_kernel(const bf16_t* __rest
     }
 }
 
-extern "C" int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D) {
+extern "C" int PADT_SYM(padt_cast_, _f32)(void* stream, const void* x, long ldx, void* y, long ldy, long rows, long D) {
     if (rows <= 0) return 0;
     if ((D & 7) || (ldx & 7) || (ldy & 3) || ((uintptr_t)x & 15) || ((uintptr_t)y & 15)) {
         padt_set_error("padt_cast_bf16_f32: D, ldx multiples of 8, ldy of 4, 16-byte aligned pointers");
@@ -374,7 +379,7 @@ extern "C" int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y
     }
     long blocks = (rows * (D / 8) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, (float*)y, ldy,
+    hipLaunchKernelGGL(cast_bf16_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const x16_t*)x, ldx, (float*)y, ldy,
                        rows, (int)(D / 8));
     PADT_CHECK_LAUNCH("cast_bf16_f32");
     return 0;
@@ -382,7 +387,7 @@ extern "C" int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y
 
 // RMSNorm of fp32 rows → bf16 (the norms that read the fp32 residual stream: ViT merger ln_q HF:141-148, LLM final norm HF:867): one wave per
 // row, statistics and scaling in fp32, ONE rounding on the way out.
-__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restrict__ x, long ldx, const bf16_t* __restrict__ w, bf16_t* __restrict__ y,
+__global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restrict__ x, long ldx, const x16_t* __restrict__ w, x16_t* __restrict__ y,
                                                           long ldy, int rows, int D, float eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
@@ -395,32 +400,29 @@ __global__ __launch_bounds__(256) void rmsnorm_f32_kernel(const float* __restric
     }
     ss = wave_sum(ss);
     const float rstd = rsqrtf(ss / (float)D + eps);
-    bf16_t* yr = y + (long)row * ldy;
+    x16_t* yr = y + (long)row * ldy;
     for (int c = lane * 4; c < D; c += 256) {
         const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
         float wv[4];
-        const u32x2 wr = *reinterpret_cast<const u32x2*>(w + c);
-        wv[0] = __builtin_bit_cast(float, wr[0] << 16);
-        wv[1] = __builtin_bit_cast(float, wr[0] & 0xffff0000u);
-        wv[2] = __builtin_bit_cast(float, wr[1] << 16);
-        wv[3] = __builtin_bit_cast(float, wr[1] & 0xffff0000u);
+        unpack4x(*reinterpret_cast<const u32x2*>(w + c), wv);
         // HF:74-79 rounds the normalised value to the input dtype before the weight multiply; with an fp32 stream that rounding is fp32
-        *reinterpret_cast<u32x2*>(yr + c) = u32x2{pack2bf(v[0] * rstd * wv[0], v[1] * rstd * wv[1]), pack2bf(v[2] * rstd * wv[2], v[3] * rstd * wv[3])};
+        *reinterpret_cast<u32x2*>(yr + c) = u32x2{pack2x(v[0] * rstd * wv[0], v[1] * rstd * wv[1]), pack2x(v[2] * rstd * wv[2], v[3] * rstd * wv[3])};
     }
 }
 
-extern "C" int padt_rmsnorm_f32(void* stream, const void* x_f32, long ldx, const void* w, void* y, long ldy, long rows, long D, float eps) {
+extern "C" int PADT_TWIN(padt_rmsnorm_f32)(void* stream, const void* x_f32, long ldx, const void* w, void* y, long ldy, long rows, long D, float eps) {
     if (rows <= 0) return 0;
     if ((D & 3) || (ldx & 3) || (ldy & 3) || ((uintptr_t)x_f32 & 15) || ((uintptr_t)y & 7) || ((uintptr_t)w & 7)) {
         padt_set_error("padt_rmsnorm_f32: D and strides multiples of 4, x 16-byte / y, w 8-byte aligned");
         return -1;
     }
     hipLaunchKernelGGL(rmsnorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x_f32, ldx,
-                       (const bf16_t*)w, (bf16_t*)y, ldy, (int)rows, (int)D, eps);
+                       (const x16_t*)w, (x16_t*)y, ldy, (int)rows, (int)D, eps);
     PADT_CHECK_LAUNCH("rmsnorm_f32");
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent (or bf16-decoder-only): compiled once
 // in-place fp32 sigmoid (bbox head's nn.Sigmoid, padt_decoder.py:164)
 __global__ void sigmoid_f32_kernel(float* __restrict__ x, long n) {
     for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x)
@@ -440,8 +442,8 @@ extern "C" int padt_sigmoid_f32(void* stream, void* x, long n) {
 // VRT embedding: inputs_embeds[t] = image_embeds[img_index[t]] if img_index[t] >= 0 else [E ‖ proto][ids[t]]
 // (padt.py:193-219 prefill, 226-229 decode) — the table is never concatenated: two base pointers.
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restrict__ ids, const int* __restrict__ img_index,
-                                                           const bf16_t* __restrict__ E, const bf16_t* __restrict__ proto,
-                                                           const bf16_t* __restrict__ image_embeds, bf16_t* __restrict__ out,
+                                                           const x16_t* __restrict__ E, const x16_t* __restrict__ proto,
+                                                           const x16_t* __restrict__ image_embeds, x16_t* __restrict__ out,
                                                            long T, int V, int n_proto, int vec_per_row, int* __restrict__ err) {
     const long total = T * vec_per_row;
     const int D = vec_per_row * 8;
@@ -450,7 +452,7 @@ __global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restric
         const int c = (int)(i % vec_per_row) * 8;
         const long id = ids[t];
         const int ii = img_index ? img_index[t] : -1;
-        const bf16_t* src;
+        const x16_t* src;
         if (ii >= 0) src = image_embeds + (long)ii * D;
         else if (id >= 0 && id < V) src = E + id * D;
         else if (id >= V && id < (long)V + n_proto) src = proto + (id - V) * D;
@@ -467,26 +469,28 @@ extern "C" int padt_embed_tokens(void* stream, const long* ids, const int* img_i
     long blocks = (T * (D / 8) + 255) / 256;
     if (blocks > 16384) blocks = 16384;
     hipLaunchKernelGGL(embed_tokens_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, ids, img_index,
-                       (const bf16_t*)embed_table, (const bf16_t*)proto, (const bf16_t*)image_embeds, (bf16_t*)out, T,
+                       (const x16_t*)embed_table, (const x16_t*)proto, (const x16_t*)image_embeds, (x16_t*)out, T,
                        (int)vocab, (int)n_proto, (int)(D / 8), err_flag);
     PADT_CHECK_LAUNCH("embed_tokens");
     return 0;
 }
+
+#endif
 
 // ---------------------------------------------------------------------------------------------------------------------
 // LLM q/k/v post-processing for T tokens: mRoPE on q and k (HF apply_multimodal_rotary_pos_emb :557-599, sections
 // [s0,s1,s2] over head_dim/2, rotate-half pairs), write q to q_out, roped k to the row-major K cache and (prefill) to a
 // packed k buffer, v to the TRANSPOSED V cache.  qkv row = [Hq*D | Hkv*D | Hkv*D] (bias already added by the GEMM).
 struct QkvPostArgs {
-    const bf16_t* qkv; long ld;
+    const x16_t* qkv; long ld;
     const int* pos;            // [3][T]  (t, h, w) rope positions
     const int* sample;         // [T] sample index (cache row); null → token index
     const int* slot;           // [T] cache slot; null → read from lens[sample] (decode)
     const int* lens;           // [B] current lengths (decode: slot = lens[b])
     const float* inv_freq;     // [D/2]
-    bf16_t* q_out; long ld_q;
-    bf16_t* k_pack; long ld_kp; // may be null
-    bf16_t* kc; bf16_t* vtc;   // caches
+    x16_t* q_out; long ld_q;
+    x16_t* k_pack; long ld_kp; // may be null
+    x16_t* kc; x16_t* vtc;   // caches
     int T, Hq, Hkv, D, S_max, sec0, sec1;
 };
 
@@ -496,7 +500,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
     const int half = p.D >> 1;
     const int b = p.sample ? p.sample[t] : t;
     const int slot = p.slot ? p.slot[t] : p.lens[b];
-    const bf16_t* row = p.qkv + (long)t * p.ld;
+    const x16_t* row = p.qkv + (long)t * p.ld;
     // the angle depends on (token, d) only: computed once per token, not once per head
     for (int d = threadIdx.x; d < half; d += blockDim.x) {
         const int axis = d < p.sec0 ? 0 : (d < p.sec0 + p.sec1 ? 1 : 2);
@@ -511,7 +515,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
         const int items = (p.Hq + p.Hkv) * cph;
         for (int i = threadIdx.x; i < items; i += blockDim.x) {
             const int h = i / cph, d = (i % cph) * 8;
-            const bf16_t* x = row + (long)h * p.D + d;
+            const x16_t* x = row + (long)h * p.D + d;
             float x1[8], x2[8], o1[8], o2[8];
             unpack8(*reinterpret_cast<const u32x4*>(x), x1);
             unpack8(*reinterpret_cast<const u32x4*>(x + half), x2);
@@ -523,16 +527,16 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
             }
             const u32x4 r1 = pack8(o1), r2 = pack8(o2);
             if (h < p.Hq) {
-                bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D + d;
+                x16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D + d;
                 *reinterpret_cast<u32x4*>(q) = r1;
                 *reinterpret_cast<u32x4*>(q + half) = r2;
             } else {
                 const int g = h - p.Hq;
-                bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D + d;
+                x16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D + d;
                 *reinterpret_cast<u32x4*>(kc) = r1;
                 *reinterpret_cast<u32x4*>(kc + half) = r2;
                 if (p.k_pack) {
-                    bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D + d;
+                    x16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D + d;
                     *reinterpret_cast<u32x4*>(kp) = r1;
                     *reinterpret_cast<u32x4*>(kp + half) = r2;
                 }
@@ -543,50 +547,51 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
         for (int i = threadIdx.x; i < nqk; i += blockDim.x) {
             const int h = i / half, d = i % half;
             const float c = cs[0][d], s = cs[1][d];
-            const bf16_t* x = row + (long)h * p.D;
-            const float x1 = bf2f(x[d]), x2 = bf2f(x[d + half]);
-            const bf16_t o1 = f2bf(rope_lo(x1, x2, c, s)), o2 = f2bf(rope_hi(x1, x2, c, s));
+            const x16_t* x = row + (long)h * p.D;
+            const float x1 = x2f(x[d]), x2 = x2f(x[d + half]);
+            const x16_t o1 = f2x(rope_lo(x1, x2, c, s)), o2 = f2x(rope_hi(x1, x2, c, s));
             if (h < p.Hq) {
-                bf16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
+                x16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
                 q[d] = o1; q[d + half] = o2;
             } else {
                 const int g = h - p.Hq;
-                bf16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
+                x16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
                 kc[d] = o1; kc[d + half] = o2;
                 if (p.k_pack) {
-                    bf16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
+                    x16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
                     kp[d] = o1; kp[d + half] = o2;
                 }
             }
         }
     }
-    const bf16_t* v = row + (long)(p.Hq + p.Hkv) * p.D;
+    const x16_t* v = row + (long)(p.Hq + p.Hkv) * p.D;
     for (int i = threadIdx.x; i < p.Hkv * p.D; i += blockDim.x) {
         const int g = i / p.D, d = i % p.D;
         p.vtc[(((long)b * p.Hkv + g) * p.D + d) * p.S_max + slot] = v[i];
     }
 }
 
-extern "C" int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample,
+extern "C" int PADT_TWIN(padt_llm_qkv_post)(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample,
                                  const int* slot, const int* lens, const void* inv_freq, void* q_out, long ld_q,
                                  void* k_pack, long ld_kp, void* k_cache, void* vt_cache, long T, int n_heads,
                                  int n_kv_heads, int head_dim, int s_max, int sec0, int sec1) {
     if (T <= 0) return 0;
     if (!slot && !lens) { padt_set_error("padt_llm_qkv_post: need slot[] or lens[]"); return -1; }
     if (head_dim > 256 || (head_dim & 1)) { padt_set_error("padt_llm_qkv_post: head_dim must be even and <= 256"); return -1; }
-    QkvPostArgs a{(const bf16_t*)qkv, ld_qkv, pos3, sample, slot, lens, (const float*)inv_freq, (bf16_t*)q_out, ld_q,
-                  (bf16_t*)k_pack, ld_kp, (bf16_t*)k_cache, (bf16_t*)vt_cache, (int)T, n_heads, n_kv_heads, head_dim,
+    QkvPostArgs a{(const x16_t*)qkv, ld_qkv, pos3, sample, slot, lens, (const float*)inv_freq, (x16_t*)q_out, ld_q,
+                  (x16_t*)k_pack, ld_kp, (x16_t*)k_cache, (x16_t*)vt_cache, (int)T, n_heads, n_kv_heads, head_dim,
                   s_max, sec0, sec1};
     hipLaunchKernelGGL(llm_qkv_post_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, a);
     PADT_CHECK_LAUNCH("llm_qkv_post");
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent (or bf16-decoder-only): compiled once
 // ---------------------------------------------------------------------------------------------------------------------
 // PaDT mask head tail (padt_decoder.py:241-274): e2[(n,a,b)][(c,d,:)] · mask_tok[obj(n)] → masks[obj][4*row+2a+c][4*col+2b+d]
 // e2: [4*Np][4*dm] bf16 (row = patch*4 + a*2 + b, col = (c*2+d)*dm + k), tok: [n_obj][dm] bf16.
-__global__ __launch_bounds__(256) void mask_scatter_kernel(const bf16_t* __restrict__ e2, long ld_e2,
-                                                           const bf16_t* __restrict__ tok, long ld_tok,
+__global__ __launch_bounds__(256) void mask_scatter_kernel(const x16_t* __restrict__ e2, long ld_e2,
+                                                           const x16_t* __restrict__ tok, long ld_tok,
                                                            const int* __restrict__ cu_patch, const int* __restrict__ obj_w,
                                                            float* __restrict__ masks, int n_obj, int Hm4, int Wm4, int dm) {
     // one thread per output logit: index = ((patch*4 + ab)*4 + cd)
@@ -600,10 +605,10 @@ __global__ __launch_bounds__(256) void mask_scatter_kernel(const bf16_t* __restr
         const int pin = (int)(patch - cu_patch[obj]);
         const int W = obj_w[obj];
         const int prow = pin / W, pcol = pin % W;
-        const bf16_t* e = e2 + (patch * 4 + ab) * ld_e2 + (long)cd * dm;
-        const bf16_t* tk = tok + (long)obj * ld_tok;
+        const x16_t* e = e2 + (patch * 4 + ab) * ld_e2 + (long)cd * dm;
+        const x16_t* tk = tok + (long)obj * ld_tok;
         float acc = 0.f;
-        for (int k = 0; k < dm; ++k) acc += bf2f(e[k]) * bf2f(tk[k]);
+        for (int k = 0; k < dm; ++k) acc += x2f(e[k]) * x2f(tk[k]);
         const int a = ab >> 1, bb = ab & 1, c = cd >> 1, d = cd & 1;
         masks[((long)obj * Hm4 + prow * 4 + a * 2 + c) * Wm4 + pcol * 4 + bb * 2 + d] = acc;
     }
@@ -615,8 +620,8 @@ extern "C" int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const
     if (n_obj <= 0 || total_patches <= 0) return 0;
     long blocks = (total_patches * 16 + 255) / 256;
     if (blocks > 16384) blocks = 16384;
-    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)e2,
-                       ld_e2, (const bf16_t*)mask_tok, ld_tok, cu_patch, obj_w, (float*)masks_f32, n_obj, Hm4, Wm4, dm);
+    hipLaunchKernelGGL(mask_scatter_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const x16_t*)e2,
+                       ld_e2, (const x16_t*)mask_tok, ld_tok, cu_patch, obj_w, (float*)masks_f32, n_obj, Hm4, Wm4, dm);
     PADT_CHECK_LAUNCH("mask_scatter");
     return 0;
 }
@@ -675,6 +680,8 @@ extern "C" int padt_mask_upsample_binarize(void* stream, const void* masks_f32, 
     return 0;
 }
 
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Image front-end tail (HF Qwen2-VL image processor: rescale → normalize → patchify,
 // image_processing_pil_qwen2_vl.py _preprocess / patchify): uint8 (H, W, 3) → pixel_values rows [C=3][T=2][14][14] in
@@ -694,12 +701,12 @@ __global__ __launch_bounds__(256) void patchify_normalize_kernel(const unsigned 
         const int px = e % patch, py = (e / patch) % patch, c = e / (patch * patch * temporal);
         const unsigned char u = img[((long)(y0 + py) * W + (x0 + px)) * 3 + c];
         const float v = lut[c * 256 + u];
-        if (out_bf16) reinterpret_cast<bf16_t*>(out)[(long)p * ld_out + e] = f2bf(v);
+        if (out_bf16) reinterpret_cast<x16_t*>(out)[(long)p * ld_out + e] = f2x(v);
         else reinterpret_cast<float*>(out)[(long)p * ld_out + e] = v;
     }
 }
 
-extern "C" int padt_patchify_normalize(void* stream, const void* img_u8, int H, int W, const void* lut_f32, void* out,
+extern "C" int PADT_TWIN(padt_patchify_normalize)(void* stream, const void* img_u8, int H, int W, const void* lut_f32, void* out,
                                        long ld_out, int out_bf16, int patch, int merge, int temporal) {
     if (H <= 0 || W <= 0) return 0;
     if (patch <= 0 || merge <= 0 || temporal <= 0 || H % (patch * merge) || W % (patch * merge)) {
@@ -713,6 +720,7 @@ extern "C" int padt_patchify_normalize(void* stream, const void* img_u8, int H, 
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent (or bf16-decoder-only): compiled once
 // ---------------------------------------------------------------------------------------------------------------------
 // Result record of the data-parallel exchange (pipeline.pack_results, SURVEY.md §8e: the decoded boxes / masks of one batch as ONE
 // fixed-capacity record, so that one all-gather moves it).  32-bit words:
@@ -764,17 +772,19 @@ extern "C" int padt_pack_results(void* stream, void* out_i32, long words, int n,
     return 0;
 }
 
+#endif
+
 // ---------------------------------------------------------------------------------------------------------------------
 // Per-row fp8 quantisation of activations for the fp8 x fp8 MFMA GEMM (padt_gemm_fp8): x8[row] = e4m3(x[row] / s), s = 2^ceil(log2(amax / 448))
 // (a power of two: the division is exact, the only rounding is the e4m3 one), rs[row] = s, or s * rsqrt(mean(x^2) + eps) when the row also
 // feeds a folded RMSNorm (norm_eps >= 0) — the GEMM scales its accumulator with rs[m] * weight_scale[n].  One wave per row, two passes (the
 // second one re-reads the row from L2).
-__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __restrict__ x, long ldx, unsigned char* __restrict__ y, long ldy,
+__global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const x16_t* __restrict__ x, long ldx, unsigned char* __restrict__ y, long ldy,
                                                              float* __restrict__ rs, int rows, int K, float norm_eps) {
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
     if (row >= rows) return;
-    const bf16_t* xr = x + (long)row * ldx;
+    const x16_t* xr = x + (long)row * ldx;
     float amax = 0.f, ss = 0.f;
     for (int c = lane * 8; c < K; c += 512) {
         float f[8];
@@ -784,6 +794,10 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
     }
     amax = wave_max(amax);
     ss = wave_sum(ss);
+    // a non-finite row (inf or NaN anywhere: fmaxf drops NaNs, the sum of squares does not) must not turn into a garbage scale and finite-looking
+    // codes: its row scale becomes NaN, so the GEMM's accumulator row is NaN like the bf16 path's would be
+    const bool finite = ss < INFINITY;
+    if (!finite) amax = 0.f;
     int e = 0;
     (void)frexpf(amax * (1.0f / 448.0f), &e);                     // amax / 448 = m * 2^e, m in [0.5, 1)  →  2^e >= amax / 448
     float scale = (amax > 0.f) ? ldexpf(1.0f, e) : 1.0f;
@@ -800,18 +814,19 @@ __global__ __launch_bounds__(256) void quant_rows_fp8_kernel(const bf16_t* __res
         hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6] * inv, f[7] * inv, hi, true);
         *reinterpret_cast<u32x2*>(yr + c) = u32x2{(unsigned)lo, (unsigned)hi};
     }
-    if (lane == 0) rs[row] = (norm_eps >= 0.f) ? scale * rsqrtf(ss / (float)K + norm_eps) : scale;
+    if (lane == 0) rs[row] = !finite ? __builtin_nanf("") : ((norm_eps >= 0.f) ? scale * rsqrtf(ss / (float)K + norm_eps) : scale);
 }
 
-extern "C" int padt_quant_rows_fp8(void* stream, const void* x, long ldx, void* x8, long ld8, void* row_scale_f32, long rows, long K, float norm_eps) {
+extern "C" int PADT_TWIN(padt_quant_rows_fp8)(void* stream, const void* x, long ldx, void* x8, long ld8, void* row_scale_f32, long rows, long K, float norm_eps) {
     if (rows <= 0) return 0;
-    if ((K & 7) || (ldx & 7) || (ld8 & 7) || ((uintptr_t)x & 15) || ((uintptr_t)x8 & 7) || ld8 < K) {
-        padt_set_error("padt_quant_rows_fp8: K, ldx, ld8 multiples of 8, x 16-byte / x8 8-byte aligned, ld8 >= K");
+    if ((K & 7) || (ldx & 7) || (ld8 & 7) || ((uintptr_t)x & 15) || ((uintptr_t)x8 & 7) || ld8 < K || rows > 0x7fffffffL || K > 0x7fffffffL) {
+        padt_set_error("padt_quant_rows_fp8: K, ldx, ld8 multiples of 8, x 16-byte / x8 8-byte aligned, ld8 >= K, rows and K below 2^31");
         return -1;
     }
-    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+    hipLaunchKernelGGL(quant_rows_fp8_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const x16_t*)x, ldx,
                        (unsigned char*)x8, ld8, (float*)row_scale_f32, (int)rows, (int)K, norm_eps);
     PADT_CHECK_LAUNCH("quant_rows_fp8");
     return 0;
 }
 
+}  // namespace PADT_NS

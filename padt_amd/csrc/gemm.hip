@@ -19,14 +19,41 @@
 #include <stdlib.h>
 #include <type_traits>
 
+extern "C" void padt_set_error(const char* msg);
+
+// Measurement surface: while a slot array is registered, every tile-GEMM call (M > 64) of this process — of either operand-type
+// instantiation — takes the next {start, end} slot and its kernels record their first block start / last block end in 100 MHz ticks.  The
+// caller initialises the slots to {~0, 0}.  The call counter is atomic (lanes of a pipelined runner launch GEMMs from one host thread today,
+// but nothing in the ABI says so).  Do not register while a graph is being captured: the slot pointer would be baked into it (the
+// captured decode step has no tile GEMM).  bench.py's in-situ roofline leg only.
+#include <atomic>
+struct GemmProfState { std::atomic<unsigned long long*> slots{nullptr}; std::atomic<long> cap{0}, n{0}; };
+#if !PADT_OP16_F16
+GemmProfState padt_g_gemm_prof;
+extern "C" long padt_gemm_profile(void* slots_u64, long capacity) {
+    const long used = padt_g_gemm_prof.n.exchange(0);
+    padt_g_gemm_prof.cap.store(slots_u64 ? capacity : 0);
+    padt_g_gemm_prof.slots.store((unsigned long long*)slots_u64);
+    return used;                                                  // calls recorded since the previous registration
+}
+extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
+    const long ticket_bytes = (((N + 15) / 16 * 4 + 255) / 256) * 256;
+    return ticket_bytes + (N + 15) / 16 * (long)split_k * 8 * 64 * 16;   // up to 8 row blocks (128 rows) of fp32 fragments
+}
+#else
+extern GemmProfState padt_g_gemm_prof;
+#endif
+
+namespace PADT_NS {
+
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
 
 struct GemmArgs {
-    const bf16_t* A; long lda;
-    const bf16_t* W; long ldw;
-    const bf16_t* bias;          // [N] or null
+    const x16_t* A; long lda;
+    const x16_t* W; long ldw;
+    const x16_t* bias;          // [N] or null
     void* C; long ldc;           // bf16 or f32
-    const bf16_t* R; long ldr;   // residual (EPI_RESID)
+    const x16_t* R; long ldr;   // residual (EPI_RESID)
     int M, N, K;
     float* ws = nullptr;         // split-K (skinny kernel, gridDim.y > 1): partial accumulators [nb][split][frags][64][4]
     int* ticket = nullptr;       //          and one completion ticket per n-block (zero between launches)
@@ -39,19 +66,16 @@ struct GemmArgs {
     int r_f32 = 0;               // EPI_RESID: R is fp32 [M][ldr] (fp32 residual stream; with OUT_F32)
     long lo_off = 0;             // bf16 output: also store lo = bf16(x - hi) at C + lo_off (split-precision pair, padt_gemm_bf16_ex)
     unsigned long long* prof = nullptr;   // tile kernels: optional in-kernel launch timing slot (padt_gemm_profile)
-    bf16_t* C2 = nullptr;        // fp32 output: optional bf16 mirror of C (fp32 residual stream → the next projection's A operand), row-major
+    x16_t* C2 = nullptr;        // fp32 output: optional bf16 mirror of C (fp32 residual stream → the next projection's A operand), row-major
     long ldc2 = 0;               //   or, with c_pack, in the fragment-packed activation layout (decode steps)
 };
 
 // bf16 split pair of 4 fp32 values: hi = bf16(x), lo = bf16(x - hi)  (hi + lo carries 16 mantissa bits)
 PADT_DEV void split4(const float* o, u32x2& hi, u32x2& lo) {
-    hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    hi = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
     float h[4];
-    h[0] = __builtin_bit_cast(float, hi[0] << 16);
-    h[1] = __builtin_bit_cast(float, hi[0] & 0xffff0000u);
-    h[2] = __builtin_bit_cast(float, hi[1] << 16);
-    h[3] = __builtin_bit_cast(float, hi[1] & 0xffff0000u);
-    lo = u32x2{pack2bf(o[0] - h[0], o[1] - h[1]), pack2bf(o[2] - h[2], o[3] - h[3])};
+    unpack4x(hi, h);
+    lo = u32x2{pack2x(o[0] - h[0], o[1] - h[1]), pack2x(o[2] - h[2], o[3] - h[3])};
 }
 
 // offset of element (m, n) of a row-major or fragment-packed [rows][ld] activation matrix (n % 4 == 0 keeps 4 elements together)
@@ -63,12 +87,7 @@ __device__ __attribute__((aligned(16))) unsigned int g_zero_page[64];   // 256 B
 
 // ---------------------------------------------------------------------------------------------------------------------
 // epilogue for one 16x16 fragment held "swapped": lane has row m, columns n..n+3 in v[0..3]
-PADT_DEV void unpack4(u32x2 v, float* f) {
-    f[0] = __builtin_bit_cast(float, v[0] << 16);
-    f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
-    f[2] = __builtin_bit_cast(float, v[1] << 16);
-    f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
-}
+PADT_DEV void unpack4(u32x2 v, float* f) { unpack4x(v, f); }
 
 template <int EPI, bool OUT_F32>
 PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
@@ -84,7 +103,7 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         for (int r = 0; r < 4; ++r) o[r] *= (n + r < p.N) ? p.cs[n + r] : 1.f;
     }
     if (n + 3 < p.N) {                                   // full fragment: 8-byte bias / residual loads, one vector store
-        const bf16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const bf16_t*>(g_zero_page);
+        const x16_t* bp = p.bias ? p.bias + n : reinterpret_cast<const x16_t*>(g_zero_page);
         const u32x2 braw = *reinterpret_cast<const u32x2*>(bp);     // both loads are issued before either is consumed
         u32x2 rraw = u32x2{0u, 0u};
         f32x4 rf = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -111,30 +130,31 @@ PADT_DEV void store_frag(const GemmArgs& p, int m, int n, f32x4 v) {
         }
         if (OUT_F32) {
             *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
-            if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + act_index(m, n, p.ldc2, p.c_pack)) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+            if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + act_index(m, n, p.ldc2, p.c_pack)) =
+                u32x2{pack2x(o[0] * PADT_STREAM_SCALE, o[1] * PADT_STREAM_SCALE), pack2x(o[2] * PADT_STREAM_SCALE, o[3] * PADT_STREAM_SCALE)};
         }
         else if (p.lo_off) {
             u32x2 hi, lo;
             split4(o, hi, lo);
-            bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+            x16_t* c = reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + n;
             *reinterpret_cast<u32x2*>(c) = hi;
             *reinterpret_cast<u32x2*>(c + p.lo_off) = lo;
         }
-        else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + act_index(m, n, p.ldc, p.c_pack)) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+        else *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + act_index(m, n, p.ldc, p.c_pack)) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
         return;
     }
     for (int r = 0; r < 4 && n + r < p.N; ++r) {         // ragged N tail: scalar
         float x = o[r];
-        if (p.bias) x += bf2f(p.bias[n + r]);
+        if (p.bias) x += x2f(p.bias[n + r]);
         if (EPI == EPI_GELU) x = gelu_erf(x);
-        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
+        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : x2f(p.R[(long)m * p.ldr + n + r]);
         if (OUT_F32) {
             reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-            if (p.C2) p.C2[act_index(m, n + r, p.ldc2, p.c_pack)] = f2bf(x);
+            if (p.C2) p.C2[act_index(m, n + r, p.ldc2, p.c_pack)] = f2x(x * PADT_STREAM_SCALE);
         } else {
-            const bf16_t h = f2bf(x);
-            reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = h;
-            if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(h));
+            const x16_t h = f2x(x);
+            reinterpret_cast<x16_t*>(p.C)[(long)m * p.ldc + n + r] = h;
+            if (p.lo_off) reinterpret_cast<x16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2x(x - x2f(h));
         }
     }
 }
@@ -146,7 +166,7 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     const int blk = n_gate >> 5, in = n_gate & 15;
     const int no = blk * 16 + in;                       // output column
     float gb[4], ub[4];
-    const bf16_t* bp = p.bias ? p.bias + n_gate : reinterpret_cast<const bf16_t*>(g_zero_page);
+    const x16_t* bp = p.bias ? p.bias + n_gate : reinterpret_cast<const x16_t*>(g_zero_page);
     unpack4(*reinterpret_cast<const u32x2*>(bp), gb);
     unpack4(*reinterpret_cast<const u32x2*>(bp + 16), ub);
     float o[4];
@@ -155,8 +175,8 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     if (p.cs) { gs = *reinterpret_cast<const f32x4*>(p.cs + n_gate); us = *reinterpret_cast<const f32x4*>(p.cs + n_gate + 16); }
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = silu(g[r] * sc * gs[r] + gb[r]) * (u[r] * sc * us[r] + ub[r]);
-    bf16_t* c = reinterpret_cast<bf16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
-    *reinterpret_cast<u32x2*>(c) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+    x16_t* c = reinterpret_cast<x16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
+    *reinterpret_cast<u32x2*>(c) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -175,7 +195,7 @@ template <int BK> struct TileCfg {
 };
 
 template <int BK>
-PADT_DEV void stage_tile(const bf16_t* __restrict__ base, long ld, int row0, int nrows, int k0, int K,
+PADT_DEV void stage_tile(const x16_t* __restrict__ base, long ld, int row0, int nrows, int k0, int K,
                          char* lds_tile, int wave, int lane) {
     using T = TileCfg<BK>;
     // LDS slot (r, s) holds global chunk swz(r, s): the DMA image is lane-linear, so the swizzle goes on the SOURCE address
@@ -237,7 +257,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 #pragma unroll
         for (int kk = 0; kk < BK / 32; ++kk) {
             const int j = kk * 4 + fq;
-            bf16x8 af[4], wf[4];
+            x16x8 af[4], wf[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) {
                 const int ra = wm * 64 + i * 16 + frow;
@@ -258,7 +278,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
         // block-uniform fast path: no per-fragment bounds checks; every bias / residual load is issued up front
         const int mb = m0 + wm * 64 + frow, nb = n0 + wn * 64 + fq * 4;
         u32x2 braw[4], rraw[4][4];
-        const bf16_t* bp = p.bias ? p.bias + nb : reinterpret_cast<const bf16_t*>(g_zero_page);
+        const x16_t* bp = p.bias ? p.bias + nb : reinterpret_cast<const x16_t*>(g_zero_page);
         const int bstep = p.bias ? 16 : 0;
 #pragma unroll
         for (int ni = 0; ni < 4; ++ni) braw[ni] = *reinterpret_cast<const u32x2*>(bp + ni * bstep);
@@ -293,7 +313,7 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
                 }
                 const long off = (long)(mb + mi * 16) * p.ldc + nb + ni * 16;
                 if (OUT_F32) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
-                else *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + off) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + off) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
             }
         return;
     }
@@ -351,7 +371,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 #pragma unroll
     for (int j = 0; j < MT; ++j) ss[j] = 0.f;
 
-    const bf16_t* wrow[NT];
+    const x16_t* wrow[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
         int n = n0 + i * 16 + frow;
@@ -361,7 +381,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     // x fragment of K-step ks = 16 bytes at xrow[j] + ks * xstep.  Row-major activations: 16 rows x 64 B per wave
     // instruction (address unit at a quarter rate — the limiter once 32 rows are decoded together); packed activations
     // (a_pack): the same fragment is 1 KiB contiguous in lane order.
-    const bf16_t* xrow[MT];
+    const x16_t* xrow[MT];
     bool xok[MT];
     const int xstep = p.a_pack ? 512 : 32;
 #pragma unroll
@@ -383,7 +403,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     static_assert(U % KG == 0, "U is a whole number of K-step pairs");
     const int g_stride = NW * gridDim.y;
     for (int gi = blockIdx.y * NW + wave; gi * KG < nks; gi += g_stride * GPI) {
-        bf16x8 wf[U][NT], xf[U][MT];
+        x16x8 wf[U][NT], xf[U][MT];
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ks = (gi + (u / KG) * g_stride) * KG + (u % KG);
@@ -397,14 +417,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
                                                   (((long)(n0 / 16 + i) * (p.ldw / 64) + (ks >> 1)) * 64 + lane) * 16;
                         u32x4 q = u32x4{0u, 0u, 0u, 0u};
                         if (ks < nks) q = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wq));
-                        wf[u][i] = fp8x8_to_bf16x8(q[0], q[1]);
-                        wf[u + (U > 1 ? 1 : 0)][i] = fp8x8_to_bf16x8(q[2], q[3]);
+                        wf[u][i] = fp8x8_to_x16x8(q[0], q[1]);
+                        wf[u + (U > 1 ? 1 : 0)][i] = fp8x8_to_x16x8(q[2], q[3]);
                     }
                     continue;
                 }
                 // PACKED: tile (n16, k32) of the fragment-packed image is 1 KiB in lane order → one contiguous wave load
-                const bf16_t* wp = PACKED ? p.W + ((long)(n0 / 16 + i) * (p.ldw / 32) + ks) * 512 + lane * 8 : wrow[i] + k;
-                wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wp)) : zero_frag();
+                const x16_t* wp = PACKED ? p.W + ((long)(n0 / 16 + i) * (p.ldw / 32) + ks) * 512 + lane * 8 : wrow[i] + k;
+                wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const x16x8*>(wp)) : zero_frag();
             }
 #pragma unroll
             for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
@@ -530,28 +550,18 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 
 // ---------------------------------------------------------------------------------------------------------------------
 // host side
-extern "C" void padt_set_error(const char* msg);
 // gemm256.hip: phase-pipelined 256x256 kernel for large-N shapes; returns 0 if it took the launch
-extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+extern "C" int PADT_TWIN(padt_gemm256_try)(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
                                 void* C2, long ldc2, unsigned long long* prof);
 
-// Measurement surface: while a slot array is registered, every tile-GEMM call (M > 64) of this process takes the next {start, end} slot
-// (host-side counter) and its kernels record their first block start / last block end in 100 MHz ticks.  The caller initialises the slots
-// to {~0, 0}.  Process-wide, not thread-safe: bench.py's in-situ roofline leg only.
-static unsigned long long* g_prof_slots = nullptr;
-static long g_prof_cap = 0, g_prof_n = 0;
-extern "C" long padt_gemm_profile(void* slots_u64, long capacity) {
-    const long used = g_prof_n;
-    g_prof_slots = (unsigned long long*)slots_u64;
-    g_prof_cap = slots_u64 ? capacity : 0;
-    g_prof_n = 0;
-    return used;                                                  // calls recorded since the previous registration
-}
 static unsigned long long* next_prof_slot() {
-    if (!g_prof_slots || g_prof_n >= g_prof_cap) return nullptr;
-    return g_prof_slots + 2 * (g_prof_n++);
+    unsigned long long* slots = padt_g_gemm_prof.slots.load();
+    if (!slots) return nullptr;
+    const long i = padt_g_gemm_prof.n.fetch_add(1);
+    if (i >= padt_g_gemm_prof.cap.load()) { padt_g_gemm_prof.n.store(padt_g_gemm_prof.cap.load()); return nullptr; }
+    return slots + 2 * i;
 }
 
 template <int EPI, bool F32, int BK>
@@ -666,28 +676,28 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         return -1;
     }
     unsigned long long* prof = (M > 64) ? next_prof_slot() : nullptr;
-    if (M > 64 && padt_gemm256_try(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
+    if (M > 64 && PADT_TWIN(padt_gemm256_try)(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
             return 0;
         }
         // a peeled ragged tail (<= 64 rows): the rest of this function streams it through the skinny kernel
-        A = (const bf16_t*)A + done * lda;
-        C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((bf16_t*)C + done * ldc);
-        if (R) R = resid_f32 ? (const void*)((const float*)R + done * ldr) : (const void*)((const bf16_t*)R + done * ldr);
+        A = (const x16_t*)A + done * lda;
+        C = out_f32 ? (void*)((float*)C + done * ldc) : (void*)((x16_t*)C + done * ldc);
+        if (R) R = resid_f32 ? (const void*)((const float*)R + done * ldr) : (const void*)((const x16_t*)R + done * ldr);
         if (rs) rs += done;
-        if (C2) C2 = (bf16_t*)C2 + done * ldc2;
+        if (C2) C2 = (x16_t*)C2 + done * ldc2;
         if (rp.cos) { rp.cos += done * rp.ld; rp.sin += done * rp.ld; }
         M -= done;
     }
-    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
+    GemmArgs a{(const x16_t*)A, lda, (const x16_t*)W, ldw, (const x16_t*)bias, C, ldc, (const x16_t*)R, ldr,
                (int)M, (int)N, (int)K};
     a.rs = rs;
     a.rope = rp;
     a.r_f32 = resid_f32;
     a.lo_off = lo_off;
-    a.C2 = (bf16_t*)C2;
+    a.C2 = (x16_t*)C2;
     a.ldc2 = ldc2;
     a.prof = (M > 64) ? prof : nullptr;                           // a peeled <= 64-row tail runs on the skinny kernel: not part of the tile-GEMM time
     hipStream_t s = (hipStream_t)stream;
@@ -706,7 +716,7 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
     return 0;
 }
 
-extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+extern "C" int PADT_SYM(padt_gemm_, )(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                               long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                               const void* row_scale) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
@@ -716,17 +726,19 @@ extern "C" int padt_gemm_bf16(void* stream, const void* A, long lda, const void*
 // Extended epilogues for the split-precision PaDT decoder (decoder_hp.hip): resid_f32 — R (and C: out_f32 must be set) is the
 // fp32 residual stream; lo_off != 0 — bf16 output stored as a (hi, lo) pair, hi at C[m][n], lo = bf16(x - hi) at C[m][lo_off + n],
 // i.e. directly the [hi | lo] A operand (K' = 2N) of the next GEMM whose weight image is [W | W].
+#if !PADT_OP16_F16
 extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                  long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                  const void* row_scale, int resid_f32, long lo_off) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
                           RopeEpi{nullptr, nullptr, 0, 0, 0}, resid_f32, lo_off);
 }
+#endif
 
 // fp32 residual stream: X32[m][n] += (A · W^T)[m][n] + bias[n] in place, and Xb = bf16(X32) (row-major mirror, may be null) — the residual
 // adds of the ViT block (HF:318-320) and the LLM layer (HF:741,757) with the stream kept in fp32 between kernels and the next projection's
 // bf16 A operand produced by the same epilogue.
-extern "C" int padt_gemm_resid32(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx,
+extern "C" int PADT_TWIN(padt_gemm_resid32)(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* X32, long ldx,
                                  void* Xb, long ldxb, long M, long N, long K) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, X32, ldx, X32, ldx, M, N, K, EPI_RESID, 1, nullptr,
                           RopeEpi{nullptr, nullptr, 0, 0, 0}, 1, 0, Xb, ldxb);
@@ -734,7 +746,7 @@ extern "C" int padt_gemm_resid32(void* stream, const void* A, long lda, const vo
 
 // C = rope(row_scale[m] * (A · W^T) + bias): the rotate-half RoPE of the leading `rope_cols` output columns fused into the
 // epilogue (ViT qkv projection: q and k columns, pair-interleaved per head by a load-time permutation of W's rows).
-extern "C" int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+extern "C" int PADT_SYM(padt_gemm_rope_, )(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                    long ldc, long M, long N, long K, const void* row_scale, const void* rope_cos,
                                    const void* rope_sin, long ld_cs, long rope_cols, int head_dim) {
     if (rope_cos == nullptr || rope_sin == nullptr || head_dim <= 0 || (head_dim & 3) || (rope_cols & 3) || rope_cols > N ||
@@ -750,7 +762,7 @@ extern "C" int padt_gemm_rope_bf16(void* stream, const void* A, long lda, const 
 // rstd = rsqrt(mean(A[m]^2) + eps) and W already carries the norm weight (W·diag(g), folded at load time).
 // epilogue 0 (none) or 3 (SwiGLU).  Replaces {input_layernorm → q/k/v_proj} and {post_attention_layernorm → gate/up_proj}
 // (HF:727-757) for the single-token decode step.
-extern "C" int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, float eps, const void* W, long ldw,
+extern "C" int PADT_SYM(padt_gemm_rmsnorm_, )(void* stream, const void* A, long lda, float eps, const void* W, long ldw,
                                       const void* bias, void* C, long ldc, long M, long N, long K, int epilogue) {
     if (M <= 0 || N <= 0) return 0;
     if (M > 64 || K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || ((uintptr_t)A & 15) || ((uintptr_t)W & 15)) {
@@ -762,7 +774,7 @@ extern "C" int padt_gemm_rmsnorm_bf16(void* stream, const void* A, long lda, flo
         padt_set_error("padt_gemm_rmsnorm_bf16: bad C/ldc/epilogue (0 or 3; SwiGLU needs N % 32 == 0)");
         return -1;
     }
-    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K};
+    GemmArgs a{(const x16_t*)A, lda, (const x16_t*)W, ldw, (const x16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K};
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_SWIGLU) dispatch_norm<EPI_SWIGLU>(a, eps, s);
     else dispatch_norm<EPI_NONE>(a, eps, s);
@@ -781,10 +793,6 @@ static void dispatch_packed(const GemmArgs& a, float eps, hipStream_t s) {
 }
 
 static long splitk_ticket_bytes(long N) { return (((N + 15) / 16 * 4 + 255) / 256) * 256; }
-
-extern "C" long padt_gemm_splitk_workspace(long N, int split_k) {
-    return splitk_ticket_bytes(N) + (N + 15) / 16 * (long)split_k * 8 * 64 * 16;   // up to 8 row blocks (128 rows) of fp32 fragments
-}
 
 static int gemm_packed_impl(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
                             long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
@@ -817,10 +825,10 @@ static int gemm_packed_impl(void* stream, const void* A, long lda, const void* W
         padt_set_error("padt_gemm_packed_bf16: bad C/ldc/bias/epilogue (0, 2 without norm, or 3 with N % 32 == 0)");
         return -1;
     }
-    GemmArgs a{(const bf16_t*)A, lda, (const bf16_t*)Wp, Kp, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr, (int)M, (int)N, (int)K};
+    GemmArgs a{(const x16_t*)A, lda, (const x16_t*)Wp, Kp, (const x16_t*)bias, C, ldc, (const x16_t*)R, ldr, (int)M, (int)N, (int)K};
     a.a_pack = act_packed & 1;
     a.c_pack = (act_packed >> 1) & 1;
-    if (resid32) { a.r_f32 = 1; a.C2 = (bf16_t*)Xb; a.ldc2 = ldxb; a.c_pack = 1; }   // c_pack addresses the MIRROR here (R / C are fp32 row-major)
+    if (resid32) { a.r_f32 = 1; a.C2 = (x16_t*)Xb; a.ldc2 = ldxb; a.c_pack = 1; }   // c_pack addresses the MIRROR here (R / C are fp32 row-major)
     if (split_k > 1) {
         a.ticket = reinterpret_cast<int*>(workspace);
         a.ws = reinterpret_cast<float*>(reinterpret_cast<char*>(workspace) + splitk_ticket_bytes(N));
@@ -848,7 +856,7 @@ static int gemm_packed_impl(void* stream, const void* A, long lda, const void* W
     return 0;
 }
 
-extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
+extern "C" int PADT_SYM(padt_gemm_packed_, )(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* bias, void* C,
                                      long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
                                      int split_k, void* workspace, int act_packed) {
     return gemm_packed_impl(stream, A, lda, Wp, Kp, bias, C, ldc, R, ldr, M, N, K, epilogue, norm_eps, split_k, workspace, act_packed, nullptr);
@@ -857,7 +865,7 @@ extern "C" int padt_gemm_packed_bf16(void* stream, const void* A, long lda, cons
 // Same decode-step projection over fp8 weights (BASELINE configs[4], the 7B "fp8 MFMA weight path"): Wq = OCP e4m3 bytes in the fp8
 // fragment-packed image [N/16][Kp/64][64 lanes][16 B] (ops.pack_weight_fp8), scales fp32 [N] (one per weight row; powers of two in
 // weights.py, so the bf16 prefill copy of the same matrix is bit-consistent).  C = epi(rstd?(A) * scale[n] * (A · Wq^T) + bias).
-extern "C" int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias,
+extern "C" int PADT_TWIN(padt_gemm_packed_fp8)(void* stream, const void* A, long lda, const void* Wq, long Kp, const void* scales, const void* bias,
                                     void* C, long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, float norm_eps,
                                     int split_k, void* workspace, int act_packed) {
     if (scales == nullptr) { padt_set_error("padt_gemm_packed_fp8: scales are required"); return -1; }
@@ -868,7 +876,7 @@ extern "C" int padt_gemm_packed_fp8(void* stream, const void* A, long lda, const
 // Decode-step residual projection (o_proj, down_proj: HF:741,757 at one token per row) over the fp32 residual stream:
 // X32[m][n] += scale?[n] * (A · W^T)[m][n]  in place (fp32 row-major), Xb = bf16(X32) in the fragment-packed activation layout — the A operand
 // of the next projection.  Wp: bf16 fragment-packed weights, or (scales != null) the fp8 image of padt_gemm_packed_fp8.
-extern "C" int padt_gemm_packed_resid32(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* scales, void* X32, long ldx,
+extern "C" int PADT_TWIN(padt_gemm_packed_resid32)(void* stream, const void* A, long lda, const void* Wp, long Kp, const void* scales, void* X32, long ldx,
                                         void* Xb, long ldxb, long M, long N, long K, int split_k, void* workspace, int a_packed) {
     if (Xb == nullptr) { padt_set_error("padt_gemm_packed_resid32: the packed mirror is required"); return -1; }
     return gemm_packed_impl(stream, A, lda, Wp, Kp, nullptr, X32, ldx, X32, ldx, M, N, K, EPI_RESID, -1.0f, split_k, workspace, a_packed ? 1 : 0,
@@ -876,12 +884,13 @@ extern "C" int padt_gemm_packed_resid32(void* stream, const void* A, long lda, c
 }
 
 // fp8 x fp8 MFMA GEMM at prompt length (gemm256.hip, FP8 instantiations of the phase-pipelined kernel); takes a profile slot like every tile GEMM.
-extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+extern "C" int PADT_TWIN(padt_gemm_fp8_impl)(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
                                   const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue,
                                   unsigned long long* prof);
-extern "C" int padt_gemm_fp8(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+extern "C" int PADT_TWIN(padt_gemm_fp8)(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
                              const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue) {
-    return padt_gemm_fp8_impl(stream, A8, lda, W8, ldw, row_scale, col_scale, bias, C, ldc, X32, ldx, Xb, ldxb, M, N, K, epilogue,
+    return PADT_TWIN(padt_gemm_fp8_impl)(stream, A8, lda, W8, ldw, row_scale, col_scale, bias, C, ldc, X32, ldx, Xb, ldxb, M, N, K, epilogue,
                               (M > 64) ? next_prof_slot() : nullptr);
 }
 
+}  // namespace PADT_NS

@@ -19,21 +19,44 @@
 #include <stdlib.h>
 #include <type_traits>
 
+// Dispatch knobs (tests force every tile variant): read from the environment ONCE when the library is loaded; tests and tools that A/B a
+// variant inside one process call padt_gemm_knobs() instead.  -1 keeps a field.  ONE object for both operand-type instantiations.
+struct Knobs256 { int mode, mf, peel, colsplit, group_m; };
+#if !PADT_OP16_F16
+static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
+Knobs256 padt_g_knobs256 = {env_int("PADT_GEMM256", 1), env_int("PADT_GEMM_MF", 0), env_int("PADT_GEMM_PEEL", 1), env_int("PADT_GEMM_COLSPLIT", 1),
+                            env_int("PADT_GEMM_GROUP_M", 8)};
+extern "C" int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m) {
+    if (mode256 >= 0) padt_g_knobs256.mode = mode256;
+    if (mf >= 0) padt_g_knobs256.mf = mf;
+    if (peel >= 0) padt_g_knobs256.peel = peel;
+    if (colsplit >= 0) padt_g_knobs256.colsplit = colsplit;
+    if (group_m >= 1) padt_g_knobs256.group_m = group_m;
+    return 0;
+}
+#else
+extern Knobs256 padt_g_knobs256;
+#endif
+extern "C" void padt_set_error(const char* msg);
+
+namespace PADT_NS {
+static Knobs256& g_knobs = padt_g_knobs256;
+
 enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RESID = 2, EPI_SWIGLU = 3 };
 
 struct Gemm256Args {
-    const bf16_t* A; long lda;
-    const bf16_t* W; long ldw;
-    const bf16_t* bias;
+    const x16_t* A; long lda;
+    const x16_t* W; long ldw;
+    const x16_t* bias;
     void* C; long ldc;
-    const bf16_t* R; long ldr;
+    const x16_t* R; long ldr;
     int M, N, K;
     const float* rs;                // optional per-row scale of the accumulator (fused RMSNorm rstd), applied before bias
     RopeEpi rope;                   // optional fused RoPE of the leading output columns (EPI_NONE)
     int group_m;                    // tile rasterisation: ids walk down group_m tile rows, then to the next tile column
     int r_f32;                      // EPI_RESID: R is fp32 [M][ldr] (with OUT_F32)
     long lo_off;                    // bf16 output: also store lo = bf16(x - hi) at C + lo_off (padt_gemm_bf16_ex)
-    bf16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
+    x16_t* C2; long ldc2;          // fp32 output: optional bf16 mirror of C (fp32 residual stream + the next GEMM's A operand, padt_gemm_resid32)
     unsigned long long* prof;       // optional {first block start, last block end} in 100 MHz wall-clock ticks (padt_gemm_profile)
     const float* cs;                // optional per-output-column scale of the accumulator (fp8 weights: dequantisation scale of weight row n)
 };
@@ -72,12 +95,12 @@ PADT_DEV void dma2(const char* base, unsigned off0, unsigned off1, char* dst, in
                                      (__attribute__((address_space(3))) void*)(dst + (wave * 2 + 1) * 1024), 16, 0, 0);
 }
 
-PADT_DEV bf16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
+PADT_DEV x16x8 rd(const char* half, int lr, int j) { return ld_frag(half + lr * 128 + ((j ^ (lr & 7)) << 4)); }
 
 // fp8 (OCP e4m3) MFMA 16x16x128: a lane's operand is 32 consecutive K bytes = two 16-byte LDS chunks; both scale exponents 0 select the
 // unscaled v_mfma_f32_16x16x128_f8f6f4 (checked: tools/ubench/f8probe.hip).  2048 FLOP per cycle per SIMD: twice the bf16 16x16x32 rate.
 typedef __attribute__((ext_vector_type(8))) int i32x8;
-PADT_DEV f32x4 mfma_f8(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4 c) {
+PADT_DEV f32x4 mfma_f8(x16x8 a_lo, x16x8 a_hi, x16x8 b_lo, x16x8 b_hi, f32x4 c) {
     const u32x4 al = __builtin_bit_cast(u32x4, a_lo), ah = __builtin_bit_cast(u32x4, a_hi);
     const u32x4 bl = __builtin_bit_cast(u32x4, b_lo), bh = __builtin_bit_cast(u32x4, b_hi);
     const i32x8 a = {(int)al[0], (int)al[1], (int)al[2], (int)al[3], (int)ah[0], (int)ah[1], (int)ah[2], (int)ah[3]};
@@ -85,12 +108,7 @@ PADT_DEV f32x4 mfma_f8(bf16x8 a_lo, bf16x8 a_hi, bf16x8 b_lo, bf16x8 b_hi, f32x4
     return __builtin_amdgcn_mfma_scale_f32_16x16x128_f8f6f4(a, b, c, 0, 0, 0, 0, 0, 0);
 }
 
-PADT_DEV void unpack4b(u32x2 v, float* f) {
-    f[0] = __builtin_bit_cast(float, v[0] << 16);
-    f[1] = __builtin_bit_cast(float, v[0] & 0xffff0000u);
-    f[2] = __builtin_bit_cast(float, v[1] << 16);
-    f[3] = __builtin_bit_cast(float, v[1] & 0xffff0000u);
-}
+PADT_DEV void unpack4b(u32x2 v, float* f) { unpack4x(v, f); }
 }  // namespace
 
 // MF = 16-row MFMA blocks per wave per m-half: tile height 64*MF (256, 192 or 128 rows) x 256 columns.  The shorter tiles
@@ -125,7 +143,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     for (int i = 0; i < 2 * MF; ++i)
 #pragma unroll
         for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-    bf16x8 af[MF][2], b0[2][2], b1[2][2];                          // A sub-tile, B n-half 0 (kept all tile), B n-half 1
+    x16x8 af[MF][2], b0[2][2], b1[2][2];                          // A sub-tile, B n-half 0 (kept all tile), B n-half 1
 
     unsigned offA[2][2], offB[2][2];                              // [half][piece] per-lane byte offsets, see piece_offset
 #pragma unroll
@@ -244,7 +262,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     if (wr_u == 0) __builtin_amdgcn_s_barrier();                  // matches the extra barrier of the lagging group
 
     // ---- epilogue (swapped MFMA: lane holds row m, 4 consecutive columns)
-    const bf16_t* zpage = reinterpret_cast<const bf16_t*>(g_zero_page256);
+    const x16_t* zpage = reinterpret_cast<const x16_t*>(g_zero_page256);
     // FAST PATH (full column tile): straight-line code.  gfx9 counts loads and stores in ONE
     // in-order vmcnt, so an epilogue that loads (bias / residual / RoPE angles) right before every store waits for the previous
     // store's round trip 32 times per wave — measured 12-14 us per tile whatever the number of busy CUs, a third of a K = 1280 GEMM
@@ -318,7 +336,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                             o[r] = FP8 ? silu(acc[mi][ni][r] * (rsc[mi] * csc[ni][r]) + bv[ni][r]) * (acc[mi][ni + 1][r] * (rsc[mi] * csc[ni + 1][r]) + bv[ni + 1][r])
                                        : silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
                         const int no = (n0 >> 1) + wc * 32 + (ni >> 1) * 16 + fq * 4;
-                        if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                        if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
                     }
                 } else {
 #pragma unroll
@@ -353,18 +371,18 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                         if (OUT_F32) {
                             if (live) *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + off) = f32x4{o[0], o[1], o[2], o[3]};
                             if (mirror) *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
-                                u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                                u32x2{pack2x(o[0] * PADT_STREAM_SCALE, o[1] * PADT_STREAM_SCALE), pack2x(o[2] * PADT_STREAM_SCALE, o[3] * PADT_STREAM_SCALE)};
                         } else if (wide) {                        // bf16 tile → LDS in row-major order, written out as full rows below
                             *reinterpret_cast<u32x2*>(smem + (wr * (32 * MF) + mi * 16 + frow) * OUT_PITCH + (wc * 64 + ni * 16 + fq * 4) * 2) =
-                                u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                                u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
                         } else if (live) {
-                            const u32x2 hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                            bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + off;
+                            const u32x2 hi = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
+                            x16_t* cp = reinterpret_cast<x16_t*>(p.C) + off;
                             *reinterpret_cast<u32x2*>(cp) = hi;
                             if (p.lo_off) {                       // split-precision pair: lo = bf16(x - hi)
                                 float hv[4];
                                 unpack4b(hi, hv);
-                                *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2bf(o[0] - hv[0], o[1] - hv[1]), pack2bf(o[2] - hv[2], o[3] - hv[3])};
+                                *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2x(o[0] - hv[0], o[1] - hv[1]), pack2x(o[2] - hv[2], o[3] - hv[3])};
                             }
                         }
                     }
@@ -375,7 +393,7 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
         else if (EPI == EPI_RESID && OUT_F32 && p.r_f32) run(std::false_type{}, std::true_type{});
         else run(std::false_type{}, std::false_type{});
         if (wide || mirror) {
-            bf16_t* cw = mirror ? p.C2 : reinterpret_cast<bf16_t*>(p.C);
+            x16_t* cw = mirror ? p.C2 : reinterpret_cast<x16_t*>(p.C);
             const long ldw_out = mirror ? p.ldc2 : p.ldc;
             // 8-byte fragment stores put 16 x 32-byte pieces on the wire per instruction and cost 4-8 us per tile in the memory system
             // (same instruction count into one 512-byte region: 1.5 us); full 512-byte rows, 16 bytes per lane, do not.
@@ -400,15 +418,15 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
             for (int ni = 0; ni < 4; ni += 2) {
                 const int n = n0 + wc * 64 + ni * 16 + fq * 4;    // interleaved row index of the gate quad
                 if (n >= p.N) continue;
-                const bf16_t* bp = p.bias ? p.bias + n : zpage;
+                const x16_t* bp = p.bias ? p.bias + n : zpage;
                 float gb[4], ub[4], o[4];
                 unpack4b(*reinterpret_cast<const u32x2*>(bp), gb);
                 unpack4b(*reinterpret_cast<const u32x2*>(bp + (p.bias ? 16 : 0)), ub);
 #pragma unroll
                 for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] * rsc + gb[r]) * (acc[mi][ni + 1][r] * rsc + ub[r]);
                 const int no = (n >> 5) * 16 + (n & 15);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + no) =
-                    u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) =
+                    u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
             }
         } else {
 #pragma unroll
@@ -417,21 +435,21 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 if (n + 3 >= p.N) {                               // ragged N tail: scalar
                     for (int r = 0; r < 4 && n + r < p.N; ++r) {
                         float x = acc[mi][ni][r] * rsc;
-                        if (p.bias) x += bf2f(p.bias[n + r]);
+                        if (p.bias) x += x2f(p.bias[n + r]);
                         if (EPI == EPI_GELU) x = gelu_erf(x);
-                        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : bf2f(p.R[(long)m * p.ldr + n + r]);
+                        if (EPI == EPI_RESID) x += p.r_f32 ? reinterpret_cast<const float*>(p.R)[(long)m * p.ldr + n + r] : x2f(p.R[(long)m * p.ldr + n + r]);
                         if (OUT_F32) {
                             reinterpret_cast<float*>(p.C)[(long)m * p.ldc + n + r] = x;
-                            if (p.C2) p.C2[(long)m * p.ldc2 + n + r] = f2bf(x);
+                            if (p.C2) p.C2[(long)m * p.ldc2 + n + r] = f2x(x * PADT_STREAM_SCALE);
                         } else {
-                            const bf16_t hb = f2bf(x);
-                            reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r] = hb;
-                            if (p.lo_off) reinterpret_cast<bf16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2bf(x - bf2f(hb));
+                            const x16_t hb = f2x(x);
+                            reinterpret_cast<x16_t*>(p.C)[(long)m * p.ldc + n + r] = hb;
+                            if (p.lo_off) reinterpret_cast<x16_t*>(p.C)[(long)m * p.ldc + n + r + p.lo_off] = f2x(x - x2f(hb));
                         }
                     }
                     continue;
                 }
-                const bf16_t* bp = p.bias ? p.bias + n : zpage;
+                const x16_t* bp = p.bias ? p.bias + n : zpage;
                 float bv[4], o[4];
                 unpack4b(*reinterpret_cast<const u32x2*>(bp), bv);
                 u32x2 rraw = u32x2{0u, 0u};
@@ -455,15 +473,16 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 }
                 if (OUT_F32) {
                     *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n) = f32x4{o[0], o[1], o[2], o[3]};
-                    if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + (long)m * p.ldc2 + n) = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
+                    if (p.C2) *reinterpret_cast<u32x2*>(p.C2 + (long)m * p.ldc2 + n) =
+                        u32x2{pack2x(o[0] * PADT_STREAM_SCALE, o[1] * PADT_STREAM_SCALE), pack2x(o[2] * PADT_STREAM_SCALE, o[3] * PADT_STREAM_SCALE)};
                 } else {
-                    const u32x2 hi = u32x2{pack2bf(o[0], o[1]), pack2bf(o[2], o[3])};
-                    bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (long)m * p.ldc + n;
+                    const u32x2 hi = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
+                    x16_t* cp = reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + n;
                     *reinterpret_cast<u32x2*>(cp) = hi;
                     if (p.lo_off) {                               // split-precision pair: lo = bf16(x - hi)
                         float hv[4];
                         unpack4b(hi, hv);
-                        *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2bf(o[0] - hv[0], o[1] - hv[1]), pack2bf(o[2] - hv[2], o[3] - hv[3])};
+                        *reinterpret_cast<u32x2*>(cp + p.lo_off) = u32x2{pack2x(o[0] - hv[0], o[1] - hv[1]), pack2x(o[2] - hv[2], o[3] - hv[3])};
                     }
                 }
             }
@@ -508,21 +527,6 @@ static Plan256 plan256(long M, long N, long K, int force_mf, bool allow_peel, bo
     return best;
 }
 
-// Dispatch knobs (tests force every tile variant): read from the environment ONCE when the library is loaded; tests and tools that A/B a
-// variant inside one process call padt_gemm_knobs() instead.  -1 keeps a field.
-struct Knobs256 { int mode, mf, peel, colsplit, group_m; };
-static int env_int(const char* name, int dflt) { const char* e = getenv(name); return e ? atoi(e) : dflt; }
-static Knobs256 g_knobs = {env_int("PADT_GEMM256", 1), env_int("PADT_GEMM_MF", 0), env_int("PADT_GEMM_PEEL", 1), env_int("PADT_GEMM_COLSPLIT", 1),
-                           env_int("PADT_GEMM_GROUP_M", 8)};
-extern "C" int padt_gemm_knobs(int mode256, int mf, int peel, int colsplit, int group_m) {
-    if (mode256 >= 0) g_knobs.mode = mode256;
-    if (mf >= 0) g_knobs.mf = mf;
-    if (peel >= 0) g_knobs.peel = peel;
-    if (colsplit >= 0) g_knobs.colsplit = colsplit;
-    if (group_m >= 1) g_knobs.group_m = group_m;
-    return 0;
-}
-
 template <int EPI, bool F32>
 static void run256(Gemm256Args a, int mf, hipStream_t s) {
     if (mf == 4) launch256_mf<EPI, F32, 4>(a, s);
@@ -565,8 +569,8 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     a2.N = a.N - (int)n1;
     a2.W = a.W + n1 * a.ldw;
     if (a.bias) a2.bias = a.bias + n1;
-    a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((bf16_t*)a.C + c1);
-    if (a.R) a2.R = a.r_f32 ? (const bf16_t*)((const float*)a.R + c1) : a.R + c1;
+    a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((x16_t*)a.C + c1);
+    if (a.R) a2.R = a.r_f32 ? (const x16_t*)((const float*)a.R + c1) : a.R + c1;
     if (a.C2) a2.C2 = a.C2 + c1;
     run256<EPI, F32>(a1, pm.mf, s);
     run256<EPI, F32>(a2, pr.mf, s);
@@ -576,7 +580,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
 // Called by padt_gemm_bf16's dispatcher (gemm.hip) for shapes where the 256^2 tiling pays; arguments already validated.
 // Returns 0 when it took the launch, 1 when the shape should stay on the 128^2 kernel.
 // *rows_done = leading rows it computed (< M when a short ragged tail is left to the caller's skinny kernel).
-extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
+extern "C" int PADT_TWIN(padt_gemm256_try)(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C,
                                 long ldc, const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32,
                                 const float* row_scale, const RopeEpi* rope, long* rows_done, int resid_f32, long lo_off,
                                 void* C2, long ldc2, unsigned long long* prof) {
@@ -590,8 +594,8 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
     }
     if (K % TK) return 1;                                         // no K-tail path in this kernel
     const int group_m = g_knobs.group_m;
-    Gemm256Args a{(const bf16_t*)A, lda, (const bf16_t*)W, ldw, (const bf16_t*)bias, C, ldc, (const bf16_t*)R, ldr,
-                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (bf16_t*)C2, ldc2, prof, nullptr};
+    Gemm256Args a{(const x16_t*)A, lda, (const x16_t*)W, ldw, (const x16_t*)bias, C, ldc, (const x16_t*)R, ldr,
+                  (int)M, (int)N, (int)K, row_scale, *rope, group_m < 1 ? 1 : group_m, resid_f32, lo_off, (x16_t*)C2, ldc2, prof, nullptr};
     hipStream_t s = (hipStream_t)stream;
     switch (epilogue * 2 + (out_f32 ? 1 : 0)) {
         case 0: *rows_done = launch256<EPI_NONE, false>(a, s); break;
@@ -612,7 +616,6 @@ extern "C" int padt_gemm256_try(void* stream, const void* A, long lda, const voi
 // fp32 scale per weight row.  C = epi(rs[m] * cs[n] * (A8 · W8^T) + bias): epilogue 0 → bf16 C; 3 → SwiGLU (W rows interleaved gate16 | up16),
 // bf16 C with N / 2 columns; 2 → the fp32 residual stream: X32 += ..., Xb = bf16(X32) (C unused).  The fp8 products are exact in fp32;
 // accumulation is fp32.  K % 128 == 0, N % 256 == 0, lda / ldw % 16 == 0, 16-byte aligned operands.
-extern "C" void padt_set_error(const char* msg);
 template <int EPI, bool F32>
 static void run256_fp8(const Gemm256Args& a, int mf, hipStream_t s) {
     if (mf == 4) launch256_mf<EPI, F32, 4, true>(a, s);
@@ -620,7 +623,7 @@ static void run256_fp8(const Gemm256Args& a, int mf, hipStream_t s) {
     else launch256_mf<EPI, F32, 2, true>(a, s);
 }
 
-extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
+extern "C" int PADT_TWIN(padt_gemm_fp8_impl)(void* stream, const void* A8, long lda, const void* W8, long ldw, const void* row_scale, const void* col_scale,
                              const void* bias, void* C, long ldc, void* X32, long ldx, void* Xb, long ldxb, long M, long N, long K, int epilogue,
                              unsigned long long* prof) {
     if (M <= 0 || N <= 0) return 0;
@@ -631,7 +634,7 @@ extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const 
     }
     RopeEpi norope{nullptr, nullptr, 0, 0, 0};
     const Plan256 pl = plan256(M, N, K / 2, g_knobs.mf, false, false);      // cost model in K-tiles: a 128-element fp8 K-tile costs what 64 bf16 elements do
-    Gemm256Args a{(const bf16_t*)A8, lda, (const bf16_t*)W8, ldw, (const bf16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K,
+    Gemm256Args a{(const x16_t*)A8, lda, (const x16_t*)W8, ldw, (const x16_t*)bias, C, ldc, nullptr, 0, (int)M, (int)N, (int)K,
                   (const float*)row_scale, norope, g_knobs.group_m < 1 ? 1 : g_knobs.group_m, 0, 0, nullptr, 0, prof, (const float*)col_scale};
     hipStream_t s = (hipStream_t)stream;
     if (epilogue == EPI_NONE) {
@@ -645,7 +648,7 @@ extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const 
             padt_set_error("padt_gemm_fp8: epilogue 2 updates the fp32 stream X32 (ldx % 4, 16-byte aligned) and writes the optional bf16 mirror Xb (ldxb % 8)");
             return -1;
         }
-        a.C = X32; a.ldc = ldx; a.R = (const bf16_t*)X32; a.ldr = ldx; a.r_f32 = 1; a.C2 = (bf16_t*)Xb; a.ldc2 = ldxb;
+        a.C = X32; a.ldc = ldx; a.R = (const x16_t*)X32; a.ldr = ldx; a.r_f32 = 1; a.C2 = (x16_t*)Xb; a.ldc2 = ldxb;
         run256_fp8<EPI_RESID, true>(a, pl.mf, s);
     } else { padt_set_error("padt_gemm_fp8: epilogue 0, 2 or 3"); return -1; }
     hipError_t e = hipGetLastError();
@@ -653,3 +656,4 @@ extern "C" int padt_gemm_fp8_impl(void* stream, const void* A8, long lda, const 
     return 0;
 }
 
+}  // namespace PADT_NS

@@ -16,6 +16,9 @@
 #include <cstdint>
 
 extern "C" void padt_set_error(const char* msg);
+extern "C" long padt_vrt_head_nblk(long vocab, long n_proto);
+
+namespace PADT_NS {
 
 // Generation-config slots kept in DEVICE memory so a captured decode graph does not bake them in
 // (HF generation_config.json: repetition_penalty, eos_token_id list; padt.py:570-580,717,756).
@@ -31,16 +34,16 @@ struct GenCfg {
 };
 
 struct HeadArgs {
-    const bf16_t* h; long ldh;         // [B][D]
-    const bf16_t* E; int V;            // text rows
-    const bf16_t* proto; int NP;       // prototype rows
+    const x16_t* h; long ldh;         // [B][D]
+    const x16_t* E; int V;            // text rows
+    const x16_t* proto; int NP;       // prototype rows
     const int* vrt_off;                // [B+1]
     const int* mode_table;             // [T] or null: 0 free, 1 text rows only, 2 own VRT rows only, 3 force EOS
     const int* step;                   // device step counter (index into mode_table) or null
     float* logits; long ldl;           // optional [B][V+NP]
     float* part_val; int* part_idx;    // [nblk][16*MT]
     int B, D, eos;
-    const bf16_t* Ep;                  // optional fragment-packed copy of E (PACKED kernels; h is then packed too)
+    const x16_t* Ep;                  // optional fragment-packed copy of E (PACKED kernels; h is then packed too)
     const GenCfg* gen;                 // optional generation config (repetition penalty) + per-sample seen-token bitmap
     const unsigned* seen; long seen_words;
 };
@@ -60,8 +63,8 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
     const int frow = lane & 15, fq = lane >> 4;
     const int NTOT = p.V + p.NP;
     const int nblk = (NTOT + 15) / 16;
-    const bf16_t* wrow[NT];
-    const bf16_t* wpk[NT];
+    const x16_t* wrow[NT];
+    const x16_t* wpk[NT];
     bool in_text[NT];
 #pragma unroll
     for (int i = 0; i < NT; ++i) {
@@ -72,7 +75,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
         wrow[i] = (n < p.V) ? p.E + (long)n * p.D : p.proto + (long)(n - p.V) * p.D;
         wpk[i] = PACKED ? p.Ep + (long)(min(n0, p.V - 16) >> 4) * (p.D >> 5) * 512 + lane * 8 : nullptr;
     }
-    const bf16_t* xrow[MT];
+    const x16_t* xrow[MT];
     bool xok[MT];
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -92,7 +95,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
     for (int g0 = wave; g0 * U < nks; g0 += 4) {
 #pragma unroll
         for (int uh = 0; uh < U; uh += UH) {
-            bf16x8 wf[UH][NT], xf[UH][MT];
+            x16x8 wf[UH][NT], xf[UH][MT];
 #pragma unroll
             for (int u = 0; u < UH; ++u) {
                 const int ks = g0 * U + uh + u;
@@ -100,7 +103,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
                 const bool kok = (ks < nks) && (k < p.D);
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    if (PACKED && in_text[i]) wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(wpk[i] + (long)ks * 512)) : zero_frag();
+                    if (PACKED && in_text[i]) wf[u][i] = kok ? __builtin_nontemporal_load(reinterpret_cast<const x16x8*>(wpk[i] + (long)ks * 512)) : zero_frag();
                     else wf[u][i] = kok ? ld_frag(wrow[i] + k) : zero_frag();
                 }
 #pragma unroll
@@ -162,6 +165,7 @@ __global__ __launch_bounds__(256) void vrt_head_kernel(HeadArgs p) {
     }
 }
 
+#if !PADT_OP16_F16   // type-independent: compiled once
 struct GreedyArgs {
     const float* part_val; const int* part_idx; int nblk;
     int B, D, eos, pad, T_max;
@@ -171,8 +175,8 @@ struct GreedyArgs {
     int* step;                // device counter
     int* slot; int* lens;     // [B] KV append index / valid-key count for the NEXT step
     int* pos3;                // [3][B] rope positions for the NEXT step
-    const bf16_t* hidden;     // [B][D] last-layer hidden of this step (post final norm)
-    bf16_t* hidden_buf;       // [T_max][B][D]
+    const x16_t* hidden;     // [B][D] last-layer hidden of this step (post final norm)
+    x16_t* hidden_buf;       // [T_max][B][D]
     int advance;              // 1: bump slot/lens/pos (decode steps and after prefill)
     const GenCfg* gen;        // optional: extra EOS ids
     unsigned* seen; long seen_words;   // optional: bitmap of ids present in each row (repetition penalty), updated here
@@ -200,8 +204,8 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
     }
     const int step = *p.step;
     if (step < p.T_max) {
-        const bf16_t* h = p.hidden + (long)b * p.D;
-        bf16_t* hb = p.hidden_buf + ((long)step * p.B + b) * p.D;
+        const x16_t* h = p.hidden + (long)b * p.D;
+        x16_t* hb = p.hidden_buf + ((long)step * p.B + b) * p.D;
         for (int c = tid * 8; c < p.D; c += 256 * 8) *reinterpret_cast<u32x4*>(hb + c) = *reinterpret_cast<const u32x4*>(h + c);
     }
     __syncthreads();
@@ -228,6 +232,7 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
 __global__ void step_inc_kernel(int* step) { *step += 1; }
 
 extern "C" long padt_vrt_head_nblk(long vocab, long n_proto) { return (vocab + n_proto + 15) / 16; }
+#endif
 
 template <int MT, int NT, bool PACKED>
 static void launch_head(const HeadArgs& a, int nblk, hipStream_t s) {
@@ -240,7 +245,7 @@ static void launch_head(const HeadArgs& a, int nblk, hipStream_t s) {
     hipLaunchKernelGGL((vrt_head_kernel<MT, NT, PACKED>), dim3((nblk + NT - 1) / NT), dim3(256), lds, s, a);
 }
 
-extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
+extern "C" int PADT_TWIN(padt_vrt_head)(void* stream, const void* hidden, long ldh, const void* embed_table, long vocab,
                              const void* proto, long n_proto, const int* vrt_off, const int* mode_table,
                              const int* step, void* logits_f32, long ld_logits, void* part_val, void* part_idx,
                              long batch, long D, int eos, const void* embed_table_packed, const void* gen_cfg,
@@ -251,9 +256,9 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
         padt_set_error("padt_vrt_head: the packed path needs D % 32 == 0, vocab % 16 == 0 and 16-byte aligned pointers");
         return -1;
     }
-    HeadArgs a{(const bf16_t*)hidden, ldh, (const bf16_t*)embed_table, (int)vocab, (const bf16_t*)proto, (int)n_proto,
+    HeadArgs a{(const x16_t*)hidden, ldh, (const x16_t*)embed_table, (int)vocab, (const x16_t*)proto, (int)n_proto,
                vrt_off, mode_table, step, (float*)logits_f32, ld_logits, (float*)part_val, (int*)part_idx, (int)batch,
-               (int)D, eos, (const bf16_t*)embed_table_packed, (const GenCfg*)gen_cfg, (const unsigned*)seen, seen_words};
+               (int)D, eos, (const x16_t*)embed_table_packed, (const GenCfg*)gen_cfg, (const unsigned*)seen, seen_words};
     if (seen && seen_words * 32 < vocab + n_proto) { padt_set_error("padt_vrt_head: seen bitmap narrower than the table"); return -1; }
     const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
     hipStream_t s = (hipStream_t)stream;
@@ -275,6 +280,7 @@ extern "C" int padt_vrt_head(void* stream, const void* hidden, long ldh, const v
     return 0;
 }
 
+#if !PADT_OP16_F16   // type-independent: compiled once
 extern "C" int padt_greedy_step(void* stream, const void* part_val, const void* part_idx, long nblk, long batch, long D,
                                 int eos, int pad, long t_max, int* unfinished, long* tokens_out, long* cur_tok,
                                 int* step, int* slot, int* lens, int* pos3, const void* hidden, void* hidden_buf,
@@ -282,7 +288,7 @@ extern "C" int padt_greedy_step(void* stream, const void* part_val, const void* 
     if (batch <= 0) return 0;
     if (D & 7) { padt_set_error("padt_greedy_step: D % 8 == 0 required"); return -1; }
     GreedyArgs a{(const float*)part_val, (const int*)part_idx, (int)nblk, (int)batch, (int)D, eos, pad, (int)t_max,
-                 unfinished, tokens_out, cur_tok, step, slot, lens, pos3, (const bf16_t*)hidden, (bf16_t*)hidden_buf,
+                 unfinished, tokens_out, cur_tok, step, slot, lens, pos3, (const x16_t*)hidden, (x16_t*)hidden_buf,
                  advance, (const GenCfg*)gen_cfg, (unsigned*)seen, seen_words};
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(greedy_step_kernel, dim3((unsigned)batch), dim3(256), 0, s, a);
@@ -480,3 +486,6 @@ extern "C" int padt_seen_init(void* stream, const long* ids, const int* rows, lo
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;
 }
+#endif
+
+}  // namespace PADT_NS

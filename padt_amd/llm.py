@@ -127,7 +127,7 @@ class DecodeSession:
     def __init__(self, cfg: PaDTConfig, W, B: int, s_max: int, np_max: int, t_max: int, device):
         self.cfg, self.W, self.B, self.s_max, self.np_max, self.t_max = cfg, W, B, s_max, np_max, t_max
         D, hd, Hkv, nl = cfg.hidden_size, cfg.head_dim, cfg.num_key_value_heads, cfg.num_hidden_layers
-        bf = torch.bfloat16
+        bf = W.op16                                         # 16-bit operand type of the model (fp16 by default, bf16: weights.prepare_weights)
         z = lambda *s, dt=bf: torch.zeros(*s, device=device, dtype=dt)
         self.kc = [z(B, Hkv, s_max, hd) for _ in range(nl)]
         self.vtc = [z(B, Hkv, hd, s_max) for _ in range(nl)]
@@ -186,17 +186,21 @@ class DecodeSession:
         Hq, Hkv, hd, D = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim, cfg.hidden_size
         B = self.B
         ops.embed_tokens(self.cur_tok, None, W["llm.embed"], self.proto, None, out=self.x_rm, err_flag=self.err)
-        ops.pack_rows(self.x_rm, self.x, B, to_packed=True)
         f32 = self.x32 is not None
+        sc = ops.stream_scale(W.op16) if f32 else 1.0
+        eps_n = W.eps_m(cfg.rms_norm_eps) if f32 else cfg.rms_norm_eps       # the fused norms read the (scaled) stream mirror
         if f32:
-            ops.cast_bf16_f32(self.x_rm, out=self.x32)
+            ops.cast_x16_f32(self.x_rm, out=self.x32)
+            if sc != 1.0:                                                     # first mirror of the step's stream: X(scale * x32)
+                ops.cast_f32_x16(self.x32, out=self.x_rm, scale=sc)
+        ops.pack_rows(self.x_rm, self.x, B, to_packed=True)
         ops.rope_table(self.pos3, self.inv_freq, self.rope_cs, hd, cfg.mrope_section)
         for i in range(cfg.num_hidden_layers):
             p = f"llm.{i}."
             # 6 launches per layer: [norm+qkv] [rope+append+split attention] [merge] [o+resid] [norm+gate/up+SwiGLU] [down+resid]
             if W.llm_weights == "fp8":                            # fp8 weight images (+ per-row scales): half the bytes per step
                 ops.gemm_packed_fp8(self.x, W[p + "qkv.wq"], W[p + "qkv.ws"], self.n_qkv, W[p + "qkv.b"], out=self.qkv,
-                                    norm_eps=cfg.rms_norm_eps, a_packed=True, rows=B)
+                                    norm_eps=eps_n, a_packed=True, rows=B)
                 ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
                                      hd, self.s_max, self.s_max, out_packed=True)
                 if f32:
@@ -206,7 +210,7 @@ class DecodeSession:
                     ops.gemm_packed_fp8(self.att, W[p + "o.wq"], W[p + "o.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
                                         split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
                 ops.gemm_packed_fp8(self.x, W[p + "gu.wq"], W[p + "gu.ws"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU,
-                                    norm_eps=cfg.rms_norm_eps, a_packed=True, c_packed=True, rows=B)
+                                    norm_eps=eps_n, a_packed=True, c_packed=True, rows=B)
                 if f32:
                     ops.gemm_packed_resid32(self.h, W[p + "down.wq"], D, self.x32, self.x, scales=W[p + "down.ws"], split_k=self.down_split,
                                             workspace=self.splitk_ws, rows=B)
@@ -214,7 +218,7 @@ class DecodeSession:
                     ops.gemm_packed_fp8(self.h, W[p + "down.wq"], W[p + "down.ws"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
                                         split_k=self.down_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
                 continue
-            ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=cfg.rms_norm_eps,
+            ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=eps_n,
                             a_packed=True, rows=B)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
                                  hd, self.s_max, self.s_max, out_packed=True)
@@ -223,7 +227,7 @@ class DecodeSession:
             else:
                 ops.gemm_packed(self.att, W[p + "o.wp"], D, out=self.x, epilogue=ops.EPI_RESID, residual=self.x,
                                 split_k=self.o_split, workspace=self.splitk_ws, a_packed=True, c_packed=True, rows=B)
-            ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=cfg.rms_norm_eps,
+            ops.gemm_packed(self.x, W[p + "gu.wp"], 2 * W.llm_ipad, out=self.h, epilogue=ops.EPI_SWIGLU, norm_eps=eps_n,
                             a_packed=True, c_packed=True, rows=B)
             if f32:
                 ops.gemm_packed_resid32(self.h, W[p + "down.wp"], D, self.x32, self.x, split_k=self.down_split, workspace=self.splitk_ws, rows=B)
@@ -323,9 +327,12 @@ class LanguageModel:
         Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         T = plan.ids.numel()
         dev = image_embeds.device
-        bf = torch.bfloat16
+        bf = W.op16
         x = ops.embed_tokens(plan.ids, plan.img_index, W["llm.embed"], sess.proto, image_embeds, err_flag=sess.err)
-        x32 = ops.cast_bf16_f32(x) if W.resid_f32 else None      # fp32 residual stream; x stays its bf16 mirror
+        x32 = ops.cast_x16_f32(x) if W.resid_f32 else None       # fp32 residual stream; x stays its 16-bit mirror
+        eps_n = W.eps_m(cfg.rms_norm_eps) if x32 is not None else cfg.rms_norm_eps
+        if x32 is not None and ops.stream_scale(bf) != 1.0:
+            ops.cast_f32_x16(x32, out=x, scale=ops.stream_scale(bf))           # mirrors hold X(scale * x32) (fp16: 2^-4, see ops.stream_scale)
         n = torch.empty_like(x)
         rstd = torch.empty((T,), device=dev, dtype=torch.float32)
         qkv = torch.empty((T, (Hq + 2 * Hkv) * hd), device=dev, dtype=bf)
@@ -345,10 +352,10 @@ class LanguageModel:
             # fp8 x fp8 MFMA path (llm_weights="fp8"): the GEMM input rows are quantised to e4m3 (power-of-two row scale x the folded norm's
             # rstd) and multiplied with the e4m3 weight image; a projection whose shape the fp8 kernel does not take keeps the bf16 GEMM
             if f8 and (p + "qkv.w8") in W:
-                ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
+                ops.quant_rows_fp8(x, norm_eps=eps_n, out=x8, rs=rs8)
                 ops.gemm_fp8(x8, W[p + "qkv.w8"], W[p + "qkv.ws"], rs8, bias=W[p + "qkv.b"], out=qkv)
             else:
-                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into qkv.w
+                ops.row_rstd(x, eps=eps_n, out=rstd)                       # norm weight is folded into qkv.w
                 ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
                              cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
@@ -361,10 +368,10 @@ class LanguageModel:
             else:
                 ops.gemm(att, W[p + "o.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
             if f8 and (p + "gu.w8") in W:
-                ops.quant_rows_fp8(x, norm_eps=cfg.rms_norm_eps, out=x8, rs=rs8)
+                ops.quant_rows_fp8(x, norm_eps=eps_n, out=x8, rs=rs8)
                 ops.gemm_fp8(x8, W[p + "gu.w8"], W[p + "gu.ws"], rs8, out=h, epilogue=ops.EPI_SWIGLU)
             else:
-                ops.row_rstd(x, eps=cfg.rms_norm_eps, out=rstd)            # norm weight is folded into gu.w
+                ops.row_rstd(x, eps=eps_n, out=rstd)                       # norm weight is folded into gu.w
                 ops.gemm(x, W[p + "gu.w"], out=h, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
             if f8 and (p + "down.w8") in W:
                 ops.quant_rows_fp8(h, out=h8, rs=rs8)

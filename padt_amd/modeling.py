@@ -86,17 +86,19 @@ class CustomGenerateDecoderOnlyOutput(dict):
 
 
 class PaDTForConditionalGeneration:
-    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16"):
+    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16", operands=None):
+        """dtype: the checkpoint's (the reference's torch_dtype argument; PaDT checkpoints are bf16).  operands: "fp16" (default) or "bf16" —
+        the 16-bit MFMA operand type ViT / LLM compute in, fp32 accumulation either way (weights.prepare_weights)."""
         if dtype != torch.bfloat16:
-            raise ValueError("the MI355X path computes in bf16 (fp32 accumulate); pass torch_dtype=torch.bfloat16")
+            raise ValueError("PaDT checkpoints are bf16: pass torch_dtype=torch.bfloat16 (the MFMA operand type is chosen with operands=)")
         _lib.load()                                            # fail loudly before touching any weight
         self.config = config
         self.device = torch.device(device)
-        self.dtype = dtype
-        self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights)
+        self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights, operands=operands)
+        self.dtype = self.W.op16                               # what pixel_values / hidden_states / past_image_embeds are held in
         self.visual = VisionEncoder(config, self.W, self.device)
         self.lm = LanguageModel(config, self.W, self.device)
-        self.vl_decoder = PaDTDecoder(config, self.W, self.device, dtype)
+        self.vl_decoder = PaDTDecoder(config, self.W, self.device, torch.bfloat16)
         self.model = SimpleNamespace(embed_tokens=SimpleNamespace(weight=self.W["llm.embed"]))
         self.use_visual_prototype_projection = config.use_visual_prototype_projection
         self.rope_deltas = None
@@ -109,7 +111,7 @@ class PaDTForConditionalGeneration:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.bfloat16, attn_implementation=None,
-                        device_map=None, config=None, llm_weights: str = "bf16", **_):
+                        device_map=None, config=None, llm_weights: str = "bf16", operands=None, **_):
         """Loads ``config.json`` + ``*.safetensors`` (checkpoint key layout of PaDT-MLLM/PaDT_*).  ``attn_implementation``
         is accepted and ignored: attention is always the HIP flash kernel."""
         path = str(pretrained_model_name_or_path)
@@ -125,7 +127,7 @@ class PaDTForConditionalGeneration:
             device = f"cuda:{d}" if isinstance(d, int) else str(d)
         elif isinstance(device_map, (str, torch.device)):
             device = str(device_map)
-        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights)
+        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights, operands=operands)
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             model.load_generation_config(json.load(open(gpath)))
@@ -150,10 +152,10 @@ class PaDTForConditionalGeneration:
     @classmethod
     def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
         """Random-init weights of the given architecture (no checkpoints offline)."""
-        kw_llm = kw.pop("llm_weights", "bf16")
+        kw_llm, kw_op = kw.pop("llm_weights", "bf16"), kw.pop("operands", None)
         sd = state_dict if state_dict is not None else synthetic_state_dict(config, seed=seed, device=device,
                                                                             dtype=torch.bfloat16, **kw)
-        return cls(config, sd, device=device, llm_weights=kw_llm)
+        return cls(config, sd, device=device, llm_weights=kw_llm, operands=kw_op)
 
     def eval(self):
         return self
@@ -390,9 +392,19 @@ class PaDTForConditionalGeneration:
             for f in feats:
                 obj_sample.append(si)
                 n_vp.append(int(f.shape[0]))
-        feats_cat = torch.cat([f.to(dev, torch.bfloat16) for f in flat], dim=0).contiguous()
-        if not self.W.dec_hp and high_res_image_embeds.dtype == torch.float32:      # the bf16-storage decoder (PADT_DECODER_HP=0) reads bf16 rows
-            high_res_image_embeds = ops.cast_f32_bf16(high_res_image_embeds.contiguous())
+        # the PaDT decoder reads fp32 or bf16 rows (its own operand pairs are bf16 (hi, lo)): fp16 rows of an fp16-operand model enter it
+        # as fp32 (exact), never through a bf16 rounding
+        def dec_in(t):
+            t = t.to(dev).contiguous()
+            if t.dtype == torch.float16:
+                t = ops.cast_x16_f32(t)
+            if not self.W.dec_hp and t.dtype == torch.float32:                      # the bf16-storage decoder (PADT_DECODER_HP=0) reads bf16 rows
+                t = ops.cast_f32_bf16(t)
+            return t
+        feats_cat = torch.cat([f.to(dev) for f in flat], dim=0)
+        feats_cat = dec_in(feats_cat if feats_cat.dtype in (torch.float16, torch.float32) else feats_cat.to(torch.bfloat16))
+        low_res_image_embeds = dec_in(low_res_image_embeds)
+        high_res_image_embeds = dec_in(high_res_image_embeds)
         bbox, score, masks, hw = self.vl_decoder.forward_objects(
             feats_cat, n_vp, low_res_image_embeds, high_res_image_embeds, visual_pes, obj_sample, patch_off, patch_num, grids)
         # "sample_idx_t": the same list as a device tensor (cached with the decoder's plan) for the device-side result pack

@@ -6,6 +6,7 @@ from . import _lib
 
 EPI_NONE, EPI_GELU, EPI_RESID, EPI_SWIGLU = 0, 1, 2, 3
 BF16 = torch.bfloat16
+F16 = torch.float16
 
 
 def _stream():
@@ -20,6 +21,43 @@ def _chk_bf16(*ts):
     for t in ts:
         if t is not None:
             assert t.is_cuda and t.dtype == BF16 and t.stride(-1) == 1, (t.dtype, t.device, t.stride())
+
+
+def _x16(*ts):
+    """→ the ONE 16-bit operand type (bf16 or fp16) of the given device tensors (None entries skipped); mixing them is an error."""
+    dt = None
+    for t in ts:
+        if t is None:
+            continue
+        assert t.is_cuda and t.dtype in (BF16, F16) and t.stride(-1) == 1, (t.dtype, t.device, t.stride())
+        assert dt is None or t.dtype == dt, ("mixed 16-bit operand types", dt, t.dtype)
+        dt = t.dtype
+    return dt
+
+
+def _fn(name, dt):
+    """The library entry point of `name` for operand type dt: the bf16 instantiation keeps the header's names, its fp16 twin replaces
+    `bf16` by `f16` in the name or appends `_f16` (include/padt_hip_f16.h)."""
+    lib = _lib.load()
+    if dt != F16:
+        return getattr(lib, name)
+    return getattr(lib, name.replace("bf16", "f16") if "bf16" in name else name + "_f16")
+
+
+_STREAM_SCALE = {}
+
+
+def stream_scale(dt):
+    """Factor between an fp32 residual stream and its 16-bit mirror of type dt (1 for bf16, 2^-4 for fp16: padt_stream_scale)."""
+    if dt not in _STREAM_SCALE:
+        _STREAM_SCALE[dt] = float(_lib.load().padt_stream_scale(1 if dt == F16 else 0))
+    return _STREAM_SCALE[dt]
+
+
+def mirror_eps(eps, dt):
+    """The eps a scale-invariant consumer of a stream mirror (row_rstd, the fused RMSNorm of gemm_packed / quant_rows_fp8) must be given
+    so that it returns rstd(x) / stream_scale: rsqrt(mean((s x)^2) + s^2 eps) = rstd(x) / s."""
+    return float(eps) * stream_scale(dt) ** 2
 
 
 GEMM_LOG = None   # bench.py sets this to a list to record (and later replay) every GEMM launch of one step
@@ -117,68 +155,65 @@ def row_rstd(x, eps=1e-6, out=None):
     M, D = x.shape
     if out is None:
         out = torch.empty((M,), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().padt_row_rstd(_stream(), _p(x), x.stride(0), _p(out), M, D, float(eps)), "padt_row_rstd")
+    _lib.check(_fn("padt_row_rstd", _x16(x))(_stream(), _p(x), x.stride(0), _p(out), M, D, float(eps)), "padt_row_rstd")
     return out
 
 
 def gemm(a, w, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_f32=False, K=None, row_scale=None):
     """out[M,N'] = epi(row_scale[m] * (a[M,K] @ w[N,K]^T) + bias).  a/w/out may be row-strided 2-D views.  N' = N/2 for SwiGLU."""
-    lib = _lib.load()
-    _chk_bf16(a, w, bias, residual)
+    dt = _x16(a, w, bias, residual)
     M = a.shape[0]
     N = w.shape[0]
     K = K if K is not None else a.shape[1]
     assert w.shape[1] >= K or w.shape[1] == K, (w.shape, K)
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else BF16)
-    assert out.stride(-1) == 1 and out.shape[0] == M and out.shape[1] >= n_out
+        out = torch.empty((M, n_out), device=a.device, dtype=torch.float32 if out_f32 else dt)
+    assert out.stride(-1) == 1 and out.shape[0] == M and out.shape[1] >= n_out and out.dtype == (torch.float32 if out_f32 else dt)
     if row_scale is not None:
         assert row_scale.dtype == torch.float32 and row_scale.numel() >= M and row_scale.is_contiguous()
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, epilogue, residual, out_f32, K, row_scale))
     _tg_note("gemm", M, N, K)
-    _lib.check(lib.padt_gemm_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
+    _lib.check(_fn("padt_gemm_bf16", dt)(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0),
                                   _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue,
                                   1 if out_f32 else 0, _p(row_scale)), "padt_gemm_bf16")
     return out
 
 
 def gemm_resid32(a, w, bias, x32, xb=None):
-    """fp32 residual stream: x32[M,N] += a @ w^T + bias (in place); xb = bf16(x32) is the next projection's A operand."""
-    lib = _lib.load()
-    _chk_bf16(a, w, bias, xb)
+    """fp32 residual stream: x32[M,N] += a @ w^T + bias (in place); xb = X(stream_scale * x32) is the next projection's A operand."""
+    dt = _x16(a, w, bias, xb)
     M, K = a.shape
     N = w.shape[0]
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and x32.shape[0] >= M and x32.shape[1] >= N
     if GEMM_LOG is not None:
         GEMM_LOG.append(("r32", a, w, bias, x32, xb))
     _tg_note("r32", M, N, K)
-    _lib.check(lib.padt_gemm_resid32(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
+    _lib.check(_fn("padt_gemm_resid32", dt)(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(x32), x32.stride(0), _p(xb),
                                      xb.stride(0) if xb is not None else 0, M, N, K), "padt_gemm_resid32")
     return x32
 
 
 def quant_rows_fp8(x, norm_eps=None, out=None, rs=None):
     """bf16 rows → (e4m3 bytes (M, K) uint8, fp32 row scales (M,)) for gemm_fp8; norm_eps: fold rsqrt(mean(x^2) + eps) into the row scale."""
-    _chk_bf16(x)
+    dt = _x16(x)
     M, K = x.shape
     if out is None:
         out = torch.empty((M, K), device=x.device, dtype=torch.uint8)
     if rs is None:
         rs = torch.empty((M,), device=x.device, dtype=torch.float32)
-    _lib.check(_lib.load().padt_quant_rows_fp8(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), _p(rs), M, K,
+    _lib.check(_fn("padt_quant_rows_fp8", dt)(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), _p(rs), M, K,
                                                -1.0 if norm_eps is None else float(norm_eps)), "padt_quant_rows_fp8")
     return out, rs
 
 
-def gemm_fp8(a8, w8, col_scale, row_scale, bias=None, out=None, epilogue=EPI_NONE, x32=None, xb=None):
+def gemm_fp8(a8, w8, col_scale, row_scale, bias=None, out=None, epilogue=EPI_NONE, x32=None, xb=None, out_dtype=BF16):
     """fp8 x fp8 MFMA GEMM (padt_gemm_fp8): a8 (M, K) / w8 (N, K) uint8 e4m3, row_scale (M,) / col_scale (N,) fp32.
     epilogue EPI_NONE / EPI_SWIGLU → bf16 `out`; EPI_RESID → x32 += ... in place (+ bf16 mirror xb)."""
-    lib = _lib.load()
     assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.stride(-1) == 1 and w8.stride(-1) == 1
     assert row_scale.dtype == torch.float32 and col_scale.dtype == torch.float32 and col_scale.is_contiguous()
-    _chk_bf16(bias, xb)
+    dt = _x16(bias, xb, out) or out_dtype
     M, K = a8.shape
     N = w8.shape[0]
     if epilogue == EPI_RESID:
@@ -186,10 +221,10 @@ def gemm_fp8(a8, w8, col_scale, row_scale, bias=None, out=None, epilogue=EPI_NON
     else:
         n_out = N // 2 if epilogue == EPI_SWIGLU else N
         if out is None:
-            out = torch.empty((M, n_out), device=a8.device, dtype=BF16)
-        _chk_bf16(out)
+            out = torch.empty((M, n_out), device=a8.device, dtype=dt)
+        assert _x16(out) == dt
     _tg_note("fp8", M, N, K)
-    _lib.check(lib.padt_gemm_fp8(_stream(), _p(a8), a8.stride(0), _p(w8), w8.stride(0), _p(row_scale), _p(col_scale), _p(bias), _p(out),
+    _lib.check(_fn("padt_gemm_fp8", dt)(_stream(), _p(a8), a8.stride(0), _p(w8), w8.stride(0), _p(row_scale), _p(col_scale), _p(bias), _p(out),
                                  out.stride(0) if out is not None else 0, _p(x32), x32.stride(0) if x32 is not None else 0, _p(xb),
                                  xb.stride(0) if xb is not None else 0, M, N, K, int(epilogue)), "padt_gemm_fp8")
     return x32 if epilogue == EPI_RESID else out
@@ -203,15 +238,14 @@ def gemm_knobs(mode256=-1, mf=-1, peel=-1, colsplit=-1, group_m=-1):
 def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
     """out = rope(row_scale[m] * (a @ w^T) + bias) with the leading rope_cols columns pair-interleaved per head (see
     weights.interleave_rope_rows): the ViT qkv projection with RoPE fused into the epilogue."""
-    lib = _lib.load()
-    _chk_bf16(a, w, bias, out)
+    dt = _x16(a, w, bias, out)
     M, K = a.shape
     N = w.shape[0]
     assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(0) == sin.stride(0)
     if GEMM_LOG is not None:
         GEMM_LOG.append((a, w, bias, out, EPI_NONE, None, False, None, row_scale))
     _tg_note("gemm", M, N, K)
-    _lib.check(lib.padt_gemm_rope_bf16(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
+    _lib.check(_fn("padt_gemm_rope_bf16", dt)(_stream(), _p(a), a.stride(0), _p(w), w.stride(0), _p(bias), _p(out), out.stride(0), M, N, K,
                                        _p(row_scale), _p(cos), _p(sin), cos.stride(0), int(rope_cols), int(head_dim)),
                "padt_gemm_rope_bf16")
     return out
@@ -219,13 +253,12 @@ def gemm_rope(a, w, bias, out, cos, sin, rope_cols, head_dim, row_scale=None):
 
 def gemm_rmsnorm(a, w, bias=None, out=None, epilogue=EPI_NONE, eps=1e-6):
     """out = epi(rstd(a) * (a @ w^T) + bias) for decode-sized batches (rows <= 64); w carries the folded norm weight."""
-    lib = _lib.load()
-    _chk_bf16(a, w, bias)
+    dt = _x16(a, w, bias, out)
     M, K, N = a.shape[0], a.shape[1], w.shape[0]
     n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
-    _lib.check(lib.padt_gemm_rmsnorm_bf16(_stream(), _p(a), a.stride(0), float(eps), _p(w), w.stride(0), _p(bias), _p(out),
+        out = torch.empty((M, n_out), device=a.device, dtype=dt)
+    _lib.check(_fn("padt_gemm_rmsnorm_bf16", dt)(_stream(), _p(a), a.stride(0), float(eps), _p(w), w.stride(0), _p(bias), _p(out),
                                           out.stride(0), M, N, K, epilogue), "padt_gemm_rmsnorm_bf16")
     return out
 
@@ -242,7 +275,7 @@ def pack_weight(w):
     return w.view(Np // 16, 16, Kp // 32, 4, 8).permute(0, 2, 3, 1, 4).contiguous().view(Np, Kp)
 
 
-def quantize_fp8_rows(w):
+def quantize_fp8_rows(w, deq_dtype=BF16):
     """Per-output-row fp8 quantisation with POWER-OF-TWO scales: → (wq uint8 OCP e4m3 bits [N][K], scale fp32 [N], w_deq bf16 [N][K]).
     scale[n] = 2^ceil(log2(max|w[n]| / 448)); e4m3 x 2^k is exactly representable in bf16, so w_deq (what prefill multiplies with and
     what the oracle sees) and scale * wq (what the decode kernel computes) are the same numbers, bit for bit."""
@@ -250,7 +283,7 @@ def quantize_fp8_rows(w):
     amax = wf.abs().amax(dim=1).clamp_min(1e-30)
     scale = torch.exp2(torch.ceil(torch.log2(amax / 448.0)))
     q = (wf / scale[:, None]).to(torch.float8_e4m3fn)
-    deq = (q.float() * scale[:, None]).to(BF16)
+    deq = (q.float() * scale[:, None]).to(deq_dtype)
     return q.view(torch.uint8), scale.contiguous(), deq
 
 
@@ -269,16 +302,15 @@ def pack_weight_fp8(wq):
 def gemm_packed_fp8(a, wq_packed, scales, n, bias=None, out=None, epilogue=EPI_NONE, residual=None, norm_eps=None, split_k=1, workspace=None,
                     a_packed=False, c_packed=False, rows=None):
     """gemm_packed over fp8 weights: out = epi(rstd?(a) * scales[n] * (a @ wq^T) + bias)."""
-    lib = _lib.load()
-    _chk_bf16(a, bias, residual)
+    dt = _x16(a, bias, residual, out)
     assert wq_packed.dtype == torch.uint8 and scales.dtype == torch.float32 and scales.is_contiguous()
     M, K = a.shape
     if rows is not None:
         M = rows
     n_out = n // 2 if epilogue == EPI_SWIGLU else n
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
-    _lib.check(lib.padt_gemm_packed_fp8(_stream(), _p(a), a.stride(0), _p(wq_packed), wq_packed.shape[1], _p(scales), _p(bias), _p(out),
+        out = torch.empty((M, n_out), device=a.device, dtype=dt)
+    _lib.check(_fn("padt_gemm_packed_fp8", dt)(_stream(), _p(a), a.stride(0), _p(wq_packed), wq_packed.shape[1], _p(scales), _p(bias), _p(out),
                                         out.stride(0), _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
                                         -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace),
                                         (1 if a_packed else 0) | (2 if c_packed else 0)), "padt_gemm_packed_fp8")
@@ -302,15 +334,14 @@ def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None,
                 a_packed=False, c_packed=False, rows=None):
     """Decode-step projection over a pack_weight() image (rows <= 128): out = epi(rstd?(a) * (a @ w^T) + bias).
     a_packed / c_packed: a / (out and residual) are fragment-packed activation buffers holding `rows` valid rows."""
-    lib = _lib.load()
-    _chk_bf16(a, wp, bias, residual)
+    dt = _x16(a, wp, bias, residual, out)
     M, K = a.shape
     if rows is not None:
         M = rows
     n_out = n // 2 if epilogue == EPI_SWIGLU else n
     if out is None:
-        out = torch.empty((M, n_out), device=a.device, dtype=BF16)
-    _lib.check(lib.padt_gemm_packed_bf16(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(bias), _p(out), out.stride(0),
+        out = torch.empty((M, n_out), device=a.device, dtype=dt)
+    _lib.check(_fn("padt_gemm_packed_bf16", dt)(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(bias), _p(out), out.stride(0),
                                          _p(residual), residual.stride(0) if residual is not None else 0, M, n, K, epilogue,
                                          -1.0 if norm_eps is None else float(norm_eps), int(split_k), _p(workspace),
                                          (1 if a_packed else 0) | (2 if c_packed else 0)), "padt_gemm_packed_bf16")
@@ -320,13 +351,12 @@ def gemm_packed(a, wp, n, bias=None, out=None, epilogue=EPI_NONE, residual=None,
 def gemm_packed_resid32(a, wp, n, x32, xb_packed, scales=None, split_k=1, workspace=None, a_packed=True, rows=None):
     """Decode-step residual projection over the fp32 stream: x32[rows, n] += scales?[n] * (a @ w^T) in place, xb_packed = bf16(x32) in the
     fragment-packed activation layout.  wp: pack_weight() image, or with scales the fp8 image."""
-    lib = _lib.load()
-    _chk_bf16(a, xb_packed)
+    dt = _x16(a, xb_packed, None if scales is not None else wp)
     M, K = a.shape
     if rows is not None:
         M = rows
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1 and (scales is None or scales.dtype == torch.float32)
-    _lib.check(lib.padt_gemm_packed_resid32(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(scales), _p(x32), x32.stride(0),
+    _lib.check(_fn("padt_gemm_packed_resid32", dt)(_stream(), _p(a), a.stride(0), _p(wp), wp.shape[1], _p(scales), _p(x32), x32.stride(0),
                                             _p(xb_packed), xb_packed.stride(0), M, n, K, int(split_k), _p(workspace), 1 if a_packed else 0),
                "padt_gemm_packed_resid32")
     return x32
@@ -335,12 +365,11 @@ def gemm_packed_resid32(a, wp, n, x32, xb_packed, scales=None, split_k=1, worksp
 def attn_varlen(q, k, v, out, cu_q, cu_k, max_seqlen_q, n_heads, n_kv_heads, head_dim, causal=False, scale=None, rope=None):
     """q/k/v/out: 2-D (tokens, row) bf16 views whose row holds the heads contiguously; cu_*: int32 device tensors.
     rope=(cos, sin) fp32 [tokens][>= head_dim/2]: rotate q and k inside the kernel (self-attention, max_seqlen_q < 256)."""
-    lib = _lib.load()
-    _chk_bf16(q, k, v, out)
+    dt = _x16(q, k, v, out)
     assert cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
     nseg = cu_q.numel() - 1
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(lib.padt_attn_varlen(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
+    _lib.check(_fn("padt_attn_varlen", dt)(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out),
                                     out.stride(0), _p(cu_q), _p(cu_k), nseg, int(max_seqlen_q), n_heads, n_kv_heads,
                                     head_dim, float(scale), 1 if causal else 0, _p(rope[0]) if rope else 0,
                                     _p(rope[1]) if rope else 0, rope[0].stride(0) if rope else 0), "padt_attn_varlen")
@@ -357,10 +386,9 @@ def new_decode_workspace(batch, n_kv_heads, head_dim, s_max, device):
 
 
 def decode_attn(q, k_cache, vt_cache, lens, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len, scale=None):
-    lib = _lib.load()
-    _chk_bf16(q, k_cache, vt_cache, out)
+    dt = _x16(q, k_cache, vt_cache, out)
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(lib.padt_decode_attn(_stream(), _p(q), _p(k_cache), _p(vt_cache), _p(lens), _p(out), _p(workspace),
+    _lib.check(_fn("padt_decode_attn", dt)(_stream(), _p(q), _p(k_cache), _p(vt_cache), _p(lens), _p(out), _p(workspace),
                                     q.shape[0], n_heads, n_kv_heads, head_dim, s_max, int(max_len), float(scale)),
                "padt_decode_attn")
     return out
@@ -376,42 +404,38 @@ def rope_table(pos3, inv_freq, out, head_dim, sections):
 
 def decode_attn_rope(qkv, rope_cs, slot, k_cache, vt_cache, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len,
                      scale=None, out_packed=False):
-    lib = _lib.load()
-    _chk_bf16(qkv, k_cache, vt_cache, out)
+    dt = _x16(qkv, k_cache, vt_cache, out)
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(lib.padt_decode_attn_rope(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
+    _lib.check(_fn("padt_decode_attn_rope", dt)(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
                                          _p(out), _p(workspace), qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max,
                                          int(max_len), float(scale), 1 if out_packed else 0), "padt_decode_attn_rope")
     return out
 
 
 def rmsnorm(x, w, out=None, eps=1e-6, add=None, add_div=1, D=None, gelu=False):
-    lib = _lib.load()
-    _chk_bf16(x, w, add)
+    dt = _x16(x, w, add, out)
     D = D if D is not None else x.shape[1]
     if out is None:
-        out = torch.empty((x.shape[0], D), device=x.device, dtype=BF16)
-    _lib.check(lib.padt_rmsnorm(_stream(), _p(x), x.stride(0), _p(add), add.stride(0) if add is not None else 0, add_div,
+        out = torch.empty((x.shape[0], D), device=x.device, dtype=dt)
+    _lib.check(_fn("padt_rmsnorm", dt)(_stream(), _p(x), x.stride(0), _p(add), add.stride(0) if add is not None else 0, add_div,
                                 _p(w), _p(out), out.stride(0), x.shape[0], D, float(eps), 1 if gelu else 0), "padt_rmsnorm")
     return out
 
 
 def layernorm(x, w, b, out=None, eps=1e-5):
-    lib = _lib.load()
-    _chk_bf16(x, w, b)
+    dt = _x16(x, w, b, out)
     if out is None:
         out = torch.empty_like(x)
-    _lib.check(lib.padt_layernorm(_stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), x.shape[0],
+    _lib.check(_fn("padt_layernorm", dt)(_stream(), _p(x), x.stride(0), _p(w), _p(b), _p(out), out.stride(0), x.shape[0],
                                   x.shape[1], float(eps)), "padt_layernorm")
     return out
 
 
 def rope_half_(x, cos, sin, n_heads, head_dim):
     """in place on the first n_heads*head_dim columns of x (T, row)."""
-    lib = _lib.load()
-    _chk_bf16(x)
+    dt = _x16(x)
     assert cos.dtype == torch.float32 and sin.dtype == torch.float32 and cos.stride(-1) == 1 and sin.stride() == cos.stride()
-    _lib.check(lib.padt_rope_half(_stream(), _p(x), x.stride(0), _p(cos), _p(sin), cos.stride(0), x.shape[0], n_heads,
+    _lib.check(_fn("padt_rope_half", dt)(_stream(), _p(x), x.stride(0), _p(cos), _p(sin), cos.stride(0), x.shape[0], n_heads,
                                   head_dim), "padt_rope_half")
     return x
 
@@ -423,7 +447,8 @@ def gather_rows(src, idx, out=None, D=None):
     n = idx.numel()
     if out is None:
         out = torch.empty((n, D), device=src.device, dtype=src.dtype)
-    if src.dtype == BF16:
+    if src.dtype in (BF16, F16):                                     # a 16-byte-vector copy: the operand type does not matter
+        assert out.dtype == src.dtype
         _lib.check(lib.padt_gather_rows(_stream(), _p(src), src.stride(0), _p(idx), _p(out), out.stride(0), n, D),
                    "padt_gather_rows")
     elif src.dtype == torch.float32:
@@ -435,44 +460,49 @@ def gather_rows(src, idx, out=None, D=None):
 
 
 def add_rows(a, b, out=None):
-    lib = _lib.load()
-    _chk_bf16(a, b)
+    dt = _x16(a, b, out)
     if out is None:
         out = torch.empty_like(a)
-    _lib.check(lib.padt_add_rows(_stream(), _p(a), a.stride(0), _p(b), b.stride(0), b.shape[0], _p(out), out.stride(0),
+    _lib.check(_fn("padt_add_rows", dt)(_stream(), _p(a), a.stride(0), _p(b), b.stride(0), b.shape[0], _p(out), out.stride(0),
                                  a.shape[0], a.shape[1]), "padt_add_rows")
     return out
 
 
-def cast_f32_bf16(x, D_pad=None, out=None):
-    lib = _lib.load()
+def cast_f32_x16(x, D_pad=None, out=None, dtype=BF16, scale=1.0):
+    """out = X(scale * x) for fp32 rows x, X = dtype (or out's); scale = stream_scale(dtype) writes the mirror of an fp32 residual stream."""
     assert x.dtype == torch.float32 and x.stride(-1) == 1
     D = x.shape[1]
     D_pad = D_pad or D
     if out is None:
-        out = torch.empty((x.shape[0], D_pad), device=x.device, dtype=BF16)
-    _lib.check(lib.padt_cast_f32_bf16(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], D, D_pad),
+        out = torch.empty((x.shape[0], D_pad), device=x.device, dtype=dtype)
+    dt = _x16(out)
+    _lib.check(_fn("padt_cast_f32_bf16", dt)(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], D, D_pad, float(scale)),
                "padt_cast_f32_bf16")
     return out
 
 
-def cast_bf16_f32(x, out=None):
-    lib = _lib.load()
-    _chk_bf16(x)
+def cast_f32_bf16(x, D_pad=None, out=None):
+    return cast_f32_x16(x, D_pad, out, BF16)
+
+
+def cast_x16_f32(x, out=None):
+    dt = _x16(x)
     if out is None:
         out = torch.empty(x.shape, device=x.device, dtype=torch.float32)
-    _lib.check(lib.padt_cast_bf16_f32(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1]), "padt_cast_bf16_f32")
+    _lib.check(_fn("padt_cast_bf16_f32", dt)(_stream(), _p(x), x.stride(0), _p(out), out.stride(0), x.shape[0], x.shape[1]), "padt_cast_bf16_f32")
     return out
+
+
+cast_bf16_f32 = cast_x16_f32
 
 
 def rmsnorm_f32(x32, w, out=None, eps=1e-6):
     """bf16 RMSNorm of fp32 rows (the norms that read the fp32 residual stream)."""
-    lib = _lib.load()
-    _chk_bf16(w)
+    dt = _x16(w, out)
     assert x32.dtype == torch.float32 and x32.stride(-1) == 1
     if out is None:
-        out = torch.empty(x32.shape, device=x32.device, dtype=BF16)
-    _lib.check(lib.padt_rmsnorm_f32(_stream(), _p(x32), x32.stride(0), _p(w), _p(out), out.stride(0), x32.shape[0], x32.shape[1], float(eps)),
+        out = torch.empty(x32.shape, device=x32.device, dtype=dt)
+    _lib.check(_fn("padt_rmsnorm_f32", dt)(_stream(), _p(x32), x32.stride(0), _p(w), _p(out), out.stride(0), x32.shape[0], x32.shape[1], float(eps)),
                "padt_rmsnorm_f32")
     return out
 
@@ -486,11 +516,11 @@ def sigmoid_f32_(x):
 
 def embed_tokens(ids, img_index, table, proto, image_embeds, out=None, err_flag=None):
     lib = _lib.load()
-    _chk_bf16(table, proto, image_embeds)
+    dt = _x16(table, proto, image_embeds, out)                       # rows are copied: one entry point serves both operand types
     assert ids.dtype == torch.int64 and ids.is_contiguous()
     T, D = ids.numel(), table.shape[1]
     if out is None:
-        out = torch.empty((T, D), device=table.device, dtype=BF16)
+        out = torch.empty((T, D), device=table.device, dtype=dt)
     _lib.check(lib.padt_embed_tokens(_stream(), _p(ids), _p(img_index), _p(table), _p(proto), _p(image_embeds), _p(out),
                                      T, table.shape[0], 0 if proto is None else proto.shape[0], D, _p(err_flag)),
                "padt_embed_tokens")
@@ -499,10 +529,9 @@ def embed_tokens(ids, img_index, table, proto, image_embeds, out=None, err_flag=
 
 def llm_qkv_post(qkv, pos3, inv_freq, q_out, k_cache, vt_cache, n_heads, n_kv_heads, head_dim, s_max, sections,
                  sample=None, slot=None, lens=None, k_pack=None):
-    lib = _lib.load()
-    _chk_bf16(qkv, q_out, k_cache, vt_cache, k_pack)
+    dt = _x16(qkv, q_out, k_cache, vt_cache, k_pack)
     assert pos3.dtype == torch.int32 and pos3.is_contiguous() and inv_freq.dtype == torch.float32
-    _lib.check(lib.padt_llm_qkv_post(_stream(), _p(qkv), qkv.stride(0), _p(pos3), _p(sample), _p(slot), _p(lens),
+    _lib.check(_fn("padt_llm_qkv_post", dt)(_stream(), _p(qkv), qkv.stride(0), _p(pos3), _p(sample), _p(slot), _p(lens),
                                      _p(inv_freq), _p(q_out), q_out.stride(0), _p(k_pack),
                                      k_pack.stride(0) if k_pack is not None else 0, _p(k_cache), _p(vt_cache),
                                      qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max, sections[0], sections[1]),
@@ -526,10 +555,9 @@ def vrt_head_nblk(vocab, n_proto):
 def vrt_head(hidden, table, proto, vrt_off, part_val, part_idx, eos, mode_table=None, step=None, logits=None,
              table_packed=None, rows=None, gen_cfg=None, seen=None):
     """table_packed: pack_weight(table) — then `hidden` is a fragment-packed activation buffer holding `rows` valid rows."""
-    lib = _lib.load()
-    _chk_bf16(hidden, table, proto, table_packed)
+    dt = _x16(hidden, table, proto, table_packed)
     B = hidden.shape[0] if rows is None else rows
-    _lib.check(lib.padt_vrt_head(_stream(), _p(hidden), hidden.stride(0), _p(table), table.shape[0], _p(proto),
+    _lib.check(_fn("padt_vrt_head", dt)(_stream(), _p(hidden), hidden.stride(0), _p(table), table.shape[0], _p(proto),
                                  proto.shape[0], _p(vrt_off), _p(mode_table), _p(step), _p(logits),
                                  logits.stride(0) if logits is not None else 0, _p(part_val), _p(part_idx),
                                  B, hidden.shape[1], eos, _p(table_packed), _p(gen_cfg), _p(seen),
@@ -591,8 +619,8 @@ def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):
     assert img_u8.dtype == torch.uint8 and img_u8.is_contiguous() and img_u8.shape[2] == 3
     assert lut.dtype == torch.float32 and lut.shape == (3, 256) and out.stride(1) == 1
     H, W = img_u8.shape[:2]
-    _lib.check(_lib.load().padt_patchify_normalize(_stream(), _p(img_u8), H, W, _p(lut), _p(out), out.stride(0),
-                                                   1 if out.dtype == BF16 else 0, patch, merge, temporal), "padt_patchify_normalize")
+    _lib.check(_fn("padt_patchify_normalize", out.dtype)(_stream(), _p(img_u8), H, W, _p(lut), _p(out), out.stride(0),
+                                                         1 if out.dtype in (BF16, F16) else 0, patch, merge, temporal), "padt_patchify_normalize")
     return out
 
 

@@ -220,6 +220,7 @@ def unpack_results(gathered: torch.Tensor, batch_per_rank: int) -> List[dict]:
         rec = gathered[r]
         frec = rec.view(torch.float32)
         n, cap, mask_hw, has_mask = (int(v) for v in rec[:_HDR].tolist())
+        has_mask &= 1                                                  # bits 8 and up: continuation marker (ResultExchange)
         o = _HDR
         sidx = rec[o: o + cap][:n].long() + r * batch_per_rank
         o += cap
@@ -242,6 +243,22 @@ def rank_batches(n_items: int, batch_size: int, rank: int, world: int):
     return list(range(rank * batch_size, all_number, world * batch_size))
 
 
+def _split_decoded(decoded: dict, cap: int) -> List[dict]:
+    """A vl_decode output with more than `cap` objects → consecutive chunks of at most `cap` objects each (views, no copies)."""
+    n = decoded["pred_boxes"].shape[0]
+    has_mask = decoded.get("pred_mask") is not None
+    chunks = []
+    for a in range(0, max(n, 1), cap):
+        b = min(n, a + cap)
+        c = {"pred_boxes": decoded["pred_boxes"][a:b], "pred_score": decoded["pred_score"][a:b], "sample_idx": list(decoded["sample_idx"][a:b]),
+             "pred_mask": decoded["pred_mask"][a:b] if has_mask else None,
+             "pred_mask_valid_hw": tuple(t[a:b] for t in decoded["pred_mask_valid_hw"]) if has_mask else ()}
+        if decoded.get("sample_idx_t") is not None:
+            c["sample_idx_t"] = decoded["sample_idx_t"][a:b]
+        chunks.append(c)
+    return chunks
+
+
 class ResultExchange:
     """The data-parallel exchange without lock-step: every rank packs `per_gather` consecutive batch records (normally one decode group)
     into one buffer and issues ONE asynchronous all_gather_into_tensor for them (RCCL runs it on its own stream); the handle is only waited
@@ -249,42 +266,74 @@ class ResultExchange:
     Every rank must add() the same number of batches.
 
         ex = ResultExchange(cap, mask_hw, per_gather=8, device=dev)
-        for decoded in ...: done += ex.add(decoded)        # → list of (world, per_gather, words) int32 tensors whose gather completed
+        for decoded in ...: done += ex.add(decoded)        # → list of (world, per_gather [+ k], words) int32 tensors whose gather completed
         done += ex.flush()
-    The returned tensors are views of a double buffer: consume (unpack / copy) them before the second-next gather is issued.
-    """
+        for t in done: for b in range(ex.per): rec = ex.batch_record(t, src_rank, b)
+
+    A batch with more objects than `cap` (an OVD image can carry tens of objects, padt.py:370) does NOT raise — on one rank that would leave
+    the other ranks waiting in the gather for ever: its first `cap` objects travel in the batch's slot, the rest as CONTINUATION records.  The
+    gather buffer's last word announces how many continuation records the rank holds for this gather; when the gather completes every rank
+    sees every rank's count, so all ranks agree — without a further message — on k = the largest count and run ONE more (synchronous)
+    gather of k records per rank.  The k continuation records are appended to the returned tensor (slots per_gather … per_gather + k − 1; word 3
+    of their header carries 1 + the batch slot they continue in bits 8 and up).  With no rank over capacity (the normal case) nothing changes:
+    one collective per decode group, the returned tensors are views of a double buffer — consume (unpack / copy) them before the second-next
+    gather is issued."""
 
     def __init__(self, cap: int, mask_hw: int, per_gather: int, device, group=None):
         import torch.distributed as dist
         self.cap, self.mask_hw, self.per, self.device, self.group = cap, mask_hw, max(1, per_gather), device, group
         self.world = dist.get_world_size(group)
         self.words = _record_words(cap, mask_hw)
-        self._bufs = [torch.zeros((self.per, self.words), dtype=torch.int32, device=device) for _ in range(2)]   # double buffer
-        self._outs = [torch.empty((self.world, self.per, self.words), dtype=torch.int32, device=device) for _ in range(2)]
+        n = self.per * self.words + 1                                  # + the continuation count
+        self._bufs = [torch.zeros(n, dtype=torch.int32, device=device) for _ in range(2)]                         # double buffer
+        self._outs = [torch.empty((self.world, n), dtype=torch.int32, device=device) for _ in range(2)]
         self._cur, self._fill, self._inflight = 0, 0, None
+        self._cont = []                                                # continuation records of the gather being filled
         self.n_gathers = 0
+        self.n_continuation_gathers = 0
+
+    def _slots(self, flat: torch.Tensor) -> torch.Tensor:
+        return flat[..., : self.per * self.words].unflatten(-1, (self.per, self.words))
 
     def add(self, decoded: dict) -> List[torch.Tensor]:
-        pack_results(decoded, self.cap, self.mask_hw, self.device, out=self._bufs[self._cur][self._fill])
+        chunks = _split_decoded(decoded, self.cap) if decoded["pred_boxes"].shape[0] > self.cap else [decoded]
+        pack_results(chunks[0], self.cap, self.mask_hw, self.device, out=self._slots(self._bufs[self._cur])[self._fill])
+        for c in chunks[1:]:
+            rec = pack_results(c, self.cap, self.mask_hw, self.device)
+            rec[3] += (self._fill + 1) << 8
+            self._cont.append(rec)
         self._fill += 1
         return self._launch() if self._fill == self.per else []
 
     def _wait(self) -> List[torch.Tensor]:
         if self._inflight is None:
             return []
-        work, out = self._inflight
+        import torch.distributed as dist
+        work, out, cont = self._inflight
         work.wait()
         self._inflight = None
-        return [out]
+        res = self._slots(out)
+        k = int(out[:, -1].max().item())                               # every rank computes the same k from the same gathered words
+        if k:
+            mine = torch.zeros((k, self.words), dtype=torch.int32, device=self.device)
+            for i, rec in enumerate(cont):
+                mine[i] = rec
+            more = torch.empty((self.world, k, self.words), dtype=torch.int32, device=self.device)
+            dist.all_gather_into_tensor(more.view(-1), mine.view(-1), group=self.group)
+            self.n_continuation_gathers += 1
+            res = torch.cat([res, more], dim=1)
+        return [res]
 
     def _launch(self) -> List[torch.Tensor]:
         import torch.distributed as dist
         done = self._wait()                                            # at most one gather in flight: its buffers are free again
         buf, out = self._bufs[self._cur], self._outs[self._cur]
         if self._fill < self.per:
-            buf[self._fill:].zero_()                                   # partially filled last group: n = 0 records
-        work = dist.all_gather_into_tensor(out.view(-1), buf.view(-1), group=self.group, async_op=True)
-        self._inflight = (work, out)
+            self._slots(buf)[self._fill:].zero_()                      # partially filled last group: n = 0 records
+        buf[-1:].fill_(len(self._cont))
+        work = dist.all_gather_into_tensor(out.view(-1), buf, group=self.group, async_op=True)
+        self._inflight = (work, out, self._cont)
+        self._cont = []
         self.n_gathers += 1
         self._cur ^= 1
         self._fill = 0
@@ -294,3 +343,16 @@ class ResultExchange:
         done = self._launch() if self._fill else []
         return done + self._wait()
 
+    def batch_record(self, gathered: torch.Tensor, src_rank: int, slot: int) -> dict:
+        """One batch's results as rank `src_rank` computed them, from a tensor add() / flush() returned: the slot's record with its
+        continuation records (if any) appended in order."""
+        parts = [unpack_results(gathered[src_rank, slot][None], batch_per_rank=0)[0]]
+        for j in range(self.per, gathered.shape[1]):
+            if (int(gathered[src_rank, j, 3]) >> 8) == slot + 1:
+                parts.append(unpack_results(gathered[src_rank, j][None], batch_per_rank=0)[0])
+        if len(parts) == 1:
+            return parts[0]
+        masks = [p["masks"] for p in parts]
+        return {"sample_idx": torch.cat([p["sample_idx"] for p in parts]), "boxes": torch.cat([p["boxes"] for p in parts]),
+                "scores": torch.cat([p["scores"] for p in parts]), "valid_hw": torch.cat([p["valid_hw"] for p in parts]),
+                "masks": torch.cat(masks) if all(m is not None for m in masks) else None}

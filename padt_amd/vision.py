@@ -104,7 +104,8 @@ class VisionEncoder:
         p = f"vit.{i}."
         full = (i in v.fullatt_block_indexes) if force_full is None else force_full
         cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
-        ops.row_rstd(x, out=rstd)                                          # RMSNorm = rstd x (weight folded into qkv.w)
+        eps = W.eps_m(1e-6) if x32 is not None else 1e-6                   # x is the (scaled) mirror of x32: rstd comes out as rstd / scale
+        ops.row_rstd(x, eps=eps, out=rstd)                                 # RMSNorm = rstd x (weight folded into qkv.w)
         # qkv projection with the rotary embedding applied in its epilogue (q / k columns are pair-interleaved per head by
         # prepare_weights): no separate pass over q and k
         if W.vit_rope_fused:
@@ -117,7 +118,7 @@ class VisionEncoder:
             ops.gemm_resid32(att, W[p + "proj.w"], W[p + "proj.b"], x32, x)
         else:
             ops.gemm(att, W[p + "proj.w"], W[p + "proj.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
-        ops.row_rstd(x, out=rstd)
+        ops.row_rstd(x, eps=eps, out=rstd)
         ops.gemm(x, W[p + "gu.w"], W[p + "gu.b"], out=hbuf, epilogue=ops.EPI_SWIGLU, row_scale=rstd)
         if x32 is not None:
             ops.gemm_resid32(hbuf, W[p + "down.w"], W[p + "down.b"], x32, x)
@@ -125,7 +126,7 @@ class VisionEncoder:
             ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
 
     def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):
-        """pixel_values (P, C*T*p*p) fp32 or bf16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
+        """pixel_values (P, C*T*p*p) fp32 / bf16 / fp16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
         cfg, W = self.cfg, self.W
         v = cfg.vision_config
         plan = self.plan(grid_thw)
@@ -133,13 +134,19 @@ class VisionEncoder:
         hd = vh // H
         if pixel_values.shape[0] != P:
             raise ValueError(f"pixel_values has {pixel_values.shape[0]} rows, image_grid_thw implies {P}")
-        pix = pixel_values if pixel_values.dtype == torch.bfloat16 else ops.cast_f32_bf16(pixel_values.float().contiguous())
+        op16 = W.op16                                                          # the operand type the weights were prepared in
+        if pixel_values.dtype == op16:
+            pix = pixel_values
+        elif pixel_values.dtype == torch.float32:
+            pix = ops.cast_f32_x16(pixel_values.contiguous(), dtype=op16)
+        else:                                                                  # the other 16-bit type: through fp32 (exact), one rounding
+            pix = ops.cast_f32_x16(ops.cast_x16_f32(pixel_values.contiguous()), dtype=op16)
         f32 = W.resid_f32
         x0 = ops.gemm(pix, W["vit.patch_embed"], out_f32=f32)                  # conv3d-as-GEMM (HF:116-122)
         x32 = None
         if f32:                                                                # fp32 residual stream + its bf16 mirror
             x32 = ops.gather_rows(x0, plan.patch_perm)                         # window order
-            x = ops.cast_f32_bf16(x32)
+            x = ops.cast_f32_x16(x32, dtype=op16, scale=ops.stream_scale(op16))   # the stream's first mirror
         else:
             x = ops.gather_rows(x0, plan.patch_perm)
         n = torch.empty_like(x)

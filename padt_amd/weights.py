@@ -2,8 +2,8 @@
 
 Input: a state dict with the checkpoint's (HF-4.50) key names — ``visual.*``, ``model.*``, ``lm_head.weight``,
 ``vis_norm.*``, ``vis_proj.*``, ``vl_decoder.*`` — from safetensors shards or from
-``synthetic_state_dict`` (no checkpoints exist offline).  Output: ``PreparedWeights``, bf16 device tensors laid out for
-the kernels in libpadt_hip.so:
+``synthetic_state_dict`` (no checkpoints exist offline).  Output: ``PreparedWeights``, 16-bit device tensors (fp16 by default for
+ViT / LLM, bf16 for the PaDT decoder: ``prepare_weights``) laid out for the kernels in libpadt_hip.so:
   * every Linear stays [out][in] (K-contiguous = MFMA operand order), conv3d patch-embed flattened to [hidden][C*T*p*p];
   * LLM q/k/v fused into one [Hq*D + 2*Hkv*D][hidden] matrix (+ fused bias); the LLM's input / post-attention RMSNorm
     weights folded into the q/k/v and gate/up matrices (W·diag(g));
@@ -12,7 +12,7 @@ the kernels in libpadt_hip.so:
 """
 import os
 import zlib
-from typing import Dict
+from typing import Dict, Optional
 
 import torch
 
@@ -201,7 +201,8 @@ def fp8_gemm_ok(n: int, k: int) -> bool:
 
 
 class PreparedWeights(dict):
-    """name → bf16 device tensor (kernel layout).  Plain dict plus a few derived sizes."""
+    """name → device tensor in kernel layout (ViT / LLM / prototype tensors in the operand type `op16`, the PaDT decoder's in bf16).
+    Plain dict plus a few derived sizes."""
     vit_ipad: int
     llm_ipad: int
     dec_ipad: int
@@ -209,27 +210,50 @@ class PreparedWeights(dict):
     llm_weights: str = "bf16"
     resid_f32: bool = True
     fp8_prefill: bool = False
+    op16: torch.dtype = torch.bfloat16
+
+    def eps_m(self, eps: float) -> float:
+        """eps for the consumers of a residual-stream mirror (ops.mirror_eps)."""
+        from .ops import mirror_eps
+        return mirror_eps(eps, self.op16)
 
 
-def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16") -> PreparedWeights:
-    """llm_weights = "fp8": the LLM's projection matrices (after the norm folding) are quantised per output row to OCP e4m3 with
+def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda", llm_weights: str = "bf16",
+                    operands: Optional[str] = None) -> PreparedWeights:
+    """operands = "fp16" (default; env PADT_OPERANDS) | "bf16": the 16-bit MFMA operand type of ViT / LLM / prototypes — activations between
+    kernels, KV caches and the weight images.  Checkpoints are bf16: a bf16 weight is exact in fp16 unless |w| < 2^-14 (then within 3e-8), and
+    the norm-folded matrices w_norm * W are ROUNDED to the operand type, which fp16 does with 11 instead of 8 mantissa bits.  fp16 operands sit
+    8x closer to the fp32 reference at the bf16 MFMA rate (tests/studies/operand_attribution.py) and need the fp32 residual streams (an
+    un-normalised stream does not fit fp16's range; its 16-bit mirror is stored scaled, ops.stream_scale).
+    llm_weights = "fp8": the LLM's projection matrices (after the norm folding) are quantised per output row to OCP e4m3 with
     power-of-two scales (ops.quantize_fp8_rows); the decode step streams the fp8 images (half the bytes), prefill multiplies with the
-    bf16 image of the SAME numbers (scale * q is exact in bf16) — BASELINE configs[4], the 7B "fp8 MFMA weight path"."""
-    if llm_weights not in ("bf16", "fp8"):
-        raise ValueError("llm_weights must be 'bf16' or 'fp8'")
+    16-bit image of the SAME numbers (scale * q is exact) — BASELINE configs[4], the 7B "fp8 MFMA weight path".  "fp8+act" additionally
+    runs the prompt pass as fp8 x fp8 MFMA GEMMs over e4m3 ACTIVATION rows quantised on the fly (1.6x the 16-bit tile GEMM on the 7B shapes;
+    costs precision: DESIGN.md §4 numerics) — opt-in since round 4 (it was implied by "fp8" in round 3)."""
+    if llm_weights not in ("bf16", "fp8", "fp8+act"):
+        raise ValueError("llm_weights must be 'bf16', 'fp8' or 'fp8+act'")
+    operands = operands or os.environ.get("PADT_OPERANDS", "fp16")
+    if operands not in ("bf16", "fp16"):
+        raise ValueError("operands must be 'fp16' or 'bf16'")
     dev = torch.device(device)
     W = PreparedWeights()
+    fp8_act = llm_weights == "fp8+act" or (llm_weights == "fp8" and os.environ.get("PADT_FP8_PREFILL", "0") == "1")
+    llm_weights = "fp8" if llm_weights == "fp8+act" else llm_weights
     W.llm_weights = llm_weights
     # fp32 residual streams in the ViT and the LLM (default; PADT_RESID_F32=0 keeps the round-2 bf16 streams for A/B runs): the
     # residual GEMMs' epilogues update an fp32 stream in place and emit its bf16 mirror for the next projection
     W.resid_f32 = os.environ.get("PADT_RESID_F32", "1") != "0"
-    # llm_weights = "fp8": at prompt length the LLM projections run as fp8 x fp8 MFMA GEMMs (activation rows quantised to e4m3 on the fly,
-    # v_mfma_f32_16x16x128_f8f6f4: 1.6x the bf16 tile GEMM on the 7B shapes) wherever the shape allows; PADT_FP8_PREFILL=0 keeps the
-    # prompt pass on the bf16 image of the quantised weights (round-2 behaviour).  Needs the fp32 residual streams.
-    W.fp8_prefill = llm_weights == "fp8" and W.resid_f32 and os.environ.get("PADT_FP8_PREFILL", "1") != "0"
+    if operands == "fp16" and not W.resid_f32:
+        raise ValueError("fp16 operands need the fp32 residual streams (PADT_RESID_F32=0 is a bf16-only A/B switch)")
+    W.op16 = torch.float16 if operands == "fp16" else BF16
+    # "fp8+act": at prompt length the LLM projections run as fp8 x fp8 MFMA GEMMs (activation rows quantised to e4m3 on the fly,
+    # v_mfma_f32_16x16x128_f8f6f4) wherever the shape allows.  Needs the fp32 residual streams.
+    W.fp8_prefill = llm_weights == "fp8" and W.resid_f32 and fp8_act
+    op16 = W.op16
 
     def put(name, t):
-        W[name] = t.to(device=dev, dtype=BF16).contiguous()
+        # everything under "dec." belongs to the split-precision PaDT decoder, whose (hi, lo) operand pairs are bf16
+        W[name] = t.to(device=dev, dtype=BF16 if name.startswith("dec.") else op16).contiguous()
 
     def get(name):
         if name not in sd:
@@ -293,8 +317,8 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
         d = f"llm.{i}."
         for nm in ("qkv", "o", "gu", "down"):
             if llm_weights == "fp8":
-                q, sc, deq = quantize_fp8_rows(W[d + nm + ".w"])
-                W[d + nm + ".w"] = deq                           # prefill: bf16 image of the quantised matrix (exact)
+                q, sc, deq = quantize_fp8_rows(W[d + nm + ".w"], deq_dtype=op16)
+                W[d + nm + ".w"] = deq                           # prefill: 16-bit image of the quantised matrix (exact)
                 W[d + nm + ".wq"] = pack_weight_fp8(q)           # decode: fp8 fragment-packed image + per-row scales
                 W[d + nm + ".ws"] = sc
                 if W.fp8_prefill and fp8_gemm_ok(q.shape[0], q.shape[1]):
@@ -306,7 +330,7 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
     if cfg.vocab_size % 16 == 0 and cfg.hidden_size % 32 == 0 and os.environ.get("PADT_HEAD_PACKED", "1") != "0":
         W["llm.head.wp"] = pack_weight(W["llm.head"])
     put("llm.norm", get("model.norm.weight"))
-    W["llm.ones"] = torch.ones(cfg.hidden_size, device=dev, dtype=BF16)
+    W["llm.ones"] = torch.ones(cfg.hidden_size, device=dev, dtype=op16)
     if cfg.use_visual_prototype_projection:
         put("proto.norm.w", get("vis_norm.weight"))
         put("proto.norm.b", get("vis_norm.bias"))

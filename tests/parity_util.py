@@ -66,52 +66,72 @@ def effective_llm_weights(model, w):
     return out
 
 
-# ------------------------------------------------------------------------------------------------ bf16-operand floor
-class bf16_operand_floor:
-    """Context manager: inside it the ORACLE's ViT / LLM arithmetic rounds every matrix-multiply operand on the activation side to
-    bf16 — the normalised rows entering qkv / gate-up, q / k / v (and with them the KV cache), the un-normalised probabilities P, the
-    attention output entering proj / o_proj, the SwiGLU hidden entering down_proj, pixel rows, merger / prototype / head inputs — and
-    keeps EVERYTHING else in fp32 (residual streams, accumulators, softmax statistics, norms, weights as given).  That is the smallest
-    distance to the fp32 reference any implementation on bf16 MFMA operands can have, whatever it stores between kernels; the full-depth
-    parity test measures it on its own inputs and bounds the HIP path by a multiple of it (tests/studies/e2e_precision_floor.py prints
-    the numbers).  The PaDT decoder is left alone (the HIP decoder runs split-precision operands)."""
+# ------------------------------------------------------------------------------------------------ operand floors
+OPERAND_CLASSES = ("vit.rows", "vit.qkv", "vit.p", "vit.ao", "vit.hid", "vit.misc",
+                   "llm.rows", "llm.qkv", "llm.p", "llm.ao", "llm.hid", "head")
+
+
+class operand_floor:
+    """Context manager: inside it the ORACLE's ViT / LLM arithmetic rounds matrix-multiply operands on the ACTIVATION side to a 16-bit
+    type and keeps EVERYTHING else in fp32 (residual streams, accumulators, softmax statistics, norms, weights as given).  With every
+    class on and dtype = bf16 that is the smallest distance to the fp32 reference any implementation on bf16 MFMA operands can have,
+    whatever it stores between kernels; the full-depth parity tests measure it on their own inputs and bound the HIP path by a multiple
+    of it.  `classes` selects WHICH operands are rounded (the attribution study, tests/studies/operand_attribution.py):
+
+      {vit,llm}.rows  the normalised rows entering qkv / gate-up     {vit,llm}.qkv  q, k, v after the rotation (and the KV cache)
+      {vit,llm}.p     the un-normalised probabilities                {vit,llm}.ao   the attention output entering proj / o_proj
+      {vit,llm}.hid   the SwiGLU hidden entering down_proj           vit.misc       pixel rows, merger and prototype-projection inputs
+      head            last-layer hidden rows and prototype rows entering the logit head
+
+    dtype: torch.bfloat16 (8 mantissa bits) or torch.float16 (11).  The PaDT decoder is left alone (call vl_decode outside the context;
+    the HIP decoder runs split-precision operands)."""
+
+    def __init__(self, dtype=torch.bfloat16, classes=OPERAND_CLASSES):
+        self.dtype = dtype
+        self.classes = frozenset(classes)
+        unknown = self.classes - set(OPERAND_CLASSES)
+        if unknown:
+            raise ValueError("unknown operand classes: %s" % sorted(unknown))
 
     def __enter__(self):
         import torch.nn.functional as F
-        bf = lambda t: t.to(torch.bfloat16).to(torch.float32)
+        dt, on = self.dtype, self.classes
         self._saved = {k: getattr(O, k) for k in ("vit_block", "llm_layer", "linear", "vrt_logits")}
 
-        def linear(x, w, b=None):
-            return F.linear(bf(x), w, b)
+        def rd(t, cls):
+            return t.to(dt).to(torch.float32) if cls in on else t
+
+        def linear(x, w, b=None):                                    # the sites outside the blocks: patch embed, merger, prototypes
+            return F.linear(rd(x, "vit.misc"), w, b)
 
         def vit_block(w, pfx, cfg, x, cu, cos, sin):
             H, T = cfg.vit_heads, x.shape[0]
-            n = O.rms_norm(x, w[pfx + "norm1.weight"], 1e-6)
-            qkv = linear(n, w[pfx + "attn.qkv.weight"], w[pfx + "attn.qkv.bias"]).reshape(T, 3, H, -1)
+            n = rd(O.rms_norm(x, w[pfx + "norm1.weight"], 1e-6), "vit.rows")
+            qkv = F.linear(n, w[pfx + "attn.qkv.weight"], w[pfx + "attn.qkv.bias"]).reshape(T, 3, H, -1)
             q, k, v = qkv.permute(1, 0, 2, 3).unbind(0)
             c, s = cos.unsqueeze(-2).float(), sin.unsqueeze(-2).float()
-            q, k, v = bf(q * c + O.rotate_half(q) * s), bf(k * c + O.rotate_half(k) * s), bf(v)
+            q, k, v = rd(q * c + O.rotate_half(q) * s, "vit.qkv"), rd(k * c + O.rotate_half(k) * s, "vit.qkv"), rd(v, "vit.qkv")
             a = torch.empty_like(q)
             for i in range(len(cu) - 1):
                 a0, a1 = int(cu[i]), int(cu[i + 1])
                 qs, ks, vs = (t[a0:a1].transpose(0, 1) for t in (q, k, v))
                 sc = torch.matmul(qs, ks.transpose(1, 2)) * (q.shape[-1] ** -0.5)
                 e = torch.exp(sc - sc.max(-1, keepdim=True).values)
-                a[a0:a1] = (torch.matmul(bf(e), vs) / e.sum(-1, keepdim=True)).transpose(0, 1)
-            x = x + linear(a.reshape(T, -1), w[pfx + "attn.proj.weight"], w[pfx + "attn.proj.bias"])
-            n = O.rms_norm(x, w[pfx + "norm2.weight"], 1e-6)
-            g = linear(n, w[pfx + "mlp.gate_proj.weight"], w[pfx + "mlp.gate_proj.bias"])
-            u = linear(n, w[pfx + "mlp.up_proj.weight"], w[pfx + "mlp.up_proj.bias"])
-            return x + linear(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"], w[pfx + "mlp.down_proj.bias"])
+                a[a0:a1] = (torch.matmul(rd(e, "vit.p"), vs) / e.sum(-1, keepdim=True)).transpose(0, 1)
+            x = x + F.linear(rd(a.reshape(T, -1), "vit.ao"), w[pfx + "attn.proj.weight"], w[pfx + "attn.proj.bias"])
+            n = rd(O.rms_norm(x, w[pfx + "norm2.weight"], 1e-6), "vit.rows")
+            g = F.linear(n, w[pfx + "mlp.gate_proj.weight"], w[pfx + "mlp.gate_proj.bias"])
+            u = F.linear(n, w[pfx + "mlp.up_proj.weight"], w[pfx + "mlp.up_proj.bias"])
+            return x + F.linear(rd(F.silu(g) * u, "vit.hid"), w[pfx + "mlp.down_proj.weight"], w[pfx + "mlp.down_proj.bias"])
 
         def llm_layer(w, pfx, cfg, h, cos, sin, attn_bias, cache, li):
             B, Lq, _ = h.shape
-            n = O.rms_norm(h, w[pfx + "input_layernorm.weight"], cfg.rms_eps)
-            q = linear(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"]).view(B, Lq, cfg.num_heads, cfg.head_dim)
-            k = linear(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
-            v = linear(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            n = rd(O.rms_norm(h, w[pfx + "input_layernorm.weight"], cfg.rms_eps), "llm.rows")
+            q = F.linear(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"]).view(B, Lq, cfg.num_heads, cfg.head_dim)
+            k = F.linear(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            v = F.linear(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
             c, s = cos.unsqueeze(2), sin.unsqueeze(2)
-            q, k, v = bf(q * c + O.rotate_half(q) * s), bf(k * c + O.rotate_half(k) * s), bf(v)
+            q, k, v = rd(q * c + O.rotate_half(q) * s, "llm.qkv"), rd(k * c + O.rotate_half(k) * s, "llm.qkv"), rd(v, "llm.qkv")
             if cache is not None:
                 k, v = cache.update(li, k, v)
             rep = cfg.num_heads // cfg.num_kv_heads
@@ -120,15 +140,15 @@ class bf16_operand_floor:
             vh = v.transpose(1, 2).repeat_interleave(rep, 1)
             sc = torch.matmul(qh, kh.transpose(2, 3)) * (cfg.head_dim ** -0.5) + attn_bias
             e = torch.exp(sc - sc.max(-1, keepdim=True).values)
-            a = (torch.matmul(bf(e), vh) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, Lq, -1)
-            h = h + linear(a, w[pfx + "self_attn.o_proj.weight"])
-            n = O.rms_norm(h, w[pfx + "post_attention_layernorm.weight"], cfg.rms_eps)
-            g = linear(n, w[pfx + "mlp.gate_proj.weight"])
-            u = linear(n, w[pfx + "mlp.up_proj.weight"])
-            return h + linear(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"])
+            a = (torch.matmul(rd(e, "llm.p"), vh) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, Lq, -1)
+            h = h + F.linear(rd(a, "llm.ao"), w[pfx + "self_attn.o_proj.weight"])
+            n = rd(O.rms_norm(h, w[pfx + "post_attention_layernorm.weight"], cfg.rms_eps), "llm.rows")
+            g = F.linear(n, w[pfx + "mlp.gate_proj.weight"])
+            u = F.linear(n, w[pfx + "mlp.up_proj.weight"])
+            return h + F.linear(rd(F.silu(g) * u, "llm.hid"), w[pfx + "mlp.down_proj.weight"])
 
         def vrt_logits(w, cfg, hidden, proto, lmask):
-            return self._saved["vrt_logits"](w, cfg, bf(hidden), bf(proto), lmask)
+            return self._saved["vrt_logits"](w, cfg, rd(hidden, "head"), rd(proto, "head"), lmask)
 
         O.linear, O.vit_block, O.llm_layer, O.vrt_logits = linear, vit_block, llm_layer, vrt_logits
         return self
@@ -137,6 +157,16 @@ class bf16_operand_floor:
         for k, v in self._saved.items():
             setattr(O, k, v)
         return False
+
+
+def bf16_operand_floor():
+    """Every operand class rounded to bf16 (what rounds 2-3 measured and asserted against)."""
+    return operand_floor(torch.bfloat16)
+
+
+def fp16_operand_floor():
+    """Every operand class rounded to fp16: the floor of an implementation on `v_mfma_f32_16x16x32_f16` operands."""
+    return operand_floor(torch.float16)
 
 
 # ------------------------------------------------------------------------------------------------ fp8 x fp8 prompt pass

@@ -19,23 +19,50 @@ def lib():
 
 def test_header_parses_and_every_symbol_is_exported(lib):
     decls = _lib.parse_header()
-    assert len(decls) >= 26
-    for name in decls:
-        assert hasattr(lib, name), f"{name} declared in include/padt_hip.h but not exported"
-    assert lib.padt_abi_version() == 1
+    twins = _lib.parse_header(_lib.HEADER_F16)
+    assert len(decls) >= 26 and len(twins) >= 20
+    for name in list(decls) + list(twins):
+        assert hasattr(lib, name), f"{name} declared in include/ but not exported"
+    assert lib.padt_abi_version() == 2
+    assert lib.padt_stream_scale(0) == 1.0 and lib.padt_stream_scale(1) == 2.0 ** -4
+
+
+def test_fp16_header_is_what_the_generator_writes():
+    """include/padt_hip_f16.h is generated (tools/gen_f16_header.py): same argument lists as the bf16 declarations, one twin per
+    PADT_TWIN / PADT_SYM definition in csrc/."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("gen_f16_header", os.path.join(ROOT, "tools", "gen_f16_header.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert open(_lib.HEADER_F16).read() == gen.render()
+    bf, f16 = _lib.parse_header(), _lib.parse_header(_lib.HEADER_F16)
+    for b, f in gen.twins():
+        assert bf[b][:2] == f16[f][:2], (b, f)
 
 
 def test_every_extern_c_symbol_is_declared(lib):
     """No undeclared entry points: every padt_* extern "C" definition in csrc/ appears in the header."""
     import re
-    decls = set(_lib.parse_header())
+    decls = set(_lib.parse_header()) | set(_lib.parse_header(_lib.HEADER_F16))
     defined = set()
     csrc = os.path.join(ROOT, "padt_amd", "csrc")
     for f in os.listdir(csrc):
         src = open(os.path.join(csrc, f)).read()
         defined |= set(re.findall(r'extern "C"\s+[\w\s\*]+?\b(padt_\w+)\s*\(', src))
-    defined -= {"padt_set_error", "padt_gemm256_try", "padt_gemm_fp8_impl"}      # internal helpers shared between translation units
+        for nm in re.findall(r'extern "C"\s+[\w\s\*]+?\bPADT_TWIN\((padt_\w+)\)\s*\(', src):      # both operand-type instantiations
+            defined |= {nm, nm + "_f16"}
+        for pre, post in re.findall(r'extern "C"\s+[\w\s\*]+?\bPADT_SYM\((padt_\w+),\s*(\w*)\)\s*\(', src):
+            defined |= {pre + "bf16" + post, pre + "f16" + post}
+    internal = {"padt_set_error", "padt_gemm256_try", "padt_gemm_fp8_impl"}      # helpers shared between translation units
+    defined -= internal | {n + "_f16" for n in internal}
     assert defined <= decls, defined - decls
+    # and nothing else leaves the library: every exported padt_* symbol is declared (or one of the internal helpers)
+    import subprocess
+    out = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True)
+    if out.returncode == 0:
+        exported = {l.split()[-1] for l in out.stdout.splitlines() if l.split() and l.split()[-1].startswith("padt_") and " T " in l}
+        extra = exported - decls - internal - {n + "_f16" for n in internal}
+        assert not extra, extra
 
 
 def test_argument_validation_without_device(lib):

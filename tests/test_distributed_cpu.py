@@ -113,3 +113,51 @@ def test_result_exchange_groups_gather_asynchronously_and_in_order():
                     ref = _fake_decoded(10 * r + b, n)
                     assert torch.equal(res["boxes"], ref["pred_boxes"]) and torch.equal(res["masks"][:, :24, :32], ref["pred_mask"])
                     assert res["sample_idx"].tolist() == ref["sample_idx"]
+
+
+def _worker_overflow(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    ex = pipeline.ResultExchange(cap=8, mask_hw=32, per_gather=2, device="cpu")
+    done = []
+    for b, n in enumerate(_OVERFLOW_COUNTS[rank]):
+        done += [t.clone() for t in ex.add(_fake_decoded(10 * rank + b, n))]
+    done += [t.clone() for t in ex.flush()]
+    out = []
+    for g, t in enumerate(done):
+        for src in range(world):
+            for slot in range(ex.per):
+                rec = ex.batch_record(t, src, slot)
+                # numpy: pickled by value (tensors travel as shared-memory handles the parent may open after this process is gone)
+                out.append((g, src, slot, rec["boxes"].numpy().copy(), rec["sample_idx"].tolist(), rec["masks"].numpy().copy() if rec["masks"] is not None else None))
+    q.put((rank, ex.n_gathers, ex.n_continuation_gathers, [t.shape[1] for t in done], out))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+_OVERFLOW_COUNTS = {0: [3, 8, 2, 1], 1: [5, 19, 9, 0]}          # cap 8: rank 1 overflows in gather 0 (19 → 8 + 8 + 3) and in gather 1 (9 → 8 + 1)
+
+
+def test_result_exchange_over_capacity_batch_is_split_not_raised():
+    """A batch with more objects than the record capacity travels as continuation records: no rank raises (which would leave the others
+    hanging in the gather), every rank — also the one that had nothing to continue — joins the extra gather the announced counts call for,
+    and batch_record() re-assembles the batch bit for bit."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_overflow, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=120) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, n_gathers, n_cont, widths, out in got:
+        assert n_gathers == 2 and n_cont == 2 and widths == [2 + 2, 2 + 1]
+        for g, src, slot, boxes, sidx, masks in out:
+            b = 2 * g + slot
+            n = _OVERFLOW_COUNTS[src][b]
+            ref = _fake_decoded(10 * src + b, n)
+            assert boxes.shape == (n, 4) and (boxes == ref["pred_boxes"].numpy()).all() and sidx == ref["sample_idx"]
+            if n:
+                assert (masks[:, :24, :32] == ref["pred_mask"].numpy()).all()
