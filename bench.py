@@ -1,13 +1,16 @@
 #!/usr/bin/env python
 """bench.py — images/s of PaDT_Pro_3B REC inference on MI355X (BASELINE.json metric), one process per GPU.
 
-  python bench.py [--gpus N --steps K --warmup W]         (N>1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py [--gpus N --steps K --warmup W]         (N>1: one rank per GPU under torch.distributed.run — given as typed, the script
+                                                           re-launches itself under it; rank 0's JSON line is the only stdout line)
 
 A "step" = one batch of `--batch` (default 8) synthetic 640x640-equivalent images (grid [1,46,46], 2116 patches,
 529 VRTs, prompt L=577) through the whole hot path with inputs already resident in HBM:
   ViT → prototypes → packed prefill → 27 hipGraph decode steps over text‖VRT (scripted 28-token REC completion: one run
   of 5 VRTs, forced EOS) → parseVRTintoCompletion → PaDT decoder (boxes + 184x184 mask logits) [→ RCCL all-gather].
-Weights: random-init PaDT_Pro_3B architecture (3.85 B parameters, bf16).  Rank 0 prints ONE JSON line.
+Weights: random-init PaDT_Pro_3B architecture (3.85 B parameters, bf16 values; ViT / LLM multiply them as fp16 MFMA operands —
+`v_mfma_f32_16x16x32_f16`, the bf16 rate with 3 more mantissa bits; `--operands bf16` is the A/B variant).  Rank 0 prints ONE JSON line.
+The timed loops rotate 4 distinct input batches (a repeated batch would sit in the 256 MB Infinity Cache).
 Extra objects on that line (N=1): "roofline" (bf16 MFMA tile-GEMM family: in-kernel start / end stamps of every tile-GEMM call INSIDE the
 running pipeline — HIP-event pairs around 290 launches per step cost 10 % throughput and count the dispatch gaps; frac_replay = the same
 launches replayed alone between one event pair), "roofline_decode" (HBM bytes of a decode step / its in-situ and stand-alone
@@ -69,8 +72,11 @@ def parse_args():
     ap.add_argument("--task", default="rec", choices=["rec", "ovd", "ric"], help="rec: BASELINE configs[1] (L=577, T=28, 1 object x 5 VRT); "
                     "ovd: BASELINE configs[3] shape per GPU (80-class prompt L=890, T=120, 7 objects x 5 VRT per image); "
                     "ric: BASELINE configs[4] shape (caption with interleaved VRT runs: T=150, 6 runs x 5 VRT)")
-    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8"], help="fp8: LLM projection weights as OCP e4m3 + power-of-two "
-                    "row scales for the decode steps (BASELINE configs[4], 7B fp8 weight path)")
+    ap.add_argument("--weights", default="bf16", choices=["bf16", "fp8", "fp8+act"], help="fp8: LLM projection weights as OCP e4m3 + power-of-two "
+                    "row scales, streamed by the decode steps (BASELINE configs[4], 7B fp8 weight path); fp8+act: additionally the prompt pass as "
+                    "fp8 x fp8 MFMA GEMMs over e4m3 activation rows")
+    ap.add_argument("--operands", default="fp16", choices=["fp16", "bf16"], help="16-bit MFMA operand type of ViT / LLM (fp32 accumulation, fp32 "
+                    "residual streams either way): fp16 (default: 8x closer to the fp32 reference at the same rate) or bf16")
     ap.add_argument("--cap", type=int, default=0, help="object capacity of the per-batch result record (default: 2 x the scheduled objects)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
@@ -100,7 +106,7 @@ def build_model(args, device):
     from padt_amd.modeling import PaDTForConditionalGeneration
     cfg = {"3b": padt_amd.padt_pro_3b, "7b": padt_amd.padt_pro_7b, "small": padt_amd.small_test_config}[args.model]()
     grid_hw = (10, 12) if args.model == "small" else (46, 46)
-    model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device, llm_weights=args.weights)
+    model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device, llm_weights=args.weights, operands=args.operands)
     return cfg, model, grid_hw
 
 
@@ -119,26 +125,42 @@ def workload(args):
     return 33, T, 1, 2, rec_schedule(T, range(2, 4))
 
 
-def make_inputs(cfg, args, grid_hw, device, seed):
+N_ROT = 4          # distinct input batches every timed loop cycles through
+
+
+def make_inputs(cfg, args, grid_hw, device, seed, dtype=torch.float16):
     from padt_amd.synthetic import FakeProcessor, synthetic_batch
     import padt_amd
     n_post, T, n_obj, n_vrt, sched = workload(args)
     args.tnew = T
     grids = [[1, grid_hw[0], grid_hw[1]]] * args.batch
-    grid, pix, ids, am = synthetic_batch(cfg, grids, n_pre=15, n_post=n_post, seed=seed)
+    rot = []
+    for k in range(N_ROT):                                             # same shapes, different pixels and prompt ids
+        grid, pix, ids, am = synthetic_batch(cfg, grids, n_pre=15, n_post=n_post, seed=seed + 7919 * k)
+        rot.append((ids.to(device), am.to(device), pix.to(device).to(dtype)))
     n_m = grid_hw[0] * grid_hw[1] // 4
     proc = padt_amd.VisonTextProcessingClass(FakeProcessor(cfg, n_m), cfg.vision_config.spatial_merge_size)
     proc.model_embed_token_size = cfg.vocab_size
     if not args.cap:
         args.cap = 2 * n_obj * args.batch
-    return dict(grid=grid, pix=pix.to(device).to(torch.bfloat16), ids=ids.to(device), am=am.to(device), proc=proc,
+    ids, am, pix = rot[0]
+    return dict(grid=grid, pix=pix, ids=ids, am=am, proc=proc, rot=rot, rot_k=[0],
                 sched=sched, n_obj=n_obj, n_vrt=n_vrt, L=ids.shape[1])
+
+
+def next_batch(inp):
+    """→ (ids (fresh copy: the callers' loop body updates them in place), attention mask, pixel_values) of the next of the N_ROT batches."""
+    k = inp["rot_k"][0]
+    inp["rot_k"][0] = (k + 1) % len(inp["rot"])
+    ids, am, pix = inp["rot"][k]
+    return ids.clone(), am, pix
 
 
 def run_step(model, inp, args, world):
     from padt_amd import pipeline
+    ids, am, pix = next_batch(inp)
     decoded, completions, labels, vrts = pipeline.rec_batch(
-        model, inp["proc"], inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew,
+        model, inp["proc"], ids, am, pix, inp["grid"], max_new_tokens=args.tnew,
         schedule=inp["sched"], sync_every=args.tnew, use_graph=not args.no_graph)
     if world > 1:
         packed = pipeline.pack_results(decoded, cap=args.cap, mask_hw=4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max())),
@@ -190,7 +212,7 @@ def insitu_leg(model, inp, args, cfg, run_steps, steps):
         e[1] += m
     top = sorted(by.items(), key=lambda kv: -kv[1][1])[:6]
     ach = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
-    roof = {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (bf16 MFMA 16x16x32; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)",
+    roof = {"bound": "mfma", "kernel": "gemm_tile256_kernel + gemm_tile_kernel (%s MFMA 16x16x32 — same rate and peak for fp16 and bf16 —; 256/192/128x256x64 phase-pipelined / 128x128x64 LDS-DMA tiles)" % args.operands,
             "achieved": round(ach, 1), "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(ach / MFMA_BF16_PEAK_TFLOPS, 4),
             "how": "in-kernel wall-clock stamps (first block start → last block end, 100 MHz s_memrealtime) of every tile-GEMM call (rows > 64) of %d pipelined "
                    "steps run right after the timed region with the same runner: algorithmic 2MNK of the un-padded shapes / sum of those durations; the decode "
@@ -312,17 +334,22 @@ def replay_leg(model, inp, args, cfg):
     # separately (tools/collect_profiles.sh), committed under profiles/, and only quoted for the workload / launch count they were measured on
     import glob
     pdir = os.path.join(ROOT, "profiles")
-    traffic, traffic_src = None, None
+    traffic, traffic_src, traffic_note = None, None, "no committed PMC measurement for this workload"
+    sha = csrc_sha16()
     for tp in sorted(glob.glob(os.path.join(pdir, "r*_pmc_traffic.json")), reverse=True):
         tj = json.load(open(tp))
         wl = tj.get("workload", {})
         if wl.get("model") == args.model and wl.get("batch") == args.batch and wl.get("tnew") == args.tnew and wl.get("task", "rec") == args.task \
                 and tj.get("gemm_calls", tj.get("launches")) == len(tile):
-            traffic, traffic_src = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tp)
+            # quoted only while it describes the kernels that ran: the measurement is stamped with the hash of csrc/ it was taken on
+            if tj.get("csrc_sha16") == sha and wl.get("operands", "bf16") == args.operands:
+                traffic, traffic_src, traffic_note = tj["traffic_bytes_per_launch"], "profiles/" + os.path.basename(tp), "csrc/ unchanged since the PMC passes"
+            else:
+                traffic_note = "profiles/%s was measured on other kernel sources (csrc sha %s, now %s): not quoted" % (os.path.basename(tp), tj.get("csrc_sha16"), sha)
             break
     return {"achieved_replay": round(ach, 1), "frac_replay": round(ach / MFMA_BF16_PEAK_TFLOPS, 4), "ms_per_step_replayed": round(ms, 3),
             "launches_replayed": len(tile), "alg_bytes_per_launch": round(alg_bytes / max(len(tile), 1), 0), "traffic": traffic,
-            "traffic_unit": "bytes per launch", "traffic_source": traffic_src}
+            "traffic_unit": "bytes per launch", "traffic_source": traffic_src, "traffic_note": traffic_note}
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg
@@ -416,7 +443,8 @@ def short_run(model, inp, args, steps):
 
     def go(k):
         for _ in range(k):
-            r.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
+            ids, am, pix = next_batch(inp)
+            r.submit(ids, am, pix, inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
         r.flush()
     go(args.depth * args.merge)
     torch.cuda.synchronize()
@@ -432,7 +460,7 @@ def extra_workloads(args, device, model3b, cfg3b, grid3b):
     uses the headline's own PaDT_Pro_3B weights; the 7B model is built (random init, fp8 e4m3 decode weights) after the 3B one is released."""
     import copy
     out = {}
-    for key, over in (("ovd_3b", dict(model="3b", task="ovd", weights="bf16", tnew=28)), ("ric_7b_fp8", dict(model="7b", task="ric", weights="fp8", tnew=28))):
+    for key, over in (("ovd_3b", dict(model="3b", task="ovd", weights="bf16", tnew=28)), ("ric_7b_fp8", dict(model="7b", task="ric", weights="fp8+act", tnew=28))):
         a = copy.copy(args)
         for k, v in over.items():
             setattr(a, k, v)
@@ -443,13 +471,16 @@ def extra_workloads(args, device, model3b, cfg3b, grid3b):
             model3b = None
         else:
             cfg, model, grid_hw = build_model(a, device)
-        inp = make_inputs(cfg, a, grid_hw, device, seed=4321)
+        inp = make_inputs(cfg, a, grid_hw, device, seed=4321, dtype=model.dtype)
         steps = 48                                                     # three decode groups of 16 batches after the priming pass
         r = short_run(model, inp, a, steps)
         alg = alg_tflop_per_image(cfg, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
         r.update({"workload": "%s %s, batch=%d/GPU, L=%d, T_new=%d, %d obj x %d VRT per image, %s LLM weights%s" % (
             {"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)"}[a.model], a.task.upper(), a.batch, inp["L"], a.tnew, inp["n_obj"], inp["n_vrt"], a.weights,
-            " (fp8 x fp8 MFMA prompt pass, fp8 weight streaming in the decode steps)" if a.weights == "fp8" else ""),
+            {"fp8": " (fp8 weight streaming in the decode steps; the prompt pass multiplies the dequantised 16-bit image)",
+             "fp8+act": " (fp8 x fp8 MFMA prompt pass over e4m3 ACTIVATION rows + fp8 weight streaming in the decode steps: e4m3 activations cost "
+                        "precision — boxes 1.6e-3, mask logits 1.3e-2 of their range against the oracle at this geometry, tests/test_real_shape_gpu.py — "
+                        "the 1e-3 parity bar is met by the 16-bit-activation paths only)"}.get(a.weights, "")),
             "alg_tflop_per_image": round(alg, 3), "mfma_frac_e2e": round(r["value"] * alg / MFMA_BF16_PEAK_TFLOPS, 4)})
         out[key] = r
         del model, inp
@@ -462,18 +493,21 @@ def from_images_leg(model, inp, args, grid_hw, steps):
     (Pillow's resampler on the device, byte-exact) → normalize + patchify → the same runner.  f2 of SURVEY.md §8f timed in the loop."""
     from padt_amd import pipeline
     from padt_amd.preprocess import ImageFrontEnd
-    fe = ImageFrontEnd(inp["pix"].device)
+    fe = ImageFrontEnd(inp["pix"].device, dtype=model.dtype)
     g = torch.Generator().manual_seed(99)
     hh, ww = grid_hw[0] * 14 - 4, grid_hw[1] * 14 - 4                  # 640 x 640 for the 46 x 46 grid: smart_resize brings it to 644 x 644
-    host = [torch.randint(0, 256, (hh, ww, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(args.batch)]
-    pix, grid = fe(host)
+    hosts = [[torch.randint(0, 256, (hh, ww, 3), dtype=torch.uint8, generator=g).pin_memory() for _ in range(args.batch)] for _ in range(N_ROT)]
+    pix, grid = fe(hosts[0])
     assert pix.shape == inp["pix"].shape and grid.tolist() == inp["grid"].tolist(), (pix.shape, grid.tolist())
     r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
+    n_sub = [0]
 
     def go(k):
         for _ in range(k):
-            pv, gr = fe(host)
-            r.submit(inp["ids"].clone(), inp["am"], pv, gr, max_new_tokens=args.tnew, schedule=inp["sched"])
+            pv, gr = fe(hosts[n_sub[0] % N_ROT])
+            n_sub[0] += 1
+            ids, am, _ = next_batch(inp)
+            r.submit(ids, am, pv, gr, max_new_tokens=args.tnew, schedule=inp["sched"])
         r.flush()
     go(args.depth * args.merge)
     torch.cuda.synchronize()
@@ -486,35 +520,92 @@ def from_images_leg(model, inp, args, grid_hw, steps):
             "note": "timed region starts at uint8 HWC images in pinned host memory: H2D + GPU resize + normalize + patchify inside the loop"}
 
 
+def to_rle_leg(model, inp, args, steps):
+    """The headline pipeline with the timed region ending where the reference's eval loop ends (utils.py:252-266): score sigmoid, pixel
+    boxes, mask up-sampling to the 640 x 640 image + sigmoid > 0.5 on the device (padt_mask_upsample_binarize), COCO RLE on the host —
+    f1 of SURVEY.md §8f timed in the loop."""
+    from padt_amd import pipeline, postprocess
+    r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
+    sizes = [(640, 640)] * args.batch
+    n_rec = [0]
+
+    def post(done):
+        for decoded, completions, labels, vrts in done:
+            n_rec[0] += len(postprocess.postprocess_results(decoded, labels, sizes))
+
+    def go(k):
+        for _ in range(k):
+            ids, am, pix = next_batch(inp)
+            post(r.submit(ids, am, pix, inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]))
+        post(r.flush())
+    go(args.depth * args.merge)
+    n_rec[0] = 0
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    go(steps)
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    return {"value": round(args.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3),
+            "records": n_rec[0],
+            "note": "timed region ends at the eval loop's records: xywh pixel boxes, scores, binary 640 x 640 masks (device) and their COCO RLE (host)"}
+
+
+def csrc_sha16():
+    """sha256 (first 16 hex digits) over the kernel sources: what a committed PMC measurement was taken on."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "padt_amd", "csrc")
+    for f in sorted(os.listdir(d)):
+        h.update(f.encode())
+        h.update(open(os.path.join(d, f), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world and world == 1 and args.gpus > 1:
-        print(f"bench.py --gpus {args.gpus} must be launched with torch.distributed.run --nproc-per-node {args.gpus}", file=sys.stderr)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` as typed: become `python -m torch.distributed.run --nproc-per-node N bench.py ...` (one rank per GPU;
+        # 127.0.0.1 rendezvous — the container hostname may not resolve; torchrun's own chatter goes to stderr, rank 0's line to stdout)
+        import socket
+        s = socket.socket()
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+        s.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+    if args.gpus != world:
+        print(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree", file=sys.stderr)
         sys.exit(2)
-    if world > 1:
+    # PADT_DIST_FORCE=1: run the data-parallel code path (process group, device-side pack, asynchronous all-gather per decode group) at
+    # world size 1 too — on a one-GPU box that is the one way to put the exchange on RCCL itself (RCCL refuses two ranks per device)
+    dist_on = world > 1 or os.environ.get("PADT_DIST_FORCE") == "1"
+    if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29531")
         # PADT_DIST_BACKEND=gloo lets the multi-rank path be exercised on a single-GPU box (ranks share device 0); the
         # driver's runs use the default: nccl = RCCL over xGMI, one GPU per rank
         backend = os.environ.get("PADT_DIST_BACKEND", "nccl")
         local = local % torch.cuda.device_count()
         torch.cuda.set_device(local)
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), rank=rank, world_size=world)
         else:
-            dist.init_process_group(backend)
+            dist.init_process_group(backend, rank=rank, world_size=world)
     else:
         torch.cuda.set_device(0)
-    device = f"cuda:{local}" if world > 1 else "cuda:0"
+    device = f"cuda:{local}" if dist_on else "cuda:0"
     cfg, model, grid_hw = build_model(args, device)
-    inp = make_inputs(cfg, args, grid_hw, device, seed=1234 + rank)
+    inp = make_inputs(cfg, args, grid_hw, device, seed=1234 + rank, dtype=model.dtype)
 
     def barrier():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist_on:
             import torch.distributed as dist
             dist.barrier()
         torch.cuda.synchronize()
@@ -525,7 +616,7 @@ def main():
     # data-parallel exchange (world > 1): device-side pack of every batch's record, ONE asynchronous all-gather per decode group
     exchange = None
     gathered = []
-    if world > 1:
+    if dist_on:
         mask_hw = 4 * max(int(inp["grid"][:, 1].max()), int(inp["grid"][:, 2].max()))
         exchange = pipeline.ResultExchange(args.cap, mask_hw, per_gather=args.merge, device=device)
     dump = [] if args.dump_exchange else None
@@ -549,7 +640,8 @@ def main():
                 deliver(last)
         else:
             for _ in range(k):
-                for r in runner.submit(inp["ids"].clone(), inp["am"], inp["pix"], inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]):
+                ids_k, am_k, pix_k = next_batch(inp)
+                for r in runner.submit(ids_k, am_k, pix_k, inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"]):
                     last = r[0]
                     deliver(last)
             for r in runner.flush():
@@ -571,7 +663,7 @@ def main():
     decoded = run_steps(args.steps)
     barrier()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         t = torch.tensor([elapsed], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -582,7 +674,7 @@ def main():
         torch.save({"local": dump, "gathered": [g.cpu() for g in gathered], "cap": args.cap, "batch": args.batch},
                    os.path.join(args.dump_exchange, f"rank{rank}.pt"))
 
-    side = world == 1 and rank == 0 and not args.no_alt
+    side = not dist_on and rank == 0 and not args.no_alt
     # same workload with every batch decoding alone (merge = 1, two batches in flight), for comparison in the same run
     alt = None
     if side and runner is not None and args.merge > 1:
@@ -633,17 +725,21 @@ def main():
         n_img = args.batch * args.steps * world
         value = n_img / elapsed
         alg_tf = alg_tflop_per_image(cfg, inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], grid_hw)
-        fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), bf16 MFMA operands, fp32 "
-               "residual streams in ViT / LLM, split-precision PaDT decoder" + (", fp8 e4m3 LLM weights: fp8 x fp8 MFMA prompt pass + fp8 weight streaming in the decode steps" if args.weights == "fp8" else "") +
-               ", random-init weights; batches of %d submitted one by one, ViT/prefill/parse/PaDT decoder per batch, decode steps of %d consecutive "
-               "batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
+        ops_txt = ("fp16 MFMA operands (v_mfma_f32_16x16x32_f16: the bf16 rate, 3 more mantissa bits; bf16 checkpoint values)" if args.operands == "fp16"
+                   else "bf16 MFMA operands")
+        fmt = ("%s, batch=%d/GPU 640x640 synthetic (grid %dx%d, L=%d, T_new=%d, %d obj x %d VRT per image, mask head on), " + ops_txt + ", fp32 accumulation, fp32 "
+               "residual streams in ViT / LLM, split-precision (bf16 hi + lo) PaDT decoder" +
+               {"fp8": ", fp8 e4m3 LLM weights streamed by the decode steps (prompt pass on the dequantised 16-bit image)",
+                "fp8+act": ", fp8 e4m3 LLM weights: fp8 x fp8 MFMA prompt pass over e4m3 activation rows + fp8 weight streaming in the decode steps"}.get(args.weights, "") +
+               ", random-init weights; batches of %d submitted one by one (4 distinct input batches in rotation), ViT/prefill/parse/PaDT decoder per batch, "
+               "decode steps of %d consecutive batches share one weight pass (in-flight batching, per-sample results bit-identical to batch-at-a-time)")
         wl = fmt % ({"3b": "PaDT_Pro_3B", "7b": "PaDT_Pro_7B (untied head)", "small": "small_test_config (plumbing)"}[args.model] + " " + args.task.upper(),
                     args.batch, grid_hw[0], grid_hw[1], inp["L"], args.tnew, inp["n_obj"], inp["n_vrt"], args.batch, args.merge)
         line = {
             "metric": "images/sec PaDT_Pro_3B REC inference, 1/2/4/8 MI355X; box IoU vs ref",
             "value": round(value, 3), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "bf16", "data": "synthetic",
+            "vs_baseline": None, "dtype": args.operands, "data": "synthetic",
             "config": {"workload": wl,
                        "global_batch": args.batch * world, "parallelism": f"dp{world}", "batches_in_flight": args.depth * args.merge,
                        "decode_groups_in_flight": args.depth, "batches_per_decode_group": args.merge},
@@ -653,6 +749,7 @@ def main():
         }
         if exchange is not None:
             line["exchange"] = {"all_gathers": exchange.n_gathers, "batches_per_gather": args.merge, "bytes_per_rank_per_gather": exchange.words * 4 * args.merge,
+                                "continuation_gathers": exchange.n_continuation_gathers, "backend": os.environ.get("PADT_DIST_BACKEND", "nccl"),
                                 "note": "device-side pack (one kernel per batch) + one asynchronous all_gather_into_tensor per decode group"}
         if lat is not None:
             line["single_batch_latency"] = lat
@@ -667,26 +764,27 @@ def main():
                 traceback.print_exc(file=sys.stderr)
                 line[key] = {"error": f"{type(e).__name__}: {e}"[:300]}
 
-        if world == 1 and not args.no_roofline and runner is not None:
+        if not dist_on and not args.no_roofline and runner is not None:
             def roofs():
                 roof, dec = insitu_leg(model, inp, args, cfg, run_steps, min(args.steps, 16))
                 roof.update(replay_leg(model, inp, args, cfg))
                 line["roofline_decode"] = decode_alone_leg(model, inp, args, cfg, dec)
                 return roof
             leg("roofline", roofs)
-        if world == 1 and args.from_images and runner is not None:
+        if not dist_on and args.from_images and runner is not None:
             leg("from_images", lambda: from_images_leg(model, inp, args, grid_hw, min(args.steps, 24)))
-        if world == 1 and not args.no_cpu_baseline:
+            leg("to_rle", lambda: to_rle_leg(model, inp, args, min(args.steps, 24)))
+        if not dist_on and not args.no_cpu_baseline:
             leg("cpu_baseline", lambda: cpu_baseline_leg(cfg, args, inp, model))
         if isinstance(line.get("cpu_baseline"), dict) and "parity" in line["cpu_baseline"]:
             line["parity_vs_oracle"] = line["cpu_baseline"]["parity"]      # top level too: the metric's "box IoU vs ref" read-out of this run
-        if world == 1 and args.extras:
+        if not dist_on and args.extras:
             del runner
             m3, model = model, None
             leg("extra_workloads", lambda: extra_workloads(args, device, m3, cfg, grid_hw))
             del m3
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist_on:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()

@@ -159,6 +159,26 @@ class operand_floor:
         return False
 
 
+def folded_weight_images(w, cfg: PaDTConfig, dtype):
+    """The reference-layout dict with q / k / v / gate / up (ViT and LLM) replaced by round_dtype(w_norm * W) / w_norm: the same function of
+    the input, carrying the ONE weight-side rounding the HIP path adds — padt_amd/weights.py folds each RMSNorm weight into the rows of the
+    projection that consumes the normalised activations and rounds the product to the operand type."""
+    out = dict(w)
+
+    def fold(names, nw):
+        for nm in names:
+            out[nm] = (w[nm] * nw).to(dtype).float() / nw
+    for i in range(cfg.num_hidden_layers):
+        s = f"model.layers.{i}."
+        fold([s + "self_attn.q_proj.weight", s + "self_attn.k_proj.weight", s + "self_attn.v_proj.weight"], w[s + "input_layernorm.weight"])
+        fold([s + "mlp.gate_proj.weight", s + "mlp.up_proj.weight"], w[s + "post_attention_layernorm.weight"])
+    for i in range(cfg.vision_config.depth):
+        s = f"visual.blocks.{i}."
+        fold([s + "attn.qkv.weight"], w[s + "norm1.weight"])
+        fold([s + "mlp.gate_proj.weight", s + "mlp.up_proj.weight"], w[s + "norm2.weight"])
+    return out
+
+
 def bf16_operand_floor():
     """Every operand class rounded to bf16 (what rounds 2-3 measured and asserted against)."""
     return operand_floor(torch.bfloat16)

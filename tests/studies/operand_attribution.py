@@ -30,22 +30,7 @@ def rel(a, b):
 
 
 def folded(w, cfg, dt):
-    """The reference-layout dict with q/k/v/gate/up replaced by round_dt(w_norm * W) / w_norm: the same function of the input, with
-    the rounding the HIP path's folded weight images carry (padt_amd/weights.py folds the norm weight into the rows at load)."""
-    out = dict(w)
-
-    def fold(names, nw):
-        for nm in names:
-            out[nm] = (w[nm] * nw).to(dt).float() / nw
-    for i in range(cfg.num_hidden_layers):
-        s = f"model.layers.{i}."
-        fold([s + "self_attn.q_proj.weight", s + "self_attn.k_proj.weight", s + "self_attn.v_proj.weight"], w[s + "input_layernorm.weight"])
-        fold([s + "mlp.gate_proj.weight", s + "mlp.up_proj.weight"], w[s + "post_attention_layernorm.weight"])
-    for i in range(cfg.vision_config.depth):
-        s = f"visual.blocks.{i}."
-        fold([s + "attn.qkv.weight"], w[s + "norm1.weight"])
-        fold([s + "mlp.gate_proj.weight", s + "mlp.up_proj.weight"], w[s + "norm2.weight"])
-    return out
+    return U.folded_weight_images(w, cfg, dt)
 
 
 def main():

@@ -133,20 +133,26 @@ def test_prompt_plan_matches_oracle_rope_index(gold):
         plan_prompt(c3, bad, a3, g, "cpu")
 
 
-def test_weight_layout(tmp_path):
+@pytest.mark.parametrize("operands", ["fp16", "bf16"])
+def test_weight_layout(tmp_path, operands):
     cfg = padt_amd.small_test_config()
     sd = synthetic_state_dict(cfg, seed=1, bias_std=0.02)
     assert set(sd) == set(weight_shapes(cfg)) == set(O.weight_shapes(U.oracle_config(cfg)))
-    W = prepare_weights(sd, cfg, device="cpu")
+    W = prepare_weights(sd, cfg, device="cpu", operands=operands)
+    op = torch.float16 if operands == "fp16" else torch.bfloat16
+    assert W.op16 == op and W["vit.0.gu.w"].dtype == op and W["llm.embed"].dtype == op and W["proto.0.w"].dtype == op
+    assert all(v.dtype in (torch.bfloat16, torch.float32) for k, v in W.items() if k.startswith("dec."))      # the PaDT decoder's (hi, lo) pairs are bf16
     I, Ip = cfg.vision_config.intermediate_size, W.vit_ipad
     assert Ip % 64 == 0 and W["vit.0.gu.w"].shape == (2 * Ip, 160) and W["vit.0.down.w"].shape == (160, Ip)
-    g, u = sd["visual.blocks.0.mlp.gate_proj.weight"].bfloat16(), sd["visual.blocks.0.mlp.up_proj.weight"].bfloat16()
+    g, u = sd["visual.blocks.0.mlp.gate_proj.weight"].to(op), sd["visual.blocks.0.mlp.up_proj.weight"].to(op)
     gu = W["vit.0.gu.w"].view(Ip // 16, 2, 16, 160)
     assert torch.equal(gu[:, 0].reshape(Ip, 160)[:I], g) and torch.equal(gu[:, 1].reshape(Ip, 160)[:I], u)
     assert (gu[:, 0].reshape(Ip, 160)[I:] == 0).all() and (W["vit.0.down.w"][:, I:] == 0).all()
     hd = cfg.head_dim
     assert W["llm.0.qkv.w"].shape == ((2 + 2) * hd, 256)
-    assert torch.equal(W["llm.0.qkv.w"][2 * hd: 3 * hd], sd["model.layers.0.self_attn.k_proj.weight"].bfloat16())
+    assert torch.equal(W["llm.0.qkv.w"][2 * hd: 3 * hd], sd["model.layers.0.self_attn.k_proj.weight"].to(op))
+    with pytest.raises(ValueError, match="operands must be"):
+        prepare_weights(sd, cfg, device="cpu", operands="fp8")
     assert W["llm.head"] is W["llm.embed"]                                        # tied (3B); 7B config is untied
     a = torch.arange(32).view(32, 1)
     assert interleave16(a, a + 100).view(-1).tolist()[:34] == list(range(16)) + list(range(100, 116)) + [16, 17]

@@ -2,8 +2,8 @@
 the reference's own `custom_visual_forward` block and `vl_decode` / `PaDTDecoder`, tests/golden/make_golden.py): one ViT block at
 2116 x 1280 (window and full attention) and the 98 M-parameter PaDT decoder with 3 objects over 2 images.
 
-The reference ran in fp32; the HIP path stores weights and activations in bf16 → tolerances are bf16-storage sized and written
-at each assert."""
+The reference ran in fp32; the HIP path multiplies 16-bit operands (fp16 by default since round 4, bf16 as the A/B variant) → tolerances
+are sized by the operand type and written at each assert."""
 import dataclasses
 import os
 
@@ -30,7 +30,8 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item(), ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
 
 
-def test_vit_block_real_shape_against_reference_output(golden_dir):
+@pytest.mark.parametrize("operands", ["fp16", "bf16"])
+def test_vit_block_real_shape_against_reference_output(golden_dir, operands):
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import padt_amd
@@ -47,21 +48,24 @@ def test_vit_block_real_shape_against_reference_output(golden_dir):
     for k, shp in O.weight_shapes(ocfg).items():                    # the seeded block weights the reference ran with
         if k.startswith("visual.blocks.0."):
             sd[k] = _seeded(shp, k, 0.1, True) if (k.endswith("norm1.weight") or k.endswith("norm2.weight")) else _seeded(shp, k, 0.02)
-    W = prepare_weights(sd, cfg, device="cuda")
+    W = prepare_weights(sd, cfg, device="cuda", operands=operands)
     enc = VisionEncoder(cfg, W, "cuda")
     grid = torch.tensor([[1, 46, 46]])
     plan = enc.plan(grid)
     g = torch.Generator().manual_seed(int(z["x_seed"]))
-    x0 = torch.randn(2116, 1280, generator=g).to(torch.bfloat16).cuda()
+    x0 = torch.randn(2116, 1280, generator=g).to(W.op16).cuda()
     rows = _t(z["rows"])
     for full, key in ((False, "y_win"), (True, "y_full")):
         x = x0.clone()
-        bufs = (torch.empty(2116, device="cuda", dtype=torch.float32), torch.empty(2116, 3 * 1280, device="cuda", dtype=torch.bfloat16),
-                torch.empty_like(x), torch.empty(2116, W.vit_ipad, device="cuda", dtype=torch.bfloat16))
+        bufs = (torch.empty(2116, device="cuda", dtype=torch.float32), torch.empty(2116, 3 * 1280, device="cuda", dtype=W.op16),
+                torch.empty_like(x), torch.empty(2116, W.vit_ipad, device="cuda", dtype=W.op16))
         enc.block(0, x, plan, *bufs, force_full=full)
         mx, rms = rel(x[rows.cuda()], _t(z[key]))
-        print(f"\\n[real ViT block {key}] vs reference: rel max {mx:.3e} rms {rms:.3e}")
-        assert rms < 1.5e-2 and mx < 6e-2, f"{key}: rel err max {mx:.3e} rms {rms:.3e}"   # bf16 weights + activations, 7 kernels deep
+        print(f"\\n[real ViT block {key}, {operands} operands and stream] vs reference: rel max {mx:.3e} rms {rms:.3e}")
+        # 16-bit weights + activations + residual stream (this call runs the block without the fp32 stream), 7 kernels deep: bf16 measured
+        # 3.2e-3 rms; fp16 carries 3 more mantissa bits
+        lim = (1.5e-2, 6e-2) if operands == "bf16" else (3e-3, 1.2e-2)
+        assert rms < lim[0] and mx < lim[1], f"{key}: rel err max {mx:.3e} rms {rms:.3e}"
 
 
 @pytest.mark.parametrize("hp", [True, False])
@@ -176,7 +180,7 @@ def test_llm_layer_real_width_against_hf_text_model(golden_dir):
     lm = model.lm
     plan = plan_prompt(cfg, ids, torch.ones_like(ids), grid, "cuda")
     sess = lm.session(1, 577 + 4, 529, 4)
-    img = x[0][is_img].to(torch.bfloat16).cuda()
+    img = x[0][is_img].to(model.W.op16).cuda()
     hn = lm.prefill(plan, img, sess)
     rows = _t(z["rows"]).cuda()
     mx, rms = rel(hn[rows], _t(z["h_rows"]))
@@ -273,10 +277,12 @@ def test_vrt_head_logits_do_not_depend_on_the_batch():
 def test_full_depth_3b_teacher_forced_against_oracle():
     """The WHOLE PaDT_Pro_3B geometry (32 ViT blocks at 2116 x 1280, 36 LLM layers at D = 2048 / 16:2 heads / MLP 11008,
     151 936 + 529 table rows, 98 M-parameter decoder) for one 46 x 46 image, seeded random weights (bf16-representable, biases
-    and norm jitter on), against the fp32 CPU oracle teacher-forced on the HIP tokens.  The tolerance is DERIVED, not chosen: the
-    oracle is run a second time inside parity_util.bf16_operand_floor() (every matmul operand on the activation side rounded to
-    bf16, everything else fp32 — the distance ANY bf16-MFMA implementation has) and every float quantity of the HIP path must be
-    within 2x that floor on the same inputs; box coordinates additionally within the north star's flat 1e-3.  (≈1 min of host CPU.)
+    and norm jitter on), against the fp32 CPU oracle teacher-forced on the HIP tokens.  Two bars.  FLAT (the north star / the round-3
+    verdict): box coordinates <= 1e-3, mask logits <= 5e-3 of their range or 1.5x the attributed floor.  DERIVED: the oracle is run a second
+    time inside parity_util.operand_floor(the model's operand type) on the model's norm-folded weight images (every matmul operand on the
+    activation side rounded to fp16, the folded q/k/v/gate/up matrices rounded like weights.py rounds them, everything else fp32 — the
+    distance ANY implementation on these MFMA operands has; tests/studies/operand_attribution.py attributes it class by class) and
+    every float quantity of the HIP path must be within 2x that floor on the same inputs.  (≈1 min of host CPU.)
       * generated ids: margin rule — a HIP token must be the oracle's arg-max unless the oracle's own top-2 margin is inside the
         logit noise the floor run shows at that step (2 x max |logit_floor - logit_fp32|); then it must be within that noise of the max;
       * ViT outputs, prototypes, per-step last-layer hidden rows: relative rms <= 2 x floor;
@@ -310,19 +316,22 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
-        with U.bf16_operand_floor():
-            fres = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        op = model.W.op16
+        wf = U.folded_weight_images(w, cfg, op)
+        with U.operand_floor(op):
+            fres = O.generate(wf, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        del wf
     t_or = time.perf_counter() - t0
     assert torch.equal(ores["sequences"], seq)
     st, fst = ores["state"], fres["state"]
-    stream = "fp32" if model.W.resid_f32 else "bf16"
+    stream = ("fp32" if model.W.resid_f32 else "bf16") + " streams, " + str(op).replace("torch.", "") + " operands"
     K = 2.0 if model.W.resid_f32 else 6.0                           # PADT_RESID_F32=0 (round-2 arithmetic, kept for A/B runs) sits 2.2-3x above the floor
     # ---- ViT (32 blocks) and prototypes
     mx, rms_h = rel(out.past_high_res_image_embeds, st.high_res)
     mxp, rms_p = rel(out.past_image_embeds, st.proto)
     _, frms_h = rel(fst.high_res, st.high_res)
     _, frms_p = rel(fst.proto, st.proto)
-    print(f"\n[full 3B, {stream} residual streams] oracle fp32 + bf16-operand floor {t_or:.1f} s on {torch.get_num_threads()} threads")
+    print(f"\n[full 3B, {stream}] oracle fp32 + operand floor {t_or:.1f} s on {torch.get_num_threads()} threads")
     print(f"[full 3B] ViT high_res rel rms {rms_h:.3e} (floor {frms_h:.3e}, x{rms_h / frms_h:.2f}); prototypes rel rms {rms_p:.3e} (floor {frms_p:.3e}, x{rms_p / frms_p:.2f})")
     assert rms_h < K * frms_h and rms_p < K * frms_p
     # ---- ids: margin rule with the measured logit noise
@@ -382,6 +391,8 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     assert db < K * fdb + 2e-4 and ds < K * fds + 1e-3 and mx < K * fmx and rms < K * frms
     if model.W.resid_f32:
         assert db < 1e-3 and iou > 0.99                              # north star on the box coordinates, end to end at full depth
+    if op == torch.float16:
+        assert mx < max(5e-3, 1.5 * fmx), f"mask logits {mx:.3e} of their range (attributed floor {fmx:.3e})"
 
 
 def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
@@ -389,11 +400,10 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     — 64-row decode steps, 8 x 529 prototypes per batch in one table, 16 REC tokens per image (VRT run of 5) — against
       (a) the un-merged path (rec_batch, one batch at a time): tokens, boxes, scores, mask logits BIT-identical for every batch;
       (b) the fp32 CPU oracle teacher-forced on the HIP tokens for all 8 samples of one batch (≈2 min of host CPU), and the oracle's
-          bf16-operand floor run (parity_util.bf16_operand_floor) on the first 3 of those images (samples are independent; ≈1 min):
-          every token by the margin rule with 2x the logit noise the floor run shows at that step (relative to the largest |logit|,
-          worst of the 3 floor samples); the batch's largest box error within 3x the largest of the 3 floor samples (+2e-4), every
-          IoU > 0.98, mask logits within 3x the floor's.  (The north star's flat 1e-3 on box coordinates is below what bf16 MFMA
-          operands alone allow on several of these 8 images — the floor run's own errors are printed.)"""
+          operand-floor run (parity_util.operand_floor on the model's operand type and folded weight images) on the first 3 of those
+          images (samples are independent; ≈1 min): every token by the margin rule with 2x the logit noise the floor run shows at that
+          step (relative to the largest |logit|, worst of the 3 floor samples); FLAT: EVERY sample's box coordinates within the north
+          star's 1e-3 (round 3 on bf16 operands: 1 of 8), every IoU > 0.995, mask logits within 5e-3 of their range or 1.5x the floor's."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
@@ -418,13 +428,13 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=8)
     res = []
     for grid, pix, ids, am in batches:
-        res += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda().to(torch.bfloat16), grid, max_new_tokens=T, schedule=sched)
+        res += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda().to(model.dtype), grid, max_new_tokens=T, schedule=sched)
     res += runner.flush()
     assert len(res) == NB
     # ---- (a) merged == un-merged, bit for bit
     for i in (0, 3, 7, 9):
         grid, pix, ids, am = batches[i]
-        dec1, comp1, lab1, vrt1 = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda().to(torch.bfloat16), grid,
+        dec1, comp1, lab1, vrt1 = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda().to(model.dtype), grid,
                                                      max_new_tokens=T, schedule=sched)
         decm, compm, labm, vrtm = res[i]
         assert compm == comp1 and vrtm == vrt1, f"batch {i}: tokens differ between merged and un-merged decode"
@@ -433,7 +443,7 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     # ---- (b) one batch, all 8 samples, against the oracle
     grid, pix, ids, am = batches[0]
     out = model.generate(input_ids=proc.assign_to_global_vrt_id(ids.clone(), grid).cuda(), attention_mask=am.cuda(),
-                         pixel_values=pix.cuda().to(torch.bfloat16), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+                         pixel_values=pix.cuda().to(model.dtype), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
     L = ids.shape[1]
     toks = out.sequences[:, L:].cpu()
     decm = res[0][0]
@@ -443,13 +453,16 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
         NF = 3                                                      # floor run on the first NF images (samples are independent)
         P1 = 46 * 46
-        with U.bf16_operand_floor():
-            fres = O.generate(w, oc, ids[:NF], am[:NF], pix[: NF * P1], grid[:NF], T, schedule=sched, collect_logits=True, force_tokens=toks[:NF])
+        op = model.W.op16
+        wf = U.folded_weight_images(w, cfg, op)
+        with U.operand_floor(op):
+            fres = O.generate(wf, oc, ids[:NF], am[:NF], pix[: NF * P1], grid[:NF], T, schedule=sched, collect_logits=True, force_tokens=toks[:NF])
+        del wf
         vf = lambda r, nb: [[torch.cat([r["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(nb)]
         ost, fst = ores["state"], fres["state"]
         odec = O.vl_decode(w, oc, vf(ores, B), ost.proto, ost.high_res, grid, ost.visual_pe)
         fdec = O.vl_decode(w, oc, vf(fres, NF), fst.proto, fst.high_res, grid[:NF], fst.visual_pe)
-    print(f"\n[3B batch 8] oracle fp32 on 8 images + bf16-operand floor on {NF}, {T} tokens: {time.perf_counter() - t0:.1f} s")
+    print(f"\n[3B batch 8, {str(op).replace('torch.', '')} operands] oracle fp32 on 8 images + operand floor on {NF}, {T} tokens: {time.perf_counter() - t0:.1f} s")
     # logit noise of the floor run per step, as a fraction of the largest |logit| of that row (worst of the NF floor samples)
     frac = []
     for t in range(T):
@@ -483,22 +496,29 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     mx, rms = rel(decm["pred_mask"], odec["pred_mask"])
     fmx, frms = rel(fdec["pred_mask"], odec["pred_mask"][:NF])
     print(f"[3B batch 8] tokens: {n_arg}/{B * T} the oracle's arg-max, {n_tie} inside the logit noise; box |d|max per sample "
-          f"{[f'{x:.1e}' for x in db.tolist()]} (bf16-operand floor {[f'{x:.1e}' for x in fdb.tolist()]}); IoU min {min(ious):.4f}; "
+          f"{[f'{x:.1e}' for x in db.tolist()]} (operand floor {[f'{x:.1e}' for x in fdb.tolist()]}); IoU min {min(ious):.4f}; "
           f"mask logits rel max {mx:.3e} (floor {fmx:.3e}) rms {rms:.3e} (floor {frms:.3e})")
     assert n_arg >= int(0.85 * B * T)
-    assert float(db.max()) < 3 * float(fdb.max()) + 2e-4 and min(ious) > 0.98 and mx < 3 * fmx and rms < 3 * frms
+    assert float(db.max()) < 3 * float(fdb.max()) + 2e-4 and mx < 3 * fmx and rms < 3 * frms
+    if op == torch.float16:
+        assert float(db.max()) < 1e-3, f"box coordinates of {int((db >= 1e-3).sum())} of {B} samples beyond 1e-3"
+        assert min(ious) > 0.995 and mx < max(5e-3, 1.5 * fmx)
+    else:
+        assert min(ious) > 0.98
 
 
-@pytest.mark.parametrize("llm_weights", ["bf16", "fp8"])
+@pytest.mark.parametrize("llm_weights", ["bf16", "fp8", "fp8+act"])
 def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     """BASELINE configs[4] at ITS geometry: padt_pro_7b() — D = 3584, 28 q / 4 kv heads (GQA group 7), MLP 18944 (padded to 18944 = 296 x 64),
     untied 152 064-row lm_head next to the embedding table, real 1280-wide ViT blocks and the real 98 M-parameter decoder — with the depth cut
     to 2 LLM layers / 2 ViT blocks so that the fp32 oracle runs in seconds.  Two ragged images, a RIC-shaped completion (caption text with
     4 interleaved runs of 5 VRTs, src/preprocess/process_ric.py:147,150 templates) through generate → parse → vl_decode:
-    ids by the margin rule, per-step hidden rows, object grouping of the parser, boxes.  bf16 weights, and the fp8 e4m3 path: the prompt
-    pass runs fp8 x fp8 MFMA GEMMs (activation rows quantised to e4m3 on the fly), the decode steps stream the fp8 weight image against
-    bf16 activations; the oracle runs the dequantised matrices (parity_util.effective_llm_weights) and quantises the same activation
-    rows at prompt length (parity_util.fp8_prefill_hooks)."""
+    ids by the margin rule, per-step hidden rows, object grouping of the parser, boxes.  16-bit weights; "fp8": e4m3 WEIGHTS (the decode
+    steps stream the fp8 image, the prompt pass multiplies the exactly dequantised 16-bit image) against the oracle on the dequantised
+    matrices (parity_util.effective_llm_weights) — same bounds as the 16-bit weights; "fp8+act": the prompt pass additionally runs fp8 x fp8
+    MFMA GEMMs over activation rows quantised to e4m3 on the fly, and the oracle quantises the same rows at prompt length
+    (parity_util.fp8_prefill_hooks).  The token margin is DERIVED in the test: 2x the logit noise of the oracle's operand-floor run
+    (parity_util.operand_floor on the model's operand type) at that step; e4m3 activations get the flat bound their noise needs (stated)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import padt_amd
@@ -513,8 +533,9 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
         (3584, 28, 4, 18944, 152064, False)
     w = U.bf16_weights(cfg, seed=31, std=0.02)
     model = PaDTForConditionalGeneration(cfg, w, device="cuda", llm_weights=llm_weights)
-    assert ("llm.0.gu.wq" in model.W) == (llm_weights == "fp8") and model.W["llm.head"].data_ptr() != model.W["llm.embed"].data_ptr()
-    wo = U.effective_llm_weights(model, w) if llm_weights == "fp8" else w
+    fp8, act8 = llm_weights != "bf16", llm_weights == "fp8+act"
+    assert ("llm.0.gu.wq" in model.W) == fp8 and model.W.fp8_prefill == act8 and model.W["llm.head"].data_ptr() != model.W["llm.embed"].data_ptr()
+    wo = U.effective_llm_weights(model, w) if fp8 else w
     oc = U.oracle_config(cfg)
     grids = [[1, 16, 20], [1, 12, 12]]
     grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=9, n_post=20, ragged=True, seed=88)
@@ -525,10 +546,12 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     seq = out.sequences.cpu()
     toks = seq[:, L:]
     assert toks.shape == (2, T) and (toks[:, -1] == cfg.eos_token_id).all()
-    if llm_weights == "fp8":
-        assert model.W.fp8_prefill and all(f"llm.0.{nm}.w8" in model.W for nm in ("qkv", "o", "gu", "down"))     # every 7B projection takes padt_gemm_fp8
-    with torch.no_grad(), U.fp8_prefill_hooks(model):              # (no-op for bf16 weights) prompt pass with e4m3 activation rows
+    if act8:
+        assert all(f"llm.0.{nm}.w8" in model.W for nm in ("qkv", "o", "gu", "down"))     # every 7B projection takes padt_gemm_fp8
+    with torch.no_grad(), U.fp8_prefill_hooks(model):              # (no-op without e4m3 activations) prompt pass with e4m3 activation rows
         ores = O.generate(wo, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    with torch.no_grad(), U.operand_floor(model.W.op16):           # the distance the model's MFMA operand type alone imposes, on these inputs
+        fres = O.generate(U.folded_weight_images(wo, cfg, model.W.op16), oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
     n_tie = 0
     for t in range(T):
         lg = ores["logits"][t]
@@ -536,7 +559,10 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
         chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
         for b in range(2):
             fin = torch.isfinite(lg[b])
-            floor = 2.5e-2 * lg[b][fin].abs().max().item()          # bf16-operand logit noise: 1.8-2.5 % of |logit|max (measured at full depth)
+            # 2 x the floor run's logit noise at this step; e4m3 activation rows (3-bit mantissa, not in the floor run): 2.5 % of |logit|max
+            floor = 2 * (fres["logits"][t][b][fin] - lg[b][fin]).abs().max().item()
+            if act8:
+                floor = max(floor, 2.5e-2 * lg[b][fin].abs().max().item())
             second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
             if (top2[b, 0] - second).item() > floor:
                 assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
@@ -553,7 +579,8 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
         # 12.5 % step), so after the first fp8 GEMM the two sides' quantisation errors (3.6 % rms per GEMM each) decorrelate: agreement with the
         # oracle that quantises the same rows is the fp8 noise level itself — measured 9.4e-2 on the prompt's last row after 2 layers x 4 GEMMs
         # at 7B width, 1-1.5e-2 on the decode-step rows (bf16 activations over the fp8-prefilled KV)
-        assert rms < (1.5e-1 if llm_weights == "fp8" else 1.5e-2), f"hidden step {t}: rel rms {rms:.3e}"
+        _, frms = rel(fres["hidden"][t][:, -1], ores["hidden"][t][:, -1])
+        assert rms < (1.5e-1 if act8 else 3 * frms + 1e-4), f"hidden step {t}: rel rms {rms:.3e} (operand floor {frms:.3e})"
     # ---- parser: 4 interleaved VRT runs per sample → 4 objects of 5 VRT features each; decoder on both sides
     n_m = [g[1] * g[2] // 4 for g in grids]
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, max(n_m)), 2)
@@ -571,7 +598,9 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
     mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
     print(f"\n[7B geometry, {llm_weights}] ties {n_tie}/{2 * T}; hidden rel rms worst {worst:.3e}; {2 * n_obj} objects: box |d|max {db:.3e}, mask rel max {mx:.3e} rms {rms:.3e}")
-    assert (db < 5e-3 and mx < 5e-2) if llm_weights == "fp8" else (db < 2e-3 and mx < 3e-2)   # measured: fp8 1.6e-3 / 1.3e-2, bf16 6.6e-4 / 8.3e-3
+    # e4m3 activations (measured in round 3: boxes 1.6e-3, mask logits 1.3e-2 — the price of a 3-bit mantissa at prompt length); 16-bit
+    # activations: the north star's 1e-3 on the boxes, mask logits 5e-3 of their range
+    assert (db < 5e-3 and mx < 5e-2) if act8 else (db < 1e-3 and mx < 5e-3)
 
 
 def test_padt_decoder_ovd_shape_seven_objects_per_image():
@@ -614,3 +643,189 @@ def test_padt_decoder_ovd_shape_seven_objects_per_image():
     mx, rms = rel(out["pred_mask"], odec["pred_mask"])
     print(f"\n[OVD-shape decoder, 14 objects] vs oracle: box |d|max {db:.3e} score |d|max {ds:.3e} mask rel max {mx:.3e} rms {rms:.3e}")
     assert db < 1e-3 and ds < 1e-3 * (odec["pred_score"].abs().max().item() + 1) and mx < 1e-3 and rms < 1e-3
+
+
+def _margin_rule(lg, tok, noise, what):
+    """A HIP token must be the oracle's arg-max unless the oracle's own top-2 margin is inside `noise`; then within `noise` of the max.
+    → 1 if the token was decided by the arg-max, 0 if it was a near-tie inside the bound."""
+    top2 = lg.topk(2).values
+    margin = (top2[0] - (top2[1] if torch.isfinite(top2[1]) else top2[0] - 1)).item()
+    gap = top2[0].item() - lg[tok].item()
+    if gap == 0.0:
+        return 1
+    assert margin <= noise and gap <= noise, f"{what}: HIP token is not the oracle arg-max (margin {margin:.3e}, gap {gap:.3e}, noise bound {noise:.3e})"
+    return 0
+
+
+def test_3b_ovd_geometry_merged_runner_against_oracle():
+    """BASELINE configs[3] at ITS geometry and depth: PaDT_Pro_3B (32 ViT blocks, 36 layers), OVD batches of 8 images — the 80-class
+    prompt (L = 890), T = 120 new tokens, 7 objects x 5 VRT per image (eval/evaluation_scripts/inference_coco.py:101-110) — through
+    PipelinedRunner(depth 2, merge 16), nine batches so that the group's decode steps run the 128-row launch shapes (72 rows):
+      (a) all 8 samples of the first and of the last batch bit-identical to the un-merged path (tokens, 56 boxes, scores, mask logits);
+      (b) the fp32 CPU oracle teacher-forced on the HIP tokens of 2 samples (≈950 cached keys by the last step): every one of the 2 x 120
+          tokens by the margin rule — noise bound 0.8 % of the largest |logit| = 2x what fp16 operands + folded weight images cost at full
+          depth (profiles/r04_operand_attribution.md, last row) —, the parser's 7 objects per sample, 14 boxes within the north star's 1e-3,
+          mask logits within 5e-3 of their range."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import padt_amd
+    import parity_util as U
+    from padt_amd import pipeline
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.synthetic import multi_object_schedule
+    from padt_amd.weights import synthetic_state_dict
+    O = U.O
+    cfg = padt_amd.padt_pro_3b()
+    sd = synthetic_state_dict(cfg, seed=3, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda")
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    oc = U.oracle_config(cfg)
+    B, T, NB, n_obj, n_vrt = 8, 120, 9, 7, 5
+    sched = multi_object_schedule(T, n_obj=n_obj, n_vrt=n_vrt)
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = [U.synthetic_batch(cfg, [[1, 46, 46]] * B, n_pre=15, n_post=346, seed=700 + i) for i in range(NB)]
+    assert batches[0][2].shape == (B, 890)
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=16)
+    res = []
+    for grid, pix, ids, am in batches:
+        res += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda().to(model.dtype), grid, max_new_tokens=T, schedule=sched)
+    res += runner.flush()
+    assert len(res) == NB
+    for i in (0, NB - 1):                                            # ---- (a)
+        grid, pix, ids, am = batches[i]
+        dec1, comp1, lab1, vrt1 = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda().to(model.dtype), grid,
+                                                     max_new_tokens=T, schedule=sched)
+        decm, compm, labm, vrtm = res[i]
+        assert decm["pred_boxes"].shape == (B * n_obj, 4) and all(len(v) == n_obj for v in vrtm)
+        assert compm == comp1 and vrtm == vrt1, f"batch {i}: tokens differ between merged (128-row steps) and un-merged decode"
+        for k in ("pred_boxes", "pred_score", "pred_mask"):
+            assert torch.equal(decm[k], dec1[k]), f"batch {i}: {k} differs between merged and un-merged decode"
+    # ---- (b) two samples of batch 0 against the oracle
+    NS = 2
+    grid, pix, ids, am = batches[0]
+    P1 = 46 * 46
+    gids = proc.assign_to_global_vrt_id(ids.clone(), grid)
+    out = model.generate(input_ids=gids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda().to(model.dtype), image_grid_thw=grid,
+                         max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    toks = out.sequences[:, L:].cpu()
+    # sample b's global VRT ids are offset by b x 529 in the batch of 8; alone (rows 0..NS-1 of the batch) the offsets are the same
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ores = O.generate(w, oc, gids[:NS], am[:NS], pix[: NS * P1], grid[:NS], T, schedule=sched, collect_logits=True, force_tokens=toks[:NS])
+        runs = [[t for t in range(T) if sched[t] == "v"][k * n_vrt: (k + 1) * n_vrt] for k in range(n_obj)]
+        st = ores["state"]
+        ofeats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in r], 0) for r in runs] for b in range(NS)]
+        odec = O.vl_decode(w, oc, ofeats, st.proto, st.high_res, grid[:NS], st.visual_pe)
+    t_or = time.perf_counter() - t0
+    n_arg = 0
+    for b in range(NS):
+        for t in range(T):
+            lg = ores["logits"][t][b]
+            fin = torch.isfinite(lg)
+            n_arg += _margin_rule(lg, int(toks[b, t]), 8e-3 * lg[fin].abs().max().item(), f"sample {b} step {t}")
+    decm = res[0][0]
+    sel = [i for i, s_ in enumerate(decm["sample_idx"]) if s_ < NS]
+    assert [decm["sample_idx"][i] for i in sel] == odec["sample_idx"] == [0] * n_obj + [1] * n_obj
+    db = (decm["pred_boxes"][sel].cpu().float() - odec["pred_boxes"]).abs().amax(dim=1)
+    mx, rms = rel(decm["pred_mask"][sel], odec["pred_mask"])
+    print(f"\n[3B OVD geometry, {model.dtype}] L = {L}, T = {T}, {NB} batches in a 16-batch decode group; oracle on {NS} samples {t_or:.1f} s; "
+          f"tokens {n_arg}/{NS * T} the oracle's arg-max (rest inside the bound); 14 boxes |d|max {float(db.max()):.3e}; mask logits rel max {mx:.3e} rms {rms:.3e}")
+    assert n_arg >= int(0.9 * NS * T)
+    assert float(db.max()) < 1e-3 and mx < 5e-3
+
+
+@pytest.mark.parametrize("llm_weights", ["bf16", "fp8+act"])
+def test_7b_full_depth_single_image_against_oracle(llm_weights):
+    """BASELINE configs[4] at FULL depth: padt_pro_7b() — 28 layers at D = 3584 / 28:4 heads / MLP 18944, untied 152 064-row head, 32 ViT
+    blocks — one 46 x 46 image, a RIC-shaped completion (2 VRT runs of 3) through generate → parse → vl_decode, against the fp32 CPU oracle
+    teacher-forced on the HIP tokens (33 GB of fp32 weights on the host).  16-bit weights: every float quantity within 2x the oracle's
+    operand floor (parity_util.operand_floor on the model's operand type and folded weight images) and boxes within the north star's 1e-3.
+    "fp8+act" (fp8 weight streaming in the decode steps + fp8 x fp8 MFMA prompt pass over e4m3 activation rows), against the oracle on the
+    dequantised matrices quantising the same rows: the measured full-depth price of e4m3 activations is PRINTED and bounded (boxes 1e-2,
+    IoU > 0.95) — it is what bench.py's ric_7b_fp8 workload string quotes."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import padt_amd
+    import parity_util as U
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.synthetic import multi_object_schedule
+    from padt_amd.weights import synthetic_state_dict
+    O = U.O
+    cfg = padt_amd.padt_pro_7b()
+    assert (cfg.num_hidden_layers, cfg.hidden_size, cfg.vision_config.depth) == (28, 3584, 32)
+    sd = synthetic_state_dict(cfg, seed=41, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda", llm_weights=llm_weights)
+    act8 = llm_weights == "fp8+act"
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    if act8:
+        w = U.effective_llm_weights(model, w)
+    oc = U.oracle_config(cfg)
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 46, 46]], n_pre=15, n_post=33, seed=78)
+    T, n_obj, n_vrt = 14, 2, 3
+    sched = multi_object_schedule(T, n_obj=n_obj, n_vrt=n_vrt)
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    seq = out.sequences.cpu()
+    toks = seq[:, L:]
+    assert toks.shape == (1, T) and int(toks[0, -1]) == cfg.eos_token_id
+    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        with U.fp8_prefill_hooks(model):
+            ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        fres = None
+        if not act8:
+            wf = U.folded_weight_images(w, cfg, model.W.op16)
+            with U.operand_floor(model.W.op16):
+                fres = O.generate(wf, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+            del wf
+    t_or = time.perf_counter() - t0
+    n_arg, n_out, worst, worst_floor = 0, 0, 0.0, 0.0
+    hid = out.hidden_states.last_layer_rows().cpu().float()
+    for t in range(T):
+        lg = ores["logits"][t][0]
+        fin = torch.isfinite(lg)
+        if act8:
+            # e4m3 activation rows at prompt length, 28 layers deep: a flat (stated) 5 % bound, and a token outside it is COUNTED, not fatal —
+            # two implementations of the same discontinuous quantised function decorrelate (DESIGN.md §4 numerics)
+            try:
+                n_arg += _margin_rule(lg, int(toks[0, t]), 5e-2 * lg[fin].abs().max().item(), f"step {t}")
+            except AssertionError:
+                n_out += 1
+        else:
+            n_arg += _margin_rule(lg, int(toks[0, t]), 2 * (fres["logits"][t][0][fin] - lg[fin]).abs().max().item(), f"step {t}")
+        _, rms = rel(hid[t], ores["hidden"][t][:, -1])
+        worst = max(worst, rms)
+        if not act8:
+            _, frms = rel(fres["hidden"][t][:, -1], ores["hidden"][t][:, -1])
+            worst_floor = max(worst_floor, frms)
+            assert rms < 2 * frms + 1e-4, f"hidden step {t}: rel rms {rms:.3e} vs operand floor {frms:.3e}"
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    local = proc.assign_to_local_vrt_id(seq.clone(), grid)[:, L:]
+    comps, feats, labels, vrts, _ = padt_amd.parseVRTintoCompletion(proc, local, out["hidden_states"], torch.Tensor([False]))
+    assert [len(f) for f in feats] == [n_obj] and all(o.shape == (n_vrt, cfg.hidden_size) for o in feats[0])
+    dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+    runs = [[t for t in range(T) if sched[t] == "v"][k * n_vrt: (k + 1) * n_vrt] for k in range(n_obj)]
+    with torch.no_grad():
+        st = ores["state"]
+        odec = O.vl_decode(w, oc, [[torch.cat([ores["hidden"][t][0:1, -1] for t in r], 0) for r in runs]], st.proto, st.high_res, grid, st.visual_pe)
+    db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
+    mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
+    ious = [O.box_iou_xywh(*[[float(x[0] - x[2] / 2), float(x[1] - x[3] / 2), float(x[2]), float(x[3])] for x in (dec["pred_boxes"][k].cpu(), odec["pred_boxes"][k])])
+            for k in range(n_obj)]
+    print(f"\n[7B full depth, {llm_weights}, {model.dtype} operands] oracle {t_or:.1f} s; tokens {n_arg}/{T} the oracle's arg-max, {n_out} outside the bound; hidden rel rms worst "
+          f"{worst:.3e} (operand floor {worst_floor:.3e}); {n_obj} boxes |d|max {db:.3e} IoU min {min(ious):.4f}; mask logits rel max {mx:.3e} rms {rms:.3e}")
+    if act8:
+        assert db < 1e-2 and min(ious) > 0.95 and n_out <= T // 4
+    else:
+        assert db < 1e-3 and min(ious) > 0.995 and mx < 5e-3
