@@ -1,6 +1,8 @@
 """Host logic of the product path against the reference-generated golden vectors and the oracle: processor wrapper,
 completion parser (incl. the dropped-sample quirk), 4.50 rope index, ViT index tables, weight layout, rank striding.
 No GPU, no HIP calls."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -252,3 +254,32 @@ def test_gumbel_uniform_is_strictly_inside_the_unit_interval():
         assert np.isfinite(-np.log(-np.log(u)))
     bad = f(f(f(0xFFFFFFFF >> 8) + f(0.5)) * f(1.0 / 16777216.0))
     assert bad == f(1.0)                                            # what the old expression did
+
+
+def test_processor_and_parser_on_a_real_bpe_tokenizer(golden_dir):
+    """a10 / a11 against the reference's own outputs on a REAL tokenizer (tests/golden/make_golden_tok.py): byte-level BPE inside a
+    transformers PreTrainedTokenizerFast, rebuilt from the JSON stored in the fixture — AddedToken semantics of the <|empty_token_i|> /
+    <|VRT_k|> additions, per-token strings with leading blanks and punctuation merges through the parser's string tests (REC, OVD with
+    multi-token labels, thinking mode, a run cut by max_new_tokens → sample dropped), and the image_prototype branch's
+    processor(text=vrts_str) round trip (padt_processor.py:15-28,76,134)."""
+    import importlib.util
+    import json
+    spec = importlib.util.spec_from_file_location("mk_tok", os.path.join(golden_dir, "make_golden_tok.py"))
+    mk = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mk)
+    z = np.load(os.path.join(golden_dir, "real_tokenizer.npz"))
+    got = mk.run(padt_amd.VisonTextProcessingClass, padt_amd.parseVRTintoCompletion, str(z["tokenizer_json"]))
+    assert set(got) == set(z.files) - {"tokenizer_json"}
+    for k, v in got.items():
+        ref = z[k]
+        if isinstance(v, str):
+            assert v == str(ref), (k, v, str(ref))
+        elif isinstance(v, (int, np.integer)):
+            assert int(v) == int(ref), k
+        else:
+            assert v.shape == ref.shape and (v == ref).all(), k
+    # the scenarios bite: VRT ids start right above the embedding rows, labels span tokens, the truncated sample is dropped
+    assert got["vocab_after_prepare"] == got["base_vocab"] + mk.EXTRA_ROWS and got["vocab_after_grid"] == got["vocab_after_prepare"] + 16
+    assert got["vrt_encode_ids"].tolist()[-5:-1:1].count(got["vocab_after_prepare"] + 15) == 1
+    assert json.loads(got["ovd.labels"]) == [["person", "traffic light", "bus"], []] and json.loads(got["truncated.labels"]) == [[], ["bus"]]
+    assert json.loads(got["think.labels"]) == [["cat"], ["cat"]] and json.loads(got["rec.n_feats"]) == [[3], [2]]
