@@ -29,6 +29,7 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(1, os.path.join(ROOT, "tests"))             # synthetic_workload.py: prompts / pixel rows / scripted schedules / tokenizer stand-in
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
@@ -83,7 +84,7 @@ def parse_args():
     ap.add_argument("--merge", type=int, default=0, help="consecutive batches of 8 whose decode steps share one session (in-flight batching; "
                     "1 = every batch decodes alone); default 8 for REC (28 new tokens), 16 for the decode-heavy OVD / RIC shapes (120 / 150 new tokens: "
                     "128-row steps cost 24 %% less per image; same-call OVD 66.1 → 69.3 images/s)")
-    ap.add_argument("--no-graph", action="store_true", help="sequential mode only: launch decode steps eagerly (profiling aid)")
+    ap.add_argument("--no-graph", action="store_true", help="launch decode steps kernel by kernel instead of replaying the captured hipGraph (counter passes)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
     ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
     ap.add_argument("--timeline", action="store_true", help="print a stream timeline of pipelined steps to stderr")
@@ -112,7 +113,7 @@ def build_model(args, device):
 
 def workload(args):
     """→ (n_post text tokens after the image, T_new, objects per image, VRTs per object, schedule)."""
-    from padt_amd.synthetic import multi_object_schedule, rec_schedule
+    from synthetic_workload import multi_object_schedule, rec_schedule
     if args.task == "ovd":
         T = args.tnew if args.tnew != 28 else 120
         return 346, T, 7, 5, multi_object_schedule(T, n_obj=7, n_vrt=5)
@@ -129,7 +130,7 @@ N_ROT = 4          # distinct input batches every timed loop cycles through
 
 
 def make_inputs(cfg, args, grid_hw, device, seed, dtype=torch.float16):
-    from padt_amd.synthetic import FakeProcessor, synthetic_batch
+    from synthetic_workload import FakeProcessor, synthetic_batch
     import padt_amd
     n_post, T, n_obj, n_vrt, sched = workload(args)
     args.tnew = T
@@ -581,6 +582,11 @@ def main():
     if args.gpus != world:
         print(f"bench.py --gpus {args.gpus} under a launcher with WORLD_SIZE={world}: the two must agree", file=sys.stderr)
         sys.exit(2)
+    # The contract is ONE JSON line on stdout.  Native libraries write banners to file descriptor 1 behind Python's back (RCCL's version
+    # block, gloo's "connected to N peer ranks"): keep a private handle on the real stdout for the line and point fd 1 at stderr.
+    sys.stdout.flush()
+    line_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     # PADT_DIST_FORCE=1: run the data-parallel code path (process group, device-side pack, asynchronous all-gather per decode group) at
     # world size 1 too — on a one-GPU box that is the one way to put the exchange on RCCL itself (RCCL refuses two ranks per device)
     dist_on = world > 1 or os.environ.get("PADT_DIST_FORCE") == "1"
@@ -611,7 +617,8 @@ def main():
         torch.cuda.synchronize()
 
     from padt_amd import pipeline
-    runner = (pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge, shared_prefill_stream=not args.lane_streams)
+    runner = (pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge, shared_prefill_stream=not args.lane_streams,
+                                       use_graph=not args.no_graph)
               if (args.depth > 1 or args.merge > 1) else None)
     # data-parallel exchange (world > 1): device-side pack of every batch's record, ONE asynchronous all-gather per decode group
     exchange = None
@@ -783,7 +790,7 @@ def main():
             m3, model = model, None
             leg("extra_workloads", lambda: extra_workloads(args, device, m3, cfg, grid_hw))
             del m3
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=line_out, flush=True)
     if dist_on:
         import torch.distributed as dist
         dist.barrier()

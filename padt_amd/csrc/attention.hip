@@ -360,8 +360,13 @@ struct DecodeArgs {
     int out_packed = 0;     // out in the 16-row fragment-packed activation layout (row length Hq*D)
 };
 
+// decode_attn_kernel and decode_attn_rope_kernel run the SAME softmax arithmetic and must give the same bits (the fused kernel is what a
+// decode step launches, the unfused pair is its test reference and the prompt path's append): `#pragma clang fp contract(off)` keeps hipcc
+// from fusing `s * scale` into the later `x - m` as an fma in one of them and not in the other — a 1-ulp fp32 difference in the exponent
+// that flips an fp16 probability every few thousand keys (found by the fp16 instantiation's test; bf16's 8x coarser grid hid it).
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
+#pragma clang fp contract(off)
     __shared__ __attribute__((aligned(16))) x16_t Pw[16 * 72];
     const int lane = threadIdx.x, frow = lane & 15, fq = lane >> 4;
     const int split = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
 
 template <int D>
 __global__ void decode_combine_kernel(DecodeArgs p) {
+#pragma clang fp contract(off)
     const int b = blockIdx.y, hq = blockIdx.x, d = threadIdx.x;
     const int group = p.Hq / p.Hkv;
     const int g = hq / group, hrow = hq % group;
@@ -516,6 +522,7 @@ struct DecodeRopeArgs {
 
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) {
+#pragma clang fp contract(off)
     constexpr int QROW = D + 8, KQ = D / 32, NB = D / 16, HALF = D / 2;
     __shared__ __attribute__((aligned(16))) x16_t Qs[16 * QROW];
     __shared__ __attribute__((aligned(16))) x16_t Knew[D];

@@ -46,8 +46,9 @@ class PipelinedRunner:
     submit()/flush() return the (decoded, completions, labels, vrts) tuples of the batches that completed, in order.
     """
 
-    def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True):
+    def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True, use_graph: bool = True):
         self.model, self.processor, self.depth, self.merge = model, processor, depth, max(1, merge)
+        self.use_graph = use_graph     # False: decode steps launched kernel by kernel (counter passes under rocprofv3; same results)
         # shared_prefill_stream=False gives every lane its own prefill stream: GEMMs of two batches may then co-run and
         # fill each other's partial waves (152-tile o_proj on 256 CUs), at the price of L2 / HBM contention
         n_pre = 1 if shared_prefill_stream else depth
@@ -104,7 +105,7 @@ class PipelinedRunner:
             self._mark(bid, "prefill_begin", pre)
             with torch.cuda.stream(pre):
                 ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
-                                                 sched, sync_every or max_new_tokens, True, g["lane"],
+                                                 sched, sync_every or max_new_tokens, self.use_graph, g["lane"],
                                                  self.decode_streams[g["lane"]], group=g["ctx"], n_slots=self.merge,
                                                  repetition_penalty=repetition_penalty, eos_token_id=eos_token_id, **sampling)
             if ctx is not None:
@@ -178,6 +179,12 @@ def pack_results(decoded: dict, cap: int, mask_hw: int, device, out: Optional[to
         if n and (sidx is None or sidx.numel() != n):                 # a dict that did not come from vl_decode
             sidx = torch.tensor(decoded["sample_idx"], dtype=torch.int32).to(device, non_blocking=True)
         hw = decoded["pred_mask_valid_hw"] if has_mask else (None, None)
+        # the decoded tensors were allocated on the runner lane's stream; the pack kernel reads them on the caller's: tell the caching
+        # allocator, or their blocks could be handed to the lane's next batch while the pack is still queued here
+        cur = torch.cuda.current_stream()
+        for t in (sidx, hw[0], hw[1], decoded["pred_boxes"], decoded["pred_score"], decoded["pred_mask"] if has_mask else None):
+            if isinstance(t, torch.Tensor) and t.is_cuda:
+                t.record_stream(cur)
         return ops.pack_results(buf, n, cap, mask_hw, sidx, hw[0], hw[1], decoded["pred_boxes"] if n else None,
                                 decoded["pred_score"] if n else None, decoded["pred_mask"] if has_mask else None)
     buf = out if out is not None else torch.empty(words, dtype=torch.int32, device=device)

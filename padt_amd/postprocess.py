@@ -25,6 +25,31 @@ def rle_counts(mask_u8: np.ndarray) -> List[int]:
 
 
 def rle_string(counts: Sequence[int]) -> str:
+    """COCO maskApi rleToString: every count (from the fourth on: its difference to the count two places earlier) as little-endian 5-bit
+    groups, bit 5 = "more follows", sign-extended, + 48.  Vectorised: a value x needs g = (bit_length(x >= 0 ? x : ~x) + 5) // 5 groups
+    (the smallest g with -2^(5g-1) <= x < 2^(5g-1)), so the output offsets are a prefix sum and group j of all values that have one is
+    one numpy pass.  (A noisy 640 x 640 mask has ~50 000 runs; the per-count Python loop — kept below as the statement the tests compare
+    against — cost 25 ms per mask and was the bottleneck of bench.py's to_rle leg.)"""
+    c = np.asarray(counts, dtype=np.int64)
+    if c.size == 0:
+        return ""
+    x = c.copy()
+    x[3:] -= c[1:-2]
+    ax = np.where(x >= 0, x, ~x)
+    bits = np.frexp(ax.astype(np.float64))[1].astype(np.int64)       # bit length (exact below 2^53)
+    g = (bits + 5) // 5
+    off = np.cumsum(g) - g
+    out = np.empty(int(g.sum()), dtype=np.uint8)
+    sel = np.arange(c.size)
+    for j in range(int(g.max())):
+        sel = sel[g[sel] > j]
+        ch = (x[sel] >> (5 * j)) & 0x1F
+        out[off[sel] + j] = (ch | ((g[sel] - 1 > j) << 5)) + 48
+    return out.tobytes().decode("ascii")
+
+
+def rle_string_loop(counts: Sequence[int]) -> str:
+    """rleToString, count by count."""
     out = []
     for i, c in enumerate(counts):
         x = int(c)

@@ -1,9 +1,9 @@
-"""Synthetic inputs for a model with random-init weights (no datasets / checkpoints offline): prompts of
+"""Test / bench support (NOT part of the product package).  Synthetic inputs for a model with random-init weights (no datasets / checkpoints offline): prompts of
 the reference's shape, N(0,1) pixel rows, a scripted completion schedule (random weights never emit EOS), and a minimal
 tokenizer stand-in so ``parseVRTintoCompletion`` can run on generated ids."""
 import torch
 
-from .config import PaDTConfig
+from padt_amd.config import PaDTConfig
 
 
 def synthetic_batch(cfg: PaDTConfig, grids, n_pre=15, n_post=33, seed=1234, ragged=False):

@@ -12,6 +12,24 @@ import torch.multiprocessing as mp
 from padt_amd import pipeline
 
 
+def _ship(o):
+    """Tensors → numpy before they go through a multiprocessing queue: a tensor travels as a shared-memory handle that the parent may
+    only open after the worker is gone (FileNotFoundError, seen as a flaky failure); arrays are pickled by value."""
+    if isinstance(o, torch.Tensor):
+        return ("__tensor__", o.detach().cpu().numpy().copy())
+    if isinstance(o, (list, tuple)):
+        return type(o)(_ship(x) for x in o)
+    return o
+
+
+def _unship(o):
+    if isinstance(o, tuple) and len(o) == 2 and isinstance(o[0], str) and o[0] == "__tensor__":
+        return torch.from_numpy(o[1])
+    if isinstance(o, (list, tuple)):
+        return type(o)(_unship(x) for x in o)
+    return o
+
+
 def _free_port():
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
@@ -37,8 +55,8 @@ def _worker(rank, world, port, q):
     gathered = pipeline.all_gather_results(packed)
     res = pipeline.unpack_results(gathered, batch_per_rank=4)
     assert gathered.shape == (world, packed.numel()) and gathered.dtype == torch.int32
-    q.put((rank, [r["boxes"].clone() for r in res], [r["sample_idx"].clone() for r in res],
-           [None if r["masks"] is None else r["masks"].clone() for r in res], [r["scores"].clone() for r in res], [r["valid_hw"].clone() for r in res]))
+    q.put(_ship((rank, [r["boxes"].clone() for r in res], [r["sample_idx"].clone() for r in res],
+                 [None if r["masks"] is None else r["masks"].clone() for r in res], [r["scores"].clone() for r in res], [r["valid_hw"].clone() for r in res])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -50,7 +68,7 @@ def test_result_all_gather_two_ranks():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [_unship(q.get(timeout=120)) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -82,7 +100,7 @@ def _worker_exchange(rank, world, port, q):
                                                          "pred_mask": torch.zeros(0, 8, 8), "sample_idx": [], "pred_mask_valid_hw": ()}
         done += [t.clone() for t in ex.add(dec)]
     done += [t.clone() for t in ex.flush()]
-    q.put((rank, ex.n_gathers, [d.clone() for d in done]))
+    q.put(_ship((rank, ex.n_gathers, [d.clone() for d in done])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -96,7 +114,7 @@ def test_result_exchange_groups_gather_asynchronously_and_in_order():
     procs = [ctx.Process(target=_worker_exchange, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [_unship(q.get(timeout=120)) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
@@ -148,7 +166,7 @@ def test_result_exchange_over_capacity_batch_is_split_not_raised():
     procs = [ctx.Process(target=_worker_overflow, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    got = [q.get(timeout=120) for _ in range(2)]
+    got = [_unship(q.get(timeout=120)) for _ in range(2)]
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0

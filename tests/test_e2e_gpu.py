@@ -420,8 +420,8 @@ def test_from_pretrained_directory_round_trip(setup, tmp_path):
     from padt_amd.modeling import PaDTForConditionalGeneration
     save_file({k: v.to(torch.bfloat16).contiguous() for k, v in w.items()}, str(tmp_path / "model.safetensors"))
     json.dump(cfg.to_dict(), open(tmp_path / "config.json", "w"))
-    m2 = PaDTForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16,
-                                                      attn_implementation="flash_attention_2", device_map={"": 0})
+    m2 = PaDTForConditionalGeneration.from_pretrained(str(tmp_path), torch_dtype=torch.bfloat16, attn_implementation="flash_attention_2",
+                                                      device_map={"": 0}, operands="fp16" if model.dtype == torch.float16 else "bf16")
     assert m2.config.vision_config.spatial_merge_size == 2 and m2.model.embed_tokens.weight.shape[0] == cfg.vocab_size
     grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=7, seed=3, ragged=True)
     T = 8
@@ -536,7 +536,7 @@ def test_ovd_shaped_completion_through_the_runner(setup):
     cfg, w, model, U, oc = setup
     import padt_amd
     from padt_amd import pipeline
-    from padt_amd.synthetic import multi_object_schedule
+    from synthetic_workload import multi_object_schedule
     O = U.O
     grids = [[1, 10, 12], [1, 8, 8]]
     T = 48
