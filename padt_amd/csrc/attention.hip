@@ -360,10 +360,12 @@ struct DecodeArgs {
     int out_packed = 0;     // out in the 16-row fragment-packed activation layout (row length Hq*D)
 };
 
-// decode_attn_kernel and decode_attn_rope_kernel run the SAME softmax arithmetic and must give the same bits (the fused kernel is what a
-// decode step launches, the unfused pair is its test reference and the prompt path's append): `#pragma clang fp contract(off)` keeps hipcc
-// from fusing `s * scale` into the later `x - m` as an fma in one of them and not in the other — a 1-ulp fp32 difference in the exponent
-// that flips an fp16 probability every few thousand keys (found by the fp16 instantiation's test; bf16's 8x coarser grid hid it).
+// decode_attn_kernel and decode_attn_rope_kernel run the SAME softmax arithmetic (the fused kernel is what a decode step launches, the
+// unfused pair llm_qkv_post + decode_attn is its test reference).  `#pragma clang fp contract(off)` pins `s * scale` and the later `x - m` as
+// two roundings in both (hipcc is otherwise free to contract one of them).  K / V appends are bit-identical between the two paths in both
+// operand types, the attention outputs are in bf16; in the fp16 instantiation at D = 128 ≈0.5 % of them still differ by ONE fp16 rounding
+// (same instruction mix in both kernels' ISA; origin not found; bounded by tests/test_kernels_f16_gpu.py).  Only the fused kernel runs in a
+// decode step, so no product invariant (merged == un-merged decode, graph == eager) depends on it.
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
 #pragma clang fp contract(off)
