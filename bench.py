@@ -87,6 +87,7 @@ def parse_args():
     ap.add_argument("--no-graph", action="store_true", help="launch decode steps kernel by kernel instead of replaying the captured hipGraph (counter passes)")
     ap.add_argument("--no-alt", action="store_true", help="skip the merge=1 comparison run")
     ap.add_argument("--lane-streams", action="store_true", help="one prefill stream per lane instead of a shared one")
+    ap.add_argument("--vit-stream", type=int, default=0, help="1: the ViT of batch b + 1 on its own stream, concurrent with the LLM prefill of batch b")
     ap.add_argument("--timeline", action="store_true", help="print a stream timeline of pipelined steps to stderr")
     ap.add_argument("--timeline-steps", type=int, default=4)
     ap.add_argument("--breakdown", action="store_true", help="also time the phases of one step (printed to stderr)")
@@ -619,7 +620,7 @@ def main():
 
     from padt_amd import pipeline
     runner = (pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge, shared_prefill_stream=not args.lane_streams,
-                                       use_graph=not args.no_graph)
+                                       use_graph=not args.no_graph, vit_stream=bool(args.vit_stream))
               if (args.depth > 1 or args.merge > 1) else None)
     # data-parallel exchange (world > 1): device-side pack of every batch's record, ONE asynchronous all-gather per decode group
     exchange = None

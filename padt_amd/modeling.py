@@ -190,7 +190,8 @@ class PaDTForConditionalGeneration:
     @torch.no_grad()
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=None,
                         schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
-                        repetition_penalty=None, eos_token_id=None, temperature=None, top_k=None, top_p=None, seed=None):
+                        repetition_penalty=None, eos_token_id=None, temperature=None, top_k=None, top_p=None, seed=None,
+                        vit_stream=None, inputs_ready=None):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -269,8 +270,26 @@ class PaDTForConditionalGeneration:
         rows = slice(row0, row0 + B)
 
         # ---- ViT → prototypes → session table
-        low, high, pe = self.visual(pixel_values.to(dev), grid)
-        proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+        if vit_stream is None:
+            low, high, pe = self.visual(pixel_values.to(dev), grid)
+            proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+        else:
+            # the ViT of this batch on its own stream: it needs the inputs (event `inputs_ready` of the caller's stream) and nothing of the
+            # current stream — so it runs while the PREVIOUS batch's prefill is still on the current stream — except for the first batch of a
+            # group, whose session may just have been (re)allocated or reset on the current stream
+            cur = torch.cuda.current_stream()
+            if inputs_ready is not None:
+                vit_stream.wait_event(inputs_ready)
+            if k == 0 or inputs_ready is None:
+                vit_stream.wait_stream(cur)
+            with torch.cuda.stream(vit_stream):
+                low, high, pe = self.visual(pixel_values.to(dev), grid)
+                proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+            cur.wait_stream(vit_stream)                           # the prefill below reads low / the prototype rows
+            for t_ in (low, high, pe[0], pe[1]):                   # allocated on vit_stream, read on the prefill / decode streams
+                t_.record_stream(cur)
+                if decode_stream is not None:
+                    t_.record_stream(decode_stream)
         # ---- per-generate device state of this batch's rows
         off = torch.tensor([proto_row0 + o for o in plan.vrt_off], dtype=torch.int32)
         sess.vrt_off[row0: row0 + B + 1].copy_(off.to(dev, non_blocking=True))

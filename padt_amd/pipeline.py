@@ -46,8 +46,12 @@ class PipelinedRunner:
     submit()/flush() return the (decoded, completions, labels, vrts) tuples of the batches that completed, in order.
     """
 
-    def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True, use_graph: bool = True):
+    def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True, use_graph: bool = True,
+                 vit_stream: bool = False):
         self.model, self.processor, self.depth, self.merge = model, processor, depth, max(1, merge)
+        # vit_stream: the ViT of batch b + 1 on its own stream, concurrent with the LLM prefill of batch b (the two phases leave different
+        # tails on the 256 CUs); per-sample results are unchanged (same kernels, same order per batch)
+        self.vit_stream = torch.cuda.Stream(device=model.device) if vit_stream else None
         self.use_graph = use_graph     # False: decode steps launched kernel by kernel (counter passes under rocprofv3; same results)
         # shared_prefill_stream=False gives every lane its own prefill stream: GEMMs of two batches may then co-run and
         # fill each other's partial waves (152-tile o_proj on 256 CUs), at the price of L2 / HBM contention
@@ -95,6 +99,7 @@ class PipelinedRunner:
             g = self.cur
             pre = g["pre"]
             pre.wait_stream(torch.cuda.current_stream())          # inputs were produced on the caller's stream
+            ev_in = torch.cuda.current_stream().record_event() if self.vit_stream is not None else None
             # ... and are consumed on the prefill / decode streams, possibly long after the caller dropped them: tell the
             # caching allocator (record_stream) so their blocks are not handed to the caller's next batch while a lagging
             # side stream still reads them; the group also holds references until its results were collected
@@ -102,12 +107,15 @@ class PipelinedRunner:
                 if isinstance(t, torch.Tensor) and t.is_cuda:
                     t.record_stream(pre)
                     t.record_stream(self.decode_streams[g["lane"]])
+                    if self.vit_stream is not None:
+                        t.record_stream(self.vit_stream)
             self._mark(bid, "prefill_begin", pre)
             with torch.cuda.stream(pre):
                 ctx = self.model.generate_launch(ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, False,
                                                  sched, sync_every or max_new_tokens, self.use_graph, g["lane"],
                                                  self.decode_streams[g["lane"]], group=g["ctx"], n_slots=self.merge,
-                                                 repetition_penalty=repetition_penalty, eos_token_id=eos_token_id, **sampling)
+                                                 repetition_penalty=repetition_penalty, eos_token_id=eos_token_id,
+                                                 vit_stream=self.vit_stream, inputs_ready=ev_in, **sampling)
             if ctx is not None:
                 break
             self._close_cur()                                     # batch does not fit this group's session: start a new one

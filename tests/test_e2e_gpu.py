@@ -202,6 +202,35 @@ def test_pipelined_runner_matches_sequential(setup, depth, merge):
         assert torch.equal(d0["pred_score"], d1["pred_score"])
 
 
+def test_pipelined_runner_with_a_vit_stream_matches_sequential(setup):
+    """PipelinedRunner(vit_stream=True): the ViT of batch b + 1 runs on its own stream, concurrent with the LLM prefill of batch b (only
+    the first ViT of a decode group is ordered after the stream's earlier work) — results bit-identical to one rec_batch call per batch."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    T = 9
+    sched = U.rec_schedule(T, vrt_at=range(3, 6))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = []
+    for s_ in range(7):
+        g = [[1, 8, 8] if (s_ + i) % 3 else [1, 10, 12] for i in range(4)]
+        grid, pix, ids, am = U.synthetic_batch(cfg, g, n_pre=5 + s_ % 2, n_post=7, seed=1300 + s_, ragged=True)
+        batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
+    ref = [pipeline.rec_batch(model, proc, b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched) for b in batches]
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=3, vit_stream=True)
+    got = []
+    for rep in range(2):                                            # second pass: sessions and graphs already exist
+        got = []
+        for b in batches:
+            got += runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+        got += runner.flush()
+        assert len(got) == len(batches)
+        for (d0, c0, l0, v0), (d1, c1, l1, v1) in zip(ref, got):
+            assert c0 == c1 and v0 == v1
+            assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"]) and torch.equal(d0["pred_score"], d1["pred_score"])
+
+
 def test_pipelined_runner_128_row_decode_groups(setup):
     """Decode groups of 16 batches of 8 (128-row decode steps: what bench.py runs for the decode-heavy OVD / RIC shapes) — 18 batches, so one
     full group and a partially filled one — bit-identical to one rec_batch call per batch."""
