@@ -663,10 +663,11 @@ def test_3b_ovd_geometry_merged_runner_against_oracle():
     PipelinedRunner(depth 2, merge 16), nine batches so that the group's decode steps run the 128-row launch shapes (72 rows):
       (a) all 8 samples of the first and of the last batch bit-identical to the un-merged path (tokens, 56 boxes, scores, mask logits);
       (b) the fp32 CPU oracle teacher-forced on the HIP tokens of 2 samples (≈950 cached keys by the last step): every one of the 2 x 120
-          tokens by the margin rule — noise bound 0.8 % of the largest |logit| = 2x what fp16 operands + folded weight images cost at full
-          depth (profiles/r04_operand_attribution.md, last row) —, the parser's 7 objects per sample, 14 boxes within the north star's 1e-3,
-          mask logits within 8e-3 of their range (measured 6.5e-3 behind ≈950 cached keys and 120 teacher-forced steps; the REC geometry's
-          attributed floor is 3.7e-3 — no floor run at this length: it would double the test's 3 minutes of host CPU)."""
+          tokens by the margin rule — noise bound 0.8 % of the largest |logit| = 1.5x what fp16 operands + folded weight images cost at THIS
+          geometry (0.52 %: profiles/r04_ovd_length_floor.md, the oracle's operand floor on the first of these images, tests/studies/
+          ovd_length_floor.py) —, the parser's 7 objects per sample, 14 boxes within the north star's 1e-3 (floor 2.7e-4), mask logits within
+          8e-3 of their range = 2x that floor (4.0e-3; measured 6.5e-3 over the 14 objects; the floor is not re-run inside the test: it
+          would double its 3 minutes of host CPU)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import time
