@@ -40,4 +40,6 @@ done
 timeout 1200 python bench.py > $OUT/bench_line.json 2> $OUT/bench_line.err
 tail -c 600 $OUT/prof_trace_line.json; head -14 $OUT/kernel_stats.md; cat $OUT/pmc_mfma.md $OUT/pmc_lds.md | head -40
 # keep the merged-back payload small
-find $OUT/prof_* -type f -size +20M -delete
+# keep the merged-back payload small (gpurun copies back at most 64 MiB, and refuses when the LOCAL gpurun_out/ already exceeds it)
+find $OUT/prof_* -type f -size +4M -delete
+du -sh $OUT
