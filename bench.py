@@ -431,7 +431,7 @@ def cpu_baseline_leg(cfg, args, inp, model):
             for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist())]
     parity = {"tokens_equal_oracle_argmax": "%d/%d" % (same, n_steps), "box_iou_vs_oracle": ious,
               "box_abs_diff_max": round(max((abs(a - b) for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist()) for a, b in zip(hb, ob)), default=0.0), 5),
-              "note": "sample 0 of the batch, oracle teacher-forced on the HIP tokens (bf16 HIP path vs fp32 oracle, random-init weights)"}
+              "note": "sample 0 of the batch, oracle teacher-forced on the HIP tokens (%s-operand HIP path vs fp32 oracle, random-init weights)" % args.operands}
     return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": cores, "kind": "port", "parity": parity,
             "sample": "1 image of the workload (L=%d, T_new=%d, %d object(s) x %d VRT), fp32 CPU oracle run end to end: generate %.2f s "
                       "(ViT + prefill + %d decode steps) + vl_decode %.2f s = %.2f s/image on %d threads of %d host cores"
