@@ -114,6 +114,16 @@ def demo_max_side_size(w: int, h: int, max_side: int = 644):
     return int(w * scale), int(h * scale)
 
 
+def fetch_image_size(w: int, h: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 16384 * 28 * 28):
+    """eval/test_demo.py:61 `process_vision_info(message)` → qwen_vl_utils.vision_process.fetch_image: the decoded RGB image is resized
+    (PIL's default filter for RGB: BICUBIC) to smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28) BEFORE
+    the demo's LANCZOS pass.  qwen_vl_utils is a third-party dependency the reference lists WITHOUT a version (setup.py:28) and that is not in the
+    build container: this restates the package's published rule (same rounding as the HF processor's smart_resize, which IS pinned here against
+    the installed transformers); parity for this one step is unpinned.  → (new_w, new_h)."""
+    nh, nw = smart_resize(h, w, factor, min_pixels, max_pixels)
+    return nw, nh
+
+
 def eval_min_side_size(w: int, h: int, min_side: int = 28):
     """eval/evaluation_scripts/utils.py:205-218: images with a side below 28 px are enlarged (LANCZOS) so the short side is 28."""
     if w >= min_side and h >= min_side:
@@ -128,10 +138,10 @@ class ImageFrontEnd:
                  max_pixels: int = 14 * 14 * 4 * 1280, dtype=torch.bfloat16, resize: str = "gpu", pre_resize=None):
         """resize: "gpu" (default: Pillow's resampler on the device, bit-exact) or "pil" (host PIL, the reference's own call).
         pre_resize: None, "demo644" (eval/test_demo.py:67-73) or "min28" (eval/evaluation_scripts/utils.py:205-218) — the callers'
-        LANCZOS pass in front of the processor, applied to the image as handed to this class.  NOT covered: in the demo the file first
-        goes through qwen_vl_utils.process_vision_info (test_demo.py:61-62; that package is not in the build container, so its
-        fetch_image step — which may itself smart-resize with BICUBIC — is unpinned); a caller who wants the demo's exact pixels for
-        images whose sides are not multiples of 28 applies that step before handing the image over."""
+        LANCZOS pass in front of the processor, applied to the image as handed to this class — or "demo" = the demo's WHOLE front end
+        from the decoded file on: qwen_vl_utils' fetch_image resize (test_demo.py:61; BICUBIC to a multiple of 28, `fetch_image_size`: the
+        package is absent and un-versioned in the reference, its published rule is restated, unpinned) → the LANCZOS max-side-644 pass →
+        the processor's own smart_resize.  Every pass runs through the same byte-exact Pillow resampler."""
         self.device, self.patch, self.merge, self.temporal = device, patch, merge, temporal
         self.min_pixels, self.max_pixels, self.dtype = min_pixels, max_pixels, dtype
         self.resize, self.pre_resize = resize, pre_resize
@@ -142,7 +152,12 @@ class ImageFrontEnd:
     def _plan_sizes(self, w, h):
         """→ list of (out_w, out_h, filter) passes applied in order."""
         steps = []
-        if self.pre_resize == "demo644":
+        if self.pre_resize == "demo":
+            nw, nh = fetch_image_size(w, h)
+            if (nw, nh) != (w, h):
+                steps.append((nw, nh, "bicubic"))
+                w, h = nw, nh
+        if self.pre_resize in ("demo644", "demo"):
             nw, nh = demo_max_side_size(w, h)
             steps.append((nw, nh, "lanczos"))
             w, h = nw, nh

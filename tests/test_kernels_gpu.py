@@ -863,7 +863,7 @@ def test_gpu_resize_is_byte_exact_with_pillow_and_front_end_matches_pil_path(ops
               Image.fromarray(rng.integers(0, 256, (96, 20, 3), dtype=np.uint8)).convert("P"),
               Image.fromarray(rng.integers(0, 256, (640, 480, 4), dtype=np.uint8), mode="RGBA"),
               rng.integers(0, 256, (1100, 1700, 3), dtype=np.uint8)]
-    for pre in (None, "demo644", "min28"):
+    for pre in (None, "demo644", "min28", "demo"):
         gpu = P.ImageFrontEnd("cuda", dtype=torch.float32, resize="gpu", pre_resize=pre)
         pil = P.ImageFrontEnd("cuda", dtype=torch.float32, resize="pil", pre_resize=pre)
         pg, gg = gpu(images)

@@ -3,6 +3,7 @@ image processor (tests/golden/make_golden_pre.py)."""
 import os
 
 import numpy as np
+import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -98,3 +99,27 @@ def test_oracle_front_end_with_resize_matches_hf_processor_bit_exact():
         rows.append(r)
         grids.append([1, gh, gw])
     assert grids == z["grid_raw"].tolist() and np.array_equal(np.concatenate(rows), z["pix_raw"])
+
+
+def test_demo_front_end_plan_is_the_callers_pil_sequence():
+    """pre_resize="demo" = eval/test_demo.py from the decoded file on: qwen_vl_utils.fetch_image's resize (BICUBIC to smart_resize(h, w, 28,
+    4 * 28^2, 16384 * 28^2): restated, the package is absent) → LANCZOS to max side 644 (test_demo.py:67-73) → the processor's own
+    smart_resize (BICUBIC).  The size plan, and the host-PIL path of the front end against the same three PIL calls written out."""
+    from PIL import Image
+    from padt_amd import preprocess as P
+    assert P.fetch_image_size(640, 427) == (644, 420) and P.fetch_image_size(333, 500) == (336, 504) and P.fetch_image_size(20, 96) == (28, 140)
+    assert P.fetch_image_size(644, 644) == (644, 644) and P.fetch_image_size(5000, 4000) == (4004, 3192)      # 16384 * 28^2 pixels cap
+    fe = P.ImageFrontEnd("cpu", dtype=torch.float32, resize="pil", pre_resize="demo")
+    assert fe._plan_sizes(640, 427) == [(644, 420, "bicubic"), (644, 420, "lanczos")]          # already a multiple of 28 afterwards: no third pass
+    assert fe._plan_sizes(1700, 1100) == [(1708, 1092, "bicubic"), (644, 411, "lanczos"), (644, 420, "bicubic")]
+    rng = np.random.default_rng(3)
+    for (h, w) in [(427, 640), (1100, 1700), (96, 20)]:
+        img = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        pil = Image.fromarray(img)
+        nw, nh = P.fetch_image_size(w, h)
+        pil = pil.resize((nw, nh))                                                             # PIL's default for RGB: BICUBIC (fetch_image)
+        mw, mh = P.demo_max_side_size(nw, nh)
+        pil = pil.resize((mw, mh), Image.Resampling.LANCZOS)                                   # test_demo.py:73
+        rh, rw = P.smart_resize(mh, mw, 28, fe.min_pixels, fe.max_pixels)
+        pil = pil.resize((rw, rh), resample=Image.BICUBIC)                                     # the HF processor
+        assert np.array_equal(fe.resize_host(img), np.asarray(pil)), (h, w)
