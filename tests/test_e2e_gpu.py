@@ -146,6 +146,52 @@ def test_generate_tokens_hidden_and_vl_decode(setup):
     assert db2 < 1e-3 and mx2 < 1e-3 and rms2 < 1e-3                  # split-precision decoder: the north star's 1e-3 on identical inputs
 
 
+def test_massive_activation_channel_beyond_fp16_range():
+    """Range safety of fp16 operands end to end.  Real checkpoints carry "massive activations": a few residual-stream channels at 1e3-1e4 (and
+    more), the rest O(1), produced by ordinary-sized weights.  Here one row of layer 0's o_proj is set to 8192 (a weight fp16 holds), which
+    drives channel 7 of the residual stream beyond fp16's 65504 from layer 0 on (checked on the oracle's layer outputs) — and the run must stay
+    finite and on the oracle: the fp32 stream holds the value, its 16-bit mirror holds fp16(2^-4 x), the folded RMSNorm divides the factor out
+    again, q / k / v come out O(1).  (A plain fp16 copy of the stream would be +inf in that channel and NaN one kernel later.)"""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    import parity_util as U
+    O = U.O
+    cfg = padt_amd.small_test_config()
+    w = U.bf16_weights(cfg, seed=21, std=0.05)
+    w["model.layers.0.self_attn.o_proj.weight"] = w["model.layers.0.self_attn.o_proj.weight"].clone()
+    w["model.layers.0.self_attn.o_proj.weight"][7, :] = 8192.0
+    oc = U.oracle_config(cfg)
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=8, ragged=True, seed=41)
+    _, (h_last, hs), _ = O.prefill(w, oc, ids, am, pix, grid, all_hidden=True)
+    peak = max(float(h[..., 7].abs().max()) for h in hs[1:-1])
+    assert peak > 65504.0, f"the test has no power: stream channel 7 peaks at {peak:.3e}"
+    model = PaDTForConditionalGeneration(cfg, w, device="cuda", operands="fp16")
+    T = 8
+    sched = U.rec_schedule(T, vrt_at=range(2, 5))
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    toks = out.sequences.cpu()[:, L:]
+    hid = out.hidden_states.last_layer_rows().cpu().float()
+    assert torch.isfinite(hid).all(), "fp16 operands overflowed"
+    ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+    worst = 0.0
+    for t in range(T):
+        mx, rms = rel_err(hid[t], ores["hidden"][t][:, -1].float())
+        worst = max(worst, rms)
+        lg = ores["logits"][t]
+        top2 = lg.topk(2, dim=-1).values
+        chosen = lg.gather(1, toks[:, t:t + 1]).squeeze(1)
+        floor = 1e-2 * lg[torch.isfinite(lg)].abs().max().item()
+        for b in range(2):
+            second = top2[b, 1] if torch.isfinite(top2[b, 1]) else top2[b, 0] - 1
+            if (top2[b, 0] - second).item() > floor:
+                assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
+    print(f"\n[stream channel at {peak:.3e} (> fp16 max), fp16 operands] hidden rel rms worst {worst:.3e}")
+    assert worst < 1e-2
+
+
 def test_graph_replay_equals_eager_and_is_repeatable(setup):
     cfg, w, model, U, oc = setup
     grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 8, 8]], n_pre=5, n_post=7)
