@@ -189,7 +189,7 @@ def test_massive_activation_channel_beyond_fp16_range():
             if (top2[b, 0] - second).item() > floor:
                 assert chosen[b] == top2[b, 0], f"step {t} sample {b}: not the oracle argmax"
     print(f"\n[stream channel at {peak:.3e} (> fp16 max), fp16 operands] hidden rel rms worst {worst:.3e}")
-    assert worst < 1e-2
+    assert worst < 1e-3                                               # measured 2.2e-5 (the massive channel dominates the norm)
 
 
 def test_graph_replay_equals_eager_and_is_repeatable(setup):

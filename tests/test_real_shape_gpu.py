@@ -312,7 +312,7 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     toks = seq[:, 577:]
     assert toks.shape[1] == T and int(toks[0, -1]) == cfg.eos_token_id
     V = cfg.vocab_size
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))         # 32: the fastest count for the oracle on the 256-core GPU box (bench.py calibrates the same)
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
@@ -447,7 +447,7 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     L = ids.shape[1]
     toks = out.sequences[:, L:].cpu()
     decm = res[0][0]
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))         # 32: the fastest count for the oracle on the 256-core GPU box (bench.py calibrates the same)
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
@@ -546,6 +546,7 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     seq = out.sequences.cpu()
     toks = seq[:, L:]
     assert toks.shape == (2, T) and (toks[:, -1] == cfg.eos_token_id).all()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
     if act8:
         assert all(f"llm.0.{nm}.w8" in model.W for nm in ("qkv", "o", "gu", "down"))     # every 7B projection takes padt_gemm_fp8
     with torch.no_grad(), U.fp8_prefill_hooks(model):              # (no-op without e4m3 activations) prompt pass with e4m3 activation rows
@@ -716,7 +717,7 @@ def test_3b_ovd_geometry_merged_runner_against_oracle():
     L = ids.shape[1]
     toks = out.sequences[:, L:].cpu()
     # sample b's global VRT ids are offset by b x 529 in the batch of 8; alone (rows 0..NS-1 of the batch) the offsets are the same
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))         # 32: the fastest count for the oracle on the 256-core GPU box (bench.py calibrates the same)
     t0 = time.perf_counter()
     with torch.no_grad():
         ores = O.generate(w, oc, gids[:NS], am[:NS], pix[: NS * P1], grid[:NS], T, schedule=sched, collect_logits=True, force_tokens=toks[:NS])
@@ -779,7 +780,7 @@ def test_7b_full_depth_single_image_against_oracle(llm_weights):
     seq = out.sequences.cpu()
     toks = seq[:, L:]
     assert toks.shape == (1, T) and int(toks[0, -1]) == cfg.eos_token_id
-    torch.set_num_threads(min(64, os.cpu_count() or 8))
+    torch.set_num_threads(min(32, os.cpu_count() or 8))         # 32: the fastest count for the oracle on the 256-core GPU box (bench.py calibrates the same)
     t0 = time.perf_counter()
     with torch.no_grad():
         with U.fp8_prefill_hooks(model):
