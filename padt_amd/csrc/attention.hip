@@ -720,8 +720,7 @@ static void launch_attn_k(const AttnArgs& a, dim3 grid, hipStream_t s) {
 
 template <int D, bool CAUSAL, int QR>
 static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
-    static const int gqa = getenv("PADT_ATTN_GQA") ? atoi(getenv("PADT_ATTN_GQA")) : 1;      // 0 off, 1 auto, (A/B knob)
-    if (gqa && a.group > 1 && a.group <= 16 * QR && a.rcos == nullptr) {                      // q heads of a kv group share the block's K / V tiles
+    if (a.group > 1 && a.group <= 16 * QR && a.rcos == nullptr) {                             // q heads of a kv group share the block's K / V tiles
         const int tpb = 64 * QR / a.group;
         launch_attn_k<D, CAUSAL, QR, false, true>(a, dim3((max_seqlen_q + tpb - 1) / tpb, H / a.group, nseg), s);
         return;
@@ -742,8 +741,7 @@ static void launch_attn_qr(const AttnArgs& a, int max_seqlen_q, int H, int nseg,
 // 69.3 → 55.9 us)
 template <int D, bool CAUSAL>
 static void launch_attn(const AttnArgs& a, int max_seqlen_q, int H, int nseg, hipStream_t s) {
-    static const int force = getenv("PADT_ATTN_QR") ? atoi(getenv("PADT_ATTN_QR")) : 0;
-    if (force ? force == 2 : (max_seqlen_q >= 256)) launch_attn_qr<D, CAUSAL, 2>(a, max_seqlen_q, H, nseg, s);
+    if (max_seqlen_q >= 256) launch_attn_qr<D, CAUSAL, 2>(a, max_seqlen_q, H, nseg, s);
     else launch_attn_qr<D, CAUSAL, 1>(a, max_seqlen_q, H, nseg, s);
 }
 

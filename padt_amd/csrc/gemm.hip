@@ -574,11 +574,7 @@ static void launch_tile_bk(const GemmArgs& a, hipStream_t s) {
 }
 
 template <int EPI, bool F32>
-static void launch_tile(const GemmArgs& a, hipStream_t s) {
-    static const int bk = getenv("PADT_TILE_BK") ? atoi(getenv("PADT_TILE_BK")) : 64;        // tuning knob
-    if (bk == 32) launch_tile_bk<EPI, F32, 32>(a, s);
-    else launch_tile_bk<EPI, F32, 64>(a, s);
-}
+static void launch_tile(const GemmArgs& a, hipStream_t s) { launch_tile_bk<EPI, F32, 64>(a, s); }     // BK = 32 measured −15 % (round 1) and is gone
 
 template <int MT, int NT, int NW, int EPI, bool F32, bool NORM, bool PACKED, int WQ>
 static void launch_skinny_nt(const GemmArgs& a, float eps, hipStream_t s) {
@@ -620,13 +616,9 @@ static void launch_skinny(const GemmArgs& a, float eps, hipStream_t s) {
     constexpr int NT = (EPI == EPI_SWIGLU) ? 2 : 1;
     const int nb = (a.N + 16 * NT - 1) / (16 * NT);
     const int ksteps = (a.K + 31) / 32 / (a.ws ? a.split : 1);   // per block; each wave keeps U = 8 K-steps in flight
-    static const int force_nw = getenv("PADT_SKINNY_NW") ? atoi(getenv("PADT_SKINNY_NW")) : 0;   // tuning knob
     // (the wave count must not depend on MT either: the cross-wave sum runs in wave order.  A 16-wave variant for <= 16 rows was 5 %
     //  faster on the 8-row down-projection and is gone for that reason.)
-    if constexpr (MT == 1 && NT == 1) {
-        if (force_nw == 16) { launch_skinny_nw<MT, 16, EPI, F32, NORM, PACKED, WQ>(a, eps, s); return; }
-    }
-    if (force_nw == 8 || (!force_nw && nb <= 512 && ksteps >= 64)) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
+    if (nb <= 512 && ksteps >= 64) launch_skinny_nw<MT, 8, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
     else launch_skinny_nw<MT, 4, EPI, F32, NORM, PACKED, WQ>(a, eps, s);
 }
 

@@ -262,12 +262,8 @@ extern "C" int PADT_TWIN(padt_vrt_head)(void* stream, const void* hidden, long l
     if (seen && seen_words * 32 < vocab + n_proto) { padt_set_error("padt_vrt_head: seen bitmap narrower than the table"); return -1; }
     const int nblk = (int)padt_vrt_head_nblk(vocab, n_proto);
     hipStream_t s = (hipStream_t)stream;
-    static const int nt_knob = getenv("PADT_HEAD_NT") ? atoi(getenv("PADT_HEAD_NT")) : 0;      // A/B knob: 1 = one table block per thread block
-    if (embed_table_packed) {
-        if (nt_knob == 1) {
-            if (batch <= 16) launch_head<1, 1, true>(a, nblk, s); else if (batch <= 32) launch_head<2, 1, true>(a, nblk, s);
-            else if (batch <= 64) launch_head<4, 1, true>(a, nblk, s); else launch_head<8, 1, true>(a, nblk, s);
-        } else if (batch <= 16) launch_head<1, 4, true>(a, nblk, s);
+    if (embed_table_packed) {                                   // NT = 4 table blocks per thread block (2 at 128 rows): profiles/r03_head_nt_ab.log
+        if (batch <= 16) launch_head<1, 4, true>(a, nblk, s);
         else if (batch <= 32) launch_head<2, 4, true>(a, nblk, s);
         else if (batch <= 64) launch_head<4, 4, true>(a, nblk, s);
         else launch_head<8, 2, true>(a, nblk, s);

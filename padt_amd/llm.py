@@ -13,7 +13,6 @@ libpadt_hip.so.  Differences from the reference's control flow that do not chang
 from dataclasses import dataclass
 from typing import List, Optional
 
-import os
 
 import torch
 
@@ -147,8 +146,7 @@ class DecodeSession:
         self.part_idx = z(self.nblk * B, dt=I32)
         self.attn_ws = ops.new_decode_workspace(B, Hkv, hd, s_max, device)
         # down_proj has only D/16 column blocks (128 for D = 2048): split K over 2 blocks each to occupy every CU
-        self.down_split = int(os.environ.get("PADT_DOWN_SPLIT", 2))
-        self.o_split = int(os.environ.get("PADT_O_SPLIT", 1))
+        self.down_split, self.o_split = 2, 1                # (o with split 2: 7.6 → 10.9 us at 64 rows, profiles/r03_decode_experiments.md §7)
         self.splitk_ws = ops.new_splitk_workspace(cfg.hidden_size, max(self.down_split, self.o_split, 1), device)
         half = hd // 2
         self.inv_freq = (1.0 / (cfg.rope_theta ** (torch.arange(0, hd, 2, dtype=torch.float) / hd))).to(device)

@@ -5,7 +5,6 @@ processor outputs → assign_to_global_vrt_id → generate → assign_to_local_v
 Images are independent, so multi-GPU = one full replica per GPU, rank-strided batches (utils.py:181-182) and ONE
 all-gather of packed results per batch over RCCL/xGMI; there is no collective on the forward path.
 """
-import os
 from typing import List, Optional, Sequence
 
 import torch
@@ -58,8 +57,7 @@ class PipelinedRunner:
         n_pre = 1 if shared_prefill_stream else depth
         self.prefill_streams = [torch.cuda.Stream(device=model.device) for _ in range(n_pre)]
         # one decode stream per lane: a group's host-synchronising collect must not queue behind the next group's decode
-        prio = int(os.environ.get("PADT_DECODE_PRIO", -1))              # tuning knob: -1 = high priority (default), 0 = normal
-        self.decode_streams = [torch.cuda.Stream(device=model.device, priority=prio) for _ in range(depth)]
+        self.decode_streams = [torch.cuda.Stream(device=model.device, priority=-1) for _ in range(depth)]      # high priority
         self.pending = []          # launched groups, oldest first
         self.cur = None            # group still accepting batches
         self.n_groups = 0

@@ -273,7 +273,7 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
         # q and k rows pair-interleaved per head ((d, d + hd/2) adjacent) so the qkv GEMM's epilogue can apply the rotary
         # embedding lane-locally (ops.gemm_rope); q·k scores are invariant under the common permutation, v is untouched
         hd_v = v.hidden_size // v.num_heads
-        W.vit_rope_fused = hd_v % 4 == 0 and os.environ.get("PADT_VIT_ROPE_FUSED", "1") != "0"
+        W.vit_rope_fused = hd_v % 4 == 0                               # else: plain qkv GEMM + rope_half pass
         il = (lambda t: interleave_rope_rows(t, 2 * v.num_heads, hd_v)) if W.vit_rope_fused else (lambda t: t)
         put(d + "qkv.w", il(get(s + "attn.qkv.weight").to(dev).float() * n1))
         put(d + "qkv.b", il(get(s + "attn.qkv.bias").to(dev)))
@@ -327,7 +327,7 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
                 W[d + nm + ".wp"] = pack_weight(W[d + nm + ".w"])
     # fragment-packed copy of the head table for the decode-step logit head (+0.62 GB at 3B; the row-major table stays: it is
     # the embedding table too, and the prefill-side gathers read rows)
-    if cfg.vocab_size % 16 == 0 and cfg.hidden_size % 32 == 0 and os.environ.get("PADT_HEAD_PACKED", "1") != "0":
+    if cfg.vocab_size % 16 == 0 and cfg.hidden_size % 32 == 0:
         W["llm.head.wp"] = pack_weight(W["llm.head"])
     put("llm.norm", get("model.norm.weight"))
     W["llm.ones"] = torch.ones(cfg.hidden_size, device=dev, dtype=op16)
