@@ -84,3 +84,26 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
     monkeypatch.setattr(_lib, "LIB_PATH", str(tmp_path / "nope.so"))
     with pytest.raises(_lib.PaDTHipError, match="no CPU/PyTorch fallback"):
         _lib.load()
+
+
+def test_integration_stub_binds_the_declared_signature():
+    """INTEGRATION.md shows the ctypes stub a PaDT maintainer adds for flash_attn_varlen_func: its argtypes list and its call must have as
+    many arguments as include/padt_hip.h declares for padt_attn_varlen (round 3 shipped a stub three arguments short)."""
+    import re
+    doc = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    n_decl = len(_lib.parse_header()["padt_attn_varlen"][1])
+    m = re.search(r"_lib\.padt_attn_varlen\.argtypes = \[([^\]]*)\]", doc)
+    assert m and len([a for a in m.group(1).split(",") if a.strip()]) == n_decl
+    call = doc[doc.index("st = _lib.padt_attn_varlen("):]
+    call = call[: call.index("\n    if st != 0")]
+    depth, n_args = 0, 1
+    for ch in call[call.index("(") + 1:]:
+        if ch in "([":
+            depth += 1
+        elif ch in ")]":
+            if depth == 0:
+                break
+            depth -= 1
+        elif ch == "," and depth == 0:
+            n_args += 1
+    assert n_args == n_decl, (n_args, n_decl)
