@@ -362,10 +362,11 @@ struct DecodeArgs {
 
 // decode_attn_kernel and decode_attn_rope_kernel run the SAME softmax arithmetic (the fused kernel is what a decode step launches, the
 // unfused pair llm_qkv_post + decode_attn is its test reference).  `#pragma clang fp contract(off)` pins `s * scale` and the later `x - m` as
-// two roundings in both (hipcc is otherwise free to contract one of them).  K / V appends are bit-identical between the two paths in both
-// operand types, the attention outputs are in bf16; in the fp16 instantiation at D = 128 ≈0.5 % of them still differ by ONE fp16 rounding
-// (same instruction mix in both kernels' ISA; origin not found; bounded by tests/test_kernels_f16_gpu.py).  Only the fused kernel runs in a
-// decode step, so no product invariant (merged == un-merged decode, graph == eager) depends on it.
+// two roundings in both (hipcc is otherwise free to contract one of them).  K / V appends and the attention outputs are bit-identical between
+// the two paths in both operand types.  (Until the end of round 4 the fp16 instantiation differed in a fraction of a per cent of the outputs
+// at D = 128: the fused kernel's scalar rotation was compiled to v_fma_mixlo_f16 — one rounding — where llm_qkv_post's vector path rounds
+// twice; see rounded32() in common.h.)  Only the fused kernel runs in a decode step, so no product invariant (merged == un-merged decode,
+// graph == eager) ever depended on it.
 template <int D>
 __global__ __launch_bounds__(64) void decode_attn_kernel(DecodeArgs p) {
 #pragma clang fp contract(off)
@@ -601,7 +602,7 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
         const int hh = i / HALF, d = i % HALF;
         const float c = Cs[2 * d], sn = Cs[2 * d + 1];
         const float x1 = x2f(Raw[hh * D + d]), x2 = x2f(Raw[hh * D + d + HALF]);
-        const x16_t o1 = f2x(rope_lo(x1, x2, c, sn)), o2 = f2x(rope_hi(x1, x2, c, sn));
+        const x16_t o1 = f2x(rounded32(rope_lo(x1, x2, c, sn))), o2 = f2x(rounded32(rope_hi(x1, x2, c, sn)));
         if (hh < group) {
             Qs[hh * QROW + d] = o1; Qs[hh * QROW + d + HALF] = o2;
         } else {

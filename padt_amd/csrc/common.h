@@ -160,6 +160,17 @@ struct RopeEpi {
 // One rotation pair — the SAME two roundings at every rope site of the library.  Left to itself hipcc contracts x1*c - x2*s into
 // fma(x1, c, -(x2*s)) in one kernel and fma(-x2, s, x1*c) in another, so the prompt and the decode path of one token could differ in the
 // last fp32 bit (a rare bf16 flip, caught by a test that draws fresh positions on every run).
+// In the fp16 instantiation there is a third way to differ: where the rotated value goes straight into a 16-bit store hipcc folds the fma and the
+// fp32 → fp16 conversion into ONE v_fma_mixlo_f16 (a single rounding of the exact fma), elsewhere it emits v_fma_f32 + v_cvt_(pk_)f16_f32 (two
+// roundings).  The two agree except when the fp32 result lands on an fp16 tie — about one element in 2^13 (round 4: one q element of 6144
+// made the fused decode attention differ from its unfused test reference in 23 outputs; tools/diag/decode_attn_paths.py).  rounded32() makes
+// the fp32 value opaque to the combiner; the scalar rotation sites (the ones that got the mixed instruction) wrap their result in it, so every
+// site rounds twice — "rotate in fp32, then cast", the reference's rule (HF:557-599).
+#if PADT_OP16_F16
+PADT_DEV float rounded32(float r) { asm("" : "+v"(r)); return r; }
+#else
+PADT_DEV float rounded32(float r) { return r; }                  // no mixed-precision fma writes bf16: nothing to pin
+#endif
 PADT_DEV float rope_lo(float x1, float x2, float c, float s) { return __builtin_fmaf(-x2, s, x1 * c); }   // x1 cos - x2 sin
 PADT_DEV float rope_hi(float x1, float x2, float c, float s) { return __builtin_fmaf(x1, s, x2 * c); }    // x2 cos + x1 sin
 

@@ -136,8 +136,8 @@ __global__ __launch_bounds__(256) void rope_half_kernel(x16_t* __restrict__ x, l
         x16_t* p = x + t * ldx + (long)h * D;
         const float c = cs[t * ld_cs + d], s = sn[t * ld_cs + d];
         const float x1 = x2f(p[d]), x2 = x2f(p[d + half]);
-        p[d] = f2x(rope_lo(x1, x2, c, s));
-        p[d + half] = f2x(rope_hi(x1, x2, c, s));
+        p[d] = f2x(rounded32(rope_lo(x1, x2, c, s)));
+        p[d + half] = f2x(rounded32(rope_hi(x1, x2, c, s)));
     }
 }
 
@@ -549,7 +549,7 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
             const float c = cs[0][d], s = cs[1][d];
             const x16_t* x = row + (long)h * p.D;
             const float x1 = x2f(x[d]), x2 = x2f(x[d + half]);
-            const x16_t o1 = f2x(rope_lo(x1, x2, c, s)), o2 = f2x(rope_hi(x1, x2, c, s));
+            const x16_t o1 = f2x(rounded32(rope_lo(x1, x2, c, s))), o2 = f2x(rounded32(rope_hi(x1, x2, c, s)));
             if (h < p.Hq) {
                 x16_t* q = p.q_out + (long)t * p.ld_q + (long)h * p.D;
                 q[d] = o1; q[d + half] = o2;

@@ -255,7 +255,7 @@ def test_decode_attn_rope_f16_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     vt = v.transpose(2, 3).contiguous()
     slot_t = torch.tensor(slots, dtype=torch.int32, device="cuda")
     inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).cuda()
-    for seed in range(1, 6):                                         # prompt path and decode path rotate a token bit-identically
+    for seed in range(1, 25):                                        # prompt path and decode path rotate a token bit-identically
         gpos = torch.randint(0, 4000, (3, B), dtype=torch.int32, generator=torch.Generator().manual_seed(seed)).cuda()
         qa, qb = torch.zeros(B, Hq * D, device="cuda", dtype=H), torch.zeros(B, Hq * D, device="cuda", dtype=H)
         ka, va, kb, vb = kc.clone(), vt.clone(), kc.clone(), vt.clone()
@@ -266,12 +266,11 @@ def test_decode_attn_rope_f16_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
         assert torch.equal(ka, kb) and torch.equal(va, vb), f"rotated K / V differ between the decode and the prompt path (seed {seed})"
         ob = torch.zeros_like(qa)
         ops.decode_attn(qb, kb, vb, slot_t + 1, ob, ops.new_decode_workspace(B, Hkv, D, S_max, "cuda"), Hq, Hkv, D, S_max, max(slots) + 1)
-        # the fused kernel against the unfused pair: bit-identical in the bf16 instantiation (test_kernels_gpu.py); in fp16 at D = 128 a
-        # fraction of a per cent of the outputs differs by one fp16 rounding (attention.hip) — bounded here, the count is printed
-        n_diff = int((qa != ob).sum())
-        if n_diff:
-            print(f"\n[decode_attn_rope_f16 D={D}] {n_diff} of {qa.numel()} outputs differ between the fused and the unfused path (seed {seed})")
-        assert (qa.float() - ob.float()).abs().max().item() <= 2.0 ** -9 * ob.float().abs().max().item(), f"attention differs between the two paths (seed {seed})"
+        # the fused kernel against the unfused pair: bit-identical, as in the bf16 instantiation (test_kernels_gpu.py).  Until the end of round 4
+        # a fraction of a per cent of the fp16 outputs differed at D = 128: hipcc had folded the fused kernel's scalar rotation + conversion
+        # into one v_fma_mixlo_f16 (a single rounding) while llm_qkv_post's vector path rounds twice — one q element in ~2^13 sat on an fp16
+        # tie (tools/diag/decode_attn_paths.py; rounded32() in csrc/common.h)
+        assert torch.equal(qa, ob), f"attention differs between the two paths (seed {seed}): {int((qa != ob).sum())} of {qa.numel()} outputs"
     rep = Hq // Hkv
     ref = torch.zeros(B, Hq * D, device="cuda")
     for b in range(B):
