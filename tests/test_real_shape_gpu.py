@@ -667,7 +667,7 @@ def test_3b_ovd_geometry_merged_runner_against_oracle():
           tokens by the margin rule — noise bound 0.8 % of the largest |logit| = 1.5x what fp16 operands + folded weight images cost at THIS
           geometry (0.52 %: profiles/r04_ovd_length_floor.md, the oracle's operand floor on the first of these images, tests/studies/
           ovd_length_floor.py) —, the parser's 7 objects per sample, 14 boxes within the north star's 1e-3 (floor 2.7e-4), mask logits within
-          8e-3 of their range = 2x that floor (4.0e-3; measured 6.5e-3 over the 14 objects; the floor is not re-run inside the test: it
+          8e-3 of their range = 2x that floor (4.0e-3; measured 6.5-6.8e-3 over the 14 objects (the value moved by 5 % when round 4 changed the rounding of ONE q element in ~2^13); the floor is not re-run inside the test: it
           would double its 3 minutes of host CPU)."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
