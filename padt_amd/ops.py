@@ -120,6 +120,8 @@ class GemmProfile:
 
     def start(self):
         global GEMM_PROF
+        if torch.cuda.is_current_stream_capturing():                 # the slot pointer would be baked into the captured graph
+            raise RuntimeError("GemmProfile.start() during a stream capture")
         self.slots[:, 0] = -1                                        # 0xFFFF...: the atomicMin identity
         self.slots[:, 1] = 0
         self.meta = []
