@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- plumbing --------------------------------------------------------------------------------------------------- */
-int         padt_abi_version(void);                                  /* 2: round 4 (fp16 twins, padt_cast_f32_bf16 scale) */
+int         padt_abi_version(void);                                  /* 3: round 5 (padt_check_finite, padt_mask_rle); 2: round 4 (fp16 twins) */
 /* The fp16 instantiation stores mirror = fp16(PADT_F16_STREAM_SCALE * X32): a residual stream is un-normalised (checkpoints carry "massive
  * activations" of 1e3-1e4 in a few channels), fp16 ends at 65504, and every consumer of a mirror is scale-invariant — padt_row_rstd_f16 and the
  * fused RMSNorm statistics of padt_gemm_packed_f16 / padt_quant_rows_fp8_f16 return rstd / scale when called with eps * scale^2, which the
@@ -189,6 +189,12 @@ int padt_cast_bf16_f32(void* stream, const void* x, long ldx, void* y, long ldy,
 /* y(bf16) = w * x * rsqrt(mean(x^2)+eps) for fp32 rows x: the norms that read the fp32 residual stream (ViT merger ln_q HF:141-148,
  * LLM final norm HF:867). */
 int padt_rmsnorm_f32(void* stream, const void* x_f32, long ldx, const void* w, void* y, long ldy, long rows, long D, float eps);
+/* flags[row / rows_per_flag] |= 1 when a row of x holds +-inf or NaN; kind 0 fp32, 1 bf16, 2 fp16; rows of whole 16-byte vectors.  The
+ * fp16-operand safety net (round 5): an overflow of an un-normalised fp16 tensor upstream (SwiGLU hidden HF:85-96,545-553, q / k / v
+ * HF:630-633, merger hidden HF:141-151) arrives as inf / NaN in the rows the product path checks with this — ViT output rows
+ * (padt.py:99-104), prototypes (padt.py:187-191), the post-norm hidden rows of the prompt pass and of every decode step (padt.py:732-737) —
+ * and is reported (PaDTHipError) or answered by a re-run on the bf16 instantiation (operands="auto") instead of returned. */
+int padt_check_finite(void* stream, const void* x, long ldx, long rows, long cols, int kind, int* flags, long rows_per_flag);
 /* in-place fp32 sigmoid (bbox head, padt_decoder.py:164). */
 int padt_sigmoid_f32(void* stream, void* x, long n);
 /* inputs_embeds from the two-pointer table [E ‖ proto] + image-embed scatter.  padt.py:193-219, 226-229.
@@ -279,6 +285,17 @@ int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj
                                 const int* src_w, const int* dst_h, const int* dst_w, void* out_u8, long out_ld_obj,
                                 long out_ld_row, void* up_f32, long up_ld_obj, long up_ld_row, int n_obj, int max_dst_h,
                                 int max_dst_w);
+/* COCO RLE of binarised masks on the device: what the eval loop's `cocomask.encode(np.asfortranarray(mask))` + `rle['counts'].decode()`
+ * produce (eval/evaluation_scripts/utils.py:263-264; pycocotools is third-party and absent here: cocoapi common/maskApi.c rleEncode +
+ * rleToString restated — column-major runs, zero run first, 5-bit groups + 48).  mask_u8: n_obj binary images [max_h][ld_row] (the
+ * output of padt_mask_upsample_binarize), object o uses its leading dst_h[o] x dst_w[o] pixels.  Per object: counts[o][0 .. n_counts[o])
+ * (scratch AND result, capacity cap_counts >= h*w + 1 in the worst case; n_counts < 0 when exceeded) and the counts string str[o][0 .. str_len[o])
+ * (capacity cap_str; str_len = -1 when exceeded).  With packed_u8 != null the strings are also written back to back into packed_u8 behind
+ * offsets[0 .. n_obj] (offsets[n_obj] = total bytes, -1 on a capacity error), so that one small device-to-host copy carries a batch's RLEs
+ * instead of its masks.  max_h <= 7680. */
+int padt_mask_rle(void* stream, const void* mask_u8, long ld_obj, long ld_row, const int* dst_h, const int* dst_w, int n_obj, int max_h,
+                  int* counts, long cap_counts, void* str_u8, long cap_str, int* n_counts, int* str_len, void* packed_u8, long cap_packed,
+                  int* offsets);
 
 /* ---- image front-end tail ------------------------------------------------------------------ */
 /* uint8 (H, W, 3) image (already resized; H, W multiples of patch*merge) → (H/patch * W/patch) rows of 3*temporal*patch*patch

@@ -11,7 +11,7 @@ from concurrent.futures import ThreadPoolExecutor
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
 LIB = os.path.join(HERE, "libpadt_hip.so")
-SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip", "decoder_hp.hip", "resize.hip"]
+SOURCES = ["capi.hip", "gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip", "decoder_hp.hip", "resize.hip", "rle.hip"]
 # Translation units written against the 16-bit operand type X of csrc/common.h: compiled a second time with X = fp16 (-DPADT_OP16_F16=1;
 # own namespace, entry points suffixed _f16: include/padt_hip_f16.h) and linked into the same library.
 TWIN_SOURCES = ["gemm.hip", "gemm256.hip", "attention.hip", "elementwise.hip", "vrt_head.hip"]

@@ -171,8 +171,23 @@ PADT_DEV float rounded32(float r) { asm("" : "+v"(r)); return r; }
 #else
 PADT_DEV float rounded32(float r) { return r; }                  // no mixed-precision fma writes bf16: nothing to pin
 #endif
-PADT_DEV float rope_lo(float x1, float x2, float c, float s) { return __builtin_fmaf(-x2, s, x1 * c); }   // x1 cos - x2 sin
-PADT_DEV float rope_hi(float x1, float x2, float c, float s) { return __builtin_fmaf(x1, s, x2 * c); }    // x2 cos + x1 sin
+// RANGE (round 5).  q and k are un-normalised projections: with fp16 operands a value beyond 65504 would become +-inf in the 16-bit store, and
+// an infinite k (or q) is the ONE overflow that can vanish silently — q·k = -inf is a key the softmax drops, the output stays finite and wrong.
+// Every rotated value therefore leaves through rope_fin(): in the fp16 instantiation a value fp16 cannot hold becomes NaN, which no kernel
+// downstream can lose (scores, soft-max, P·V, the residual stream and the final norm all propagate it) and which the finite checks of the
+// product path (padt_check_finite on the hidden rows of every prefill / decode step and on the ViT outputs) report.  Everywhere else an
+// overflow is +-inf and reaches the stream as inf / NaN by itself (h = silu(g)·u → down_proj, v → P·V → o_proj).  rope_fin also pins
+// "rotate in fp32, THEN cast" (rounded32) at every site, vector paths included.  bf16 has fp32's range: identity.
+#if PADT_OP16_F16
+PADT_DEV float rope_fin(float r) {
+    r = rounded32(r);
+    return __builtin_fabsf(r) <= 65504.0f ? r : __builtin_nanf("");
+}
+#else
+PADT_DEV float rope_fin(float r) { return r; }
+#endif
+PADT_DEV float rope_lo(float x1, float x2, float c, float s) { return rope_fin(__builtin_fmaf(-x2, s, x1 * c)); }   // x1 cos - x2 sin
+PADT_DEV float rope_hi(float x1, float x2, float c, float s) { return rope_fin(__builtin_fmaf(x1, s, x2 * c)); }    // x2 cos + x1 sin
 
 PADT_DEV void rope_pairs(float* o, int m, int n, const RopeEpi& r) {
     if (r.cos == nullptr || n >= r.cols) return;

@@ -439,6 +439,47 @@ extern "C" int padt_sigmoid_f32(void* stream, void* x, long n) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Finite check of a result tensor (round 5: the fp16-operand safety net).  flags[row / rows_per_flag] |= 1 when any element of the row
+// is +-inf or NaN.  kind 0: fp32, 1: bf16, 2: fp16.  An fp16-operand overflow anywhere upstream (SwiGLU hidden, q / k / v, attention
+// output, merger hidden, a stream beyond 2^20) reaches the rows checked here as inf / NaN (common.h rope_fin for the one case that
+// could otherwise vanish), so the product path never returns a silently wrong number: modeling.py raises or re-runs the batch on the
+// bf16 instantiation.  Reads the tensor once (16-byte vectors); the atomic only fires on a bad element.
+__global__ __launch_bounds__(256) void check_finite_kernel(const unsigned* __restrict__ x, long ld_bytes, long rows, int vec_per_row, int kind,
+                                                           int* __restrict__ flags, long rows_per_flag) {
+    const long total = rows * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vec_per_row;
+        const int c = (int)(i % vec_per_row);
+        const u32x4 v = *reinterpret_cast<const u32x4*>(reinterpret_cast<const char*>(x) + r * ld_bytes + (long)c * 16);
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const unsigned w = v[j];
+            if (kind == 0) bad |= (w & 0x7F800000u) == 0x7F800000u;
+            else if (kind == 1) bad |= ((w & 0x7F80u) == 0x7F80u) | ((w & 0x7F800000u) == 0x7F800000u);
+            else bad |= ((w & 0x7C00u) == 0x7C00u) | ((w & 0x7C000000u) == 0x7C000000u);
+        }
+        if (bad) atomicOr(flags + r / rows_per_flag, 1);
+    }
+}
+
+extern "C" int padt_check_finite(void* stream, const void* x, long ldx, long rows, long cols, int kind, int* flags, long rows_per_flag) {
+    if (rows <= 0 || cols <= 0) return 0;
+    const int es = kind == 0 ? 4 : 2;
+    if (kind < 0 || kind > 2 || flags == nullptr || rows_per_flag <= 0 || ((cols * es) & 15) || ((ldx * es) & 15) || ((uintptr_t)x & 15)) {
+        padt_set_error("padt_check_finite: kind 0 (fp32) / 1 (bf16) / 2 (fp16), 16-byte aligned rows of whole 16-byte vectors, flags and rows_per_flag >= 1 required");
+        return -1;
+    }
+    const int vpr = (int)(cols * es / 16);
+    long blocks = (rows * vpr + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    hipLaunchKernelGGL(check_finite_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const unsigned*)x, ldx * es, rows, vpr, kind,
+                       flags, rows_per_flag);
+    PADT_CHECK_LAUNCH("check_finite");
+    return 0;
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // VRT embedding: inputs_embeds[t] = image_embeds[img_index[t]] if img_index[t] >= 0 else [E ‖ proto][ids[t]]
 // (padt.py:193-219 prefill, 226-229 decode) — the table is never concatenated: two base pointers.
 __global__ __launch_bounds__(256) void embed_tokens_kernel(const long* __restrict__ ids, const int* __restrict__ img_index,

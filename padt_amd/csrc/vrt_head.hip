@@ -212,6 +212,9 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs p) {
     if (tid == 0) {
         const int unf = p.unfinished[b];
         long next = unf ? (long)si[0] : (long)p.pad;                 // padt.py:749
+        // a row whose logits are all NaN (an fp16 operand overflowed upstream: the range guard flags the batch, padt_check_finite) has no
+        // arg-max — bidx is still the sentinel; continue with the pad token so that every later index stays inside its table
+        if (si[0] == 0x7fffffff || next < 0 || (p.seen && (next >> 5) >= p.seen_words)) next = (long)p.pad;
         if (step < p.T_max) p.tokens_out[(long)b * p.T_max + step] = next;
         p.cur_tok[b] = next;
         bool is_eos = next == p.eos;

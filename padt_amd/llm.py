@@ -171,6 +171,7 @@ class DecodeSession:
         self.gen_cfg = ops.gen_cfg_tensor(1.0, (), device)
         self.seen = z(B, (cfg.vocab_size + np_max + 31) // 32, dt=I32)
         self.err = z(1, dt=I32)
+        self.nf = z(B, dt=I32)           # per row: a decode step produced a non-finite hidden row (fp16 operand overflow; ops.check_finite)
         self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
         self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
         self.graphs = {}                 # captured decode-step graph per mode (greedy / sampling: different kernel sequences)
@@ -237,6 +238,7 @@ class DecodeSession:
         else:
             ops.pack_rows(self.x, self.x_rm, B, to_packed=False)
             ops.rmsnorm(self.x_rm, W["llm.norm"], out=self.hn, eps=cfg.rms_norm_eps)
+        ops.check_finite(self.hn, self.nf, rows_per_flag=1, rows=B)      # sticky per-row flag, read once per generate (modeling.generate_collect)
         self.head_and_select(self.hn, advance=True)
 
     def head_and_select(self, hn, advance: bool):
@@ -293,17 +295,21 @@ class LanguageModel:
         self.cfg, self.W, self.device = cfg, W, device
         self._sessions = {}
 
-    def prototypes(self, image_embeds: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
-        """padt.py:187-191: LayerNorm then + W2(W1 x)."""
+    def prototypes(self, image_embeds: torch.Tensor, out: Optional[torch.Tensor] = None, nf=None) -> torch.Tensor:
+        """padt.py:187-191: LayerNorm then + W2(W1 x).  nf: int32 device flag set when a prototype row is not finite."""
         W = self.W
         if not self.cfg.use_visual_prototype_projection:
             if out is None:
-                return image_embeds.clone()
-            out.copy_(image_embeds)
-            return out
-        p = ops.layernorm(image_embeds, W["proto.norm.w"], W["proto.norm.b"], eps=1e-5)
-        t = ops.gemm(p, W["proto.0.w"])
-        return ops.gemm(t, W["proto.1.w"], out=out, epilogue=ops.EPI_RESID, residual=p)
+                out = image_embeds.clone()
+            else:
+                out.copy_(image_embeds)
+        else:
+            p = ops.layernorm(image_embeds, W["proto.norm.w"], W["proto.norm.b"], eps=1e-5)
+            t = ops.gemm(p, W["proto.0.w"])
+            out = ops.gemm(t, W["proto.1.w"], out=out, epilogue=ops.EPI_RESID, residual=p)
+        if nf is not None:
+            ops.check_finite(out, nf)
+        return out
 
     def session(self, B: int, need_s: int, need_np: int, need_t: int, lane: int = 0, grow: bool = True) -> Optional[DecodeSession]:
         """The lane's session for B rows, (re)allocated when too small; with grow=False returns None instead (a session
@@ -319,8 +325,9 @@ class LanguageModel:
             self._sessions[key] = s
         return s
 
-    def prefill(self, plan: PromptPlan, image_embeds: torch.Tensor, sess: DecodeSession):
-        """Packed prefill; fills the session's KV caches; returns the post-norm hidden states of all prompt tokens (T,D)."""
+    def prefill(self, plan: PromptPlan, image_embeds: torch.Tensor, sess: DecodeSession, nf=None):
+        """Packed prefill; fills the session's KV caches; returns the post-norm hidden states of all prompt tokens (T,D).
+        nf: int32 device flag set when a post-norm row is not finite (the residual stream absorbs every upstream inf / NaN)."""
         cfg, W = self.cfg, self.W
         Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         T = plan.ids.numel()
@@ -379,5 +386,9 @@ class LanguageModel:
             else:
                 ops.gemm(h, W[p + "down.w"], out=x, epilogue=ops.EPI_RESID, residual=x)
         if x32 is not None:
-            return ops.rmsnorm_f32(x32, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)
-        return ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)
+            ops.rmsnorm_f32(x32, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)
+        else:
+            ops.rmsnorm(x, W["llm.norm"], out=n, eps=cfg.rms_norm_eps)
+        if nf is not None:
+            ops.check_finite(n, nf)
+        return n

@@ -22,7 +22,7 @@ from .config import PaDTConfig
 from .decoder import PaDTDecoder
 from .llm import MODE, LanguageModel, plan_prompt
 from .vision import VisionEncoder
-from .weights import load_checkpoint_state_dict, prepare_weights, synthetic_state_dict
+from .weights import Fp16RangeError, load_checkpoint_state_dict, prepare_weights, synthetic_state_dict
 
 
 class StepHiddenStates:
@@ -85,16 +85,87 @@ class CustomGenerateDecoderOnlyOutput(dict):
             raise AttributeError(k) from e
 
 
+# ------------------------------------------------------------------------------------------------ generate() argument policy
+# HF / reference generate() arguments that cannot change what this path returns: accepted when they hold one of the listed values
+# (None = any value), otherwise NotImplementedError.
+_GENERATE_IGNORED = {
+    "attn_implementation": None, "tokenizer": None, "assistant_tokenizer": None, "cache_implementation": None, "logits_to_keep": None,
+    "generation_config": (None,), "output_attentions": (False, None), "output_scores": (False, None), "output_logits": (False, None),
+    "num_beams": (1, None), "num_beam_groups": (1, None), "num_return_sequences": (1, None), "penalty_alpha": (None,), "min_new_tokens": (0, None),
+    "min_length": (0, None), "no_repeat_ngram_size": (0, None), "bad_words_ids": (None,), "force_words_ids": (None,), "token_healing": (False, None),
+    "length_penalty": (1.0, None), "early_stopping": (False, None), "typical_p": (1.0, None), "min_p": (None,), "epsilon_cutoff": (0.0, None),
+    "eta_cutoff": (0.0, None), "encoder_repetition_penalty": (1.0, None), "guidance_scale": (None, 1.0), "renormalize_logits": (False, None),
+}
+# arguments the reference honours (padt.py:418-424,445,511-533,570-580,719-737) and this path does not implement
+_GENERATE_REJECTED = ("inputs", "logits_processor", "stopping_criteria", "prefix_allowed_tokens_fn", "assistant_model", "streamer",
+                      "negative_prompt_ids", "negative_prompt_attention_mask", "pixel_values_videos", "video_grid_thw", "second_per_grid_ts",
+                      "inputs_embeds", "past_key_values", "position_ids", "cache_position", "rope_deltas", "stop_strings", "max_time",
+                      "sequence_bias", "suppress_tokens", "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id",
+                      "exponential_decay_length_penalty", "prompt_lookup_num_tokens", "dola_layers", "labels")
+
+
+def check_generate_kwargs(kwargs: dict, max_new_tokens, max_length, prompt_len) -> int:
+    """The drop-in surface's argument policy (see generate()): → the effective max_new_tokens.  Raises NotImplementedError naming an
+    argument the reference honours and this path does not, ValueError (HF's _validate_model_kwargs wording) for an unknown one."""
+    for k in list(kwargs):
+        v = kwargs[k]
+        if k in _GENERATE_REJECTED:
+            if v is None or (k in ("logits_processor", "stopping_criteria") and hasattr(v, "__len__") and len(v) == 0):
+                continue                                              # the reference's own defaults (None / empty lists)
+            raise NotImplementedError(f"generate({k}=...) is not implemented on the MI355X path (the reference honours it, padt.py:414-580): "
+                                      "remove the argument or run the reference for this call")
+        if k in _GENERATE_IGNORED:
+            ok = _GENERATE_IGNORED[k]
+            if ok is None or v in ok:
+                continue
+            raise NotImplementedError(f"generate({k}={v!r}) is not implemented on the MI355X path (supported: {ok})")
+        raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}'] (note: typos in the generate arguments will also "
+                         "show up in this list)")
+    if max_new_tokens is None:
+        if max_length is not None:
+            if prompt_len is None or int(max_length) <= int(prompt_len):
+                raise ValueError(f"Input length of input_ids is {prompt_len}, but `max_length` is set to {max_length}. This can lead to unexpected "
+                                 "behavior. You should consider increasing `max_length` or, better yet, setting `max_new_tokens`.")
+            return int(max_length) - int(prompt_len)
+        return 1024
+    return int(max_new_tokens)
+
+
 class PaDTForConditionalGeneration:
-    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16", operands=None):
-        """dtype: the checkpoint's (the reference's torch_dtype argument; PaDT checkpoints are bf16).  operands: "fp16" (default) or "bf16" —
-        the 16-bit MFMA operand type ViT / LLM compute in, fp32 accumulation either way (weights.prepare_weights)."""
+    def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16", operands=None,
+                 state_dict_factory=None):
+        """dtype: the checkpoint's (the reference's torch_dtype argument; PaDT checkpoints are bf16).  operands: the 16-bit MFMA operand type
+        ViT / LLM compute in, fp32 accumulation either way (weights.prepare_weights):
+          "auto" (default; env PADT_OPERANDS) — fp16 operands (8x closer to the fp32 reference than bf16 at the same MFMA rate) UNDER A RANGE
+                 GUARD: every generate() checks its ViT output rows, prototypes and the post-norm hidden rows of the prompt pass and of every
+                 decode step for inf / NaN on the device (fp16 ends at 65504; an overflow of any un-normalised fp16 tensor — SwiGLU hidden,
+                 q / k / v, attention output, merger hidden — arrives there, csrc/common.h rope_fin); a flagged batch is RE-RUN on the bf16
+                 instantiation of the same kernels (fp32 range; built lazily from the same checkpoint, +13 GB at 3B) and a warning is logged;
+          "fp16" — the same guard, but a flagged batch raises PaDTHipError (no second weight set is ever built);
+          "bf16" — bf16 operands (the reference's own dtype): nothing to guard but NaN weights; a flagged batch raises.
+        state_dict_factory: callable returning the checkpoint's state dict again (from_pretrained / from_synthetic pass one so that the
+        fallback does not have to keep a second copy of the checkpoint alive); default: the dict given here is retained."""
         if dtype != torch.bfloat16:
             raise ValueError("PaDT checkpoints are bf16: pass torch_dtype=torch.bfloat16 (the MFMA operand type is chosen with operands=)")
         _lib.load()                                            # fail loudly before touching any weight
         self.config = config
         self.device = torch.device(device)
-        self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights, operands=operands)
+        operands = operands or os.environ.get("PADT_OPERANDS", "auto")
+        if operands not in ("auto", "fp16", "bf16"):
+            raise ValueError("operands must be 'auto', 'fp16' or 'bf16'")
+        self.operands = operands
+        self._llm_weights = llm_weights
+        self._sd_factory = state_dict_factory if state_dict_factory is not None else (lambda sd=state_dict: sd) if operands == "auto" else None
+        self._fallback = None                                  # the bf16-operand twin, built on the first flagged batch (operands="auto")
+        self.overflow_reruns = 0                               # batches answered by the twin so far
+        try:
+            self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights, operands="bf16" if operands == "bf16" else "fp16")
+        except Fp16RangeError as e:                            # a weight fp16 cannot hold: "auto" multiplies bf16 operands from the start
+            if operands != "auto":
+                raise
+            import warnings
+            warnings.warn("padt_amd: %s — operands='auto' falls back to bf16 MFMA operands for this checkpoint" % e, RuntimeWarning, stacklevel=2)
+            self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights, operands="bf16")
         self.dtype = self.W.op16                               # what pixel_values / hidden_states / past_image_embeds are held in
         self.visual = VisionEncoder(config, self.W, self.device)
         self.lm = LanguageModel(config, self.W, self.device)
@@ -127,7 +198,8 @@ class PaDTForConditionalGeneration:
             device = f"cuda:{d}" if isinstance(d, int) else str(d)
         elif isinstance(device_map, (str, torch.device)):
             device = str(device_map)
-        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights, operands=operands)
+        model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights, operands=operands,
+                    state_dict_factory=lambda: load_checkpoint_state_dict(path))
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             model.load_generation_config(json.load(open(gpath)))
@@ -153,9 +225,19 @@ class PaDTForConditionalGeneration:
     def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
         """Random-init weights of the given architecture (no checkpoints offline)."""
         kw_llm, kw_op = kw.pop("llm_weights", "bf16"), kw.pop("operands", None)
-        sd = state_dict if state_dict is not None else synthetic_state_dict(config, seed=seed, device=device,
-                                                                            dtype=torch.bfloat16, **kw)
-        return cls(config, sd, device=device, llm_weights=kw_llm, operands=kw_op)
+        make = (lambda: state_dict) if state_dict is not None else (lambda: synthetic_state_dict(config, seed=seed, device=device, dtype=torch.bfloat16, **kw))
+        return cls(config, make(), device=device, llm_weights=kw_llm, operands=kw_op, state_dict_factory=make)
+
+    def fallback_model(self):
+        """The bf16-operand twin of an operands="auto" model (same checkpoint, same kernels in their bf16 instantiation: fp32 range), built on
+        first use; its generation defaults follow this model's."""
+        if self._fallback is None:
+            if self.operands != "auto" or self._sd_factory is None:
+                raise _lib.PaDTHipError("no bf16 fallback: the model was built with operands=%r" % self.operands)
+            fb = PaDTForConditionalGeneration(self.config, self._sd_factory(), device=self.device, llm_weights=self._llm_weights, operands="bf16")
+            fb.generation_config = self.generation_config
+            self._fallback = fb
+        return self._fallback
 
     def eval(self):
         return self
@@ -163,12 +245,19 @@ class PaDTForConditionalGeneration:
     # ------------------------------------------------------------------ generate (padt.py:414-616 → 618-800)
     @torch.no_grad()
     def generate(self, input_ids=None, attention_mask=None, pixel_values=None, image_grid_thw=None, use_cache=True,
-                 max_new_tokens=1024, do_sample=None, output_hidden_states=True, return_dict_in_generate=True,
+                 max_new_tokens=None, do_sample=None, output_hidden_states=True, return_dict_in_generate=True,
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
                  use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None,
                  temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
-                 seed: Optional[int] = None, **unused):
+                 seed: Optional[int] = None, max_length: Optional[int] = None, **kwargs):
         """Greedy generation over the unified text‖VRT vocabulary.
+
+        Arguments of the reference's ``generate`` (padt.py:414-434 + the HF generation kwargs it forwards) that this path does not
+        implement are REJECTED by name (``NotImplementedError``: ``stopping_criteria``, ``logits_processor``, ``streamer``, ``min_length``,
+        ``num_beams`` > 1, video inputs, ``inputs_embeds``, ``output_scores`` / ``output_logits`` …), arguments that cannot change the
+        result here are accepted and ignored (``use_cache``, ``attn_implementation``, ``synced_gpus=False`` …), anything else raises the
+        ``ValueError`` HF's ``_validate_model_kwargs`` raises (padt.py:440) — a caller never gets silently different behaviour.
+        ``max_length`` (padt.py:511-520): total length incl. the (padded) prompt; ``max_new_tokens`` wins when both are given, as in HF.
 
         ``schedule`` (synthetic weights only): per-step logits-processor code — 't' text rows only, 'v' the sample's own
         VRT rows only, 'e' force EOS, None free — applied where HF's ``logits_processor`` sits (padt.py:717).
@@ -182,6 +271,10 @@ class PaDTForConditionalGeneration:
         by ``seed`` (default: drawn from torch's global generator, so torch.manual_seed makes runs repeatable).  The draws are
         not torch.multinomial's; the distribution is.
         """
+        if synced_gpus:
+            raise NotImplementedError("generate(synced_gpus=True) is the ZeRO-3 / FSDP lock-step loop (padt.py:445,670): every rank holds a full "
+                                      "replica on this path — pass synced_gpus=False")
+        max_new_tokens = check_generate_kwargs(kwargs, max_new_tokens, max_length, None if input_ids is None else input_ids.shape[1])
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
                                    schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
                                    eos_token_id=eos_token_id, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
@@ -240,7 +333,7 @@ class PaDTForConditionalGeneration:
             sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
                          use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule,
-                         gen_key=gen_key, eos_list=eos_list)
+                         gen_key=gen_key, eos_list=eos_list, lane=lane)
             sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu", do_sample=samp is not None, seed=samp[3] if samp else 0,
                                                   temperature=samp[0] if samp else 1.0, top_k=samp[1] if samp else 0,
                                                   top_p=samp[2] if samp else 1.0).to(dev, non_blocking=True))
@@ -268,11 +361,13 @@ class PaDTForConditionalGeneration:
                     or sess.np_max < proto_row0 + n_proto):
                 return None
         rows = slice(row0, row0 + B)
+        sess.nf[rows].zero_()
+        nf = torch.zeros(1, dtype=torch.int32, device=dev)       # this batch's range guard: ViT rows, prototypes, prompt-pass hidden rows
 
         # ---- ViT → prototypes → session table
         if vit_stream is None:
-            low, high, pe = self.visual(pixel_values.to(dev), grid)
-            proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+            low, high, pe = self.visual(pixel_values.to(dev), grid, nf=nf)
+            proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto], nf=nf)
         else:
             # the ViT of this batch on its own stream: it needs the inputs (event `inputs_ready` of the caller's stream) and nothing of the
             # current stream — so it runs while the PREVIOUS batch's prefill is still on the current stream — except for the first batch of a
@@ -283,8 +378,8 @@ class PaDTForConditionalGeneration:
             if k == 0 or inputs_ready is None:
                 vit_stream.wait_stream(cur)
             with torch.cuda.stream(vit_stream):
-                low, high, pe = self.visual(pixel_values.to(dev), grid)
-                proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto])
+                low, high, pe = self.visual(pixel_values.to(dev), grid, nf=nf)
+                proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto], nf=nf)
             cur.wait_stream(vit_stream)                           # the prefill below reads low / the prototype rows
             for t_ in (low, high, pe[0], pe[1]):                   # allocated on vit_stream, read on the prefill / decode streams
                 t_.record_stream(cur)
@@ -310,10 +405,11 @@ class PaDTForConditionalGeneration:
             ops.seen_init(ids_full.reshape(-1).contiguous(), rws.reshape(-1), sess.seen)
 
         # ---- prefill; the first token is selected together with the other batches of the group (launch_decode)
-        hn_all = self.lm.prefill(plan, low, sess)
+        hn_all = self.lm.prefill(plan, low, sess, nf=nf)
         ops.gather_rows(hn_all, plan.last_idx, out=sess.hn_first[rows])
         group["subs"].append(dict(plan=plan, low=low, high=high, pe=pe, proto=proto, hn_all=hn_all, input_ids=input_ids,
-                                  n_proto=n_proto, row0=row0, proto_row0=proto_row0))
+                                  n_proto=n_proto, row0=row0, proto_row0=proto_row0, nf=nf,
+                                  inputs=(attention_mask, pixel_values, image_grid_thw)))       # what a re-run on the bf16 twin needs
         group["proto_rows"] = proto_row0 + n_proto
         if len(group["subs"]) == group["n_slots"]:
             self.launch_decode(group)
@@ -355,11 +451,18 @@ class PaDTForConditionalGeneration:
             sess.run_steps(n, use_graph=group["use_graph"])
             done_steps += n
         group["done"] = done_steps
-        if int(sess.err) != 0:
+        # ONE read-back of every device flag of the group: the table-range assert (padt.py:203) and the range guard (per batch: ViT rows,
+        # prototypes, prompt-pass rows; per row: every decode step's hidden row)
+        flags = torch.cat([sess.err, sess.nf] + [sub["nf"] for sub in group["subs"]]).cpu()
+        if int(flags[0]) != 0:
             raise AssertionError("input_ids.max() >= extended table rows (padt.py:203)")
+        n_rows = sess.nf.numel()
         outs = []
-        for sub in group["subs"]:
+        for k_sub, sub in enumerate(group["subs"]):
             plan, row0, B = sub["plan"], sub["row0"], group["B"]
+            if int(flags[1 + n_rows + k_sub]) != 0 or bool(flags[1 + row0: 1 + row0 + B].any()):
+                outs.append(self._non_finite_batch(group, sub, output_hidden_states, return_dict_in_generate))
+                continue
             toks = sess.tokens[row0: row0 + B, :done_steps].clone()
             if sub["proto_row0"]:                                  # back to this batch's own global VRT ids
                 toks = torch.where(toks >= cfg.vocab_size, toks - sub["proto_row0"], toks)
@@ -389,6 +492,30 @@ class PaDTForConditionalGeneration:
                 past_visual_pe=sub["pe"])
             outs.append(out if return_dict_in_generate else sequences)
         return outs if all_batches else outs[0]
+
+    def _non_finite_batch(self, group, sub, output_hidden_states, return_dict_in_generate):
+        """A batch whose range guard fired: inf / NaN reached its ViT output, prototypes or hidden rows.  With fp16 operands that is an
+        overflow of an un-normalised 16-bit tensor (65504); operands="auto" answers it with the SAME batch on the bf16 instantiation."""
+        what = ("a non-finite value reached the ViT output / prototypes / post-norm hidden rows of a batch (%s MFMA operands)"
+                % ("fp16" if self.dtype == torch.float16 else "bf16"))
+        if self.operands != "auto" or self.dtype != torch.float16:
+            raise _lib.PaDTHipError(what + (": an un-normalised activation exceeded fp16's 65504 — build the model with operands='auto' (re-runs such "
+                                            "batches on bf16 operands) or operands='bf16'" if self.dtype == torch.float16 else
+                                            ": NaN / inf weights or inputs?"))
+        import warnings
+        fb = self.fallback_model()
+        self.overflow_reruns += 1
+        warnings.warn("padt_amd: " + what + " — fp16 range exceeded; the batch is re-run on the bf16-operand instantiation "
+                      "(%d so far; operands='bf16' avoids the second pass)" % self.overflow_reruns, RuntimeWarning, stacklevel=3)
+        am, pix, grid = sub["inputs"]
+        pen, eos, samp = group["gen_key"]
+        kw = dict(do_sample=False)
+        if samp is not None:
+            kw = dict(do_sample=True, temperature=samp[0], top_k=samp[1], top_p=samp[2], seed=samp[3])
+        return fb.generate(input_ids=sub["input_ids"], attention_mask=am, pixel_values=pix, image_grid_thw=grid, max_new_tokens=group["T_max"],
+                           schedule=group["schedule"], sync_every=group["sync_every"], use_graph=group["use_graph"], lane=("fb", group["lane"]),
+                           repetition_penalty=pen, eos_token_id=list(eos), output_hidden_states=output_hidden_states,
+                           return_dict_in_generate=return_dict_in_generate, **kw)
 
     # ------------------------------------------------------------------ vl_decode (padt.py:342-412)
     @torch.no_grad()

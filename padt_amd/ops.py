@@ -509,6 +509,21 @@ def rmsnorm_f32(x32, w, out=None, eps=1e-6):
     return out
 
 
+_KIND = {torch.float32: 0, BF16: 1, F16: 2}
+
+
+def check_finite(x, flags, rows_per_flag=None, rows=None):
+    """flags[row // rows_per_flag] |= 1 (int32 device tensor, caller zeroes it) for every row of the 2-D tensor x that holds +-inf or NaN
+    (padt_check_finite: the fp16-operand safety net).  rows_per_flag None → one flag for the whole tensor."""
+    assert x.is_cuda and x.dim() == 2 and x.stride(1) == 1 and x.dtype in _KIND, (x.dtype, x.shape, x.stride())
+    assert flags.dtype == torch.int32 and flags.is_cuda and flags.is_contiguous()
+    rows = x.shape[0] if rows is None else int(rows)
+    rpf = max(rows, 1) if rows_per_flag is None else int(rows_per_flag)
+    assert flags.numel() >= (rows + rpf - 1) // rpf
+    _lib.check(_lib.load().padt_check_finite(_stream(), _p(x), x.stride(0), rows, x.shape[1], _KIND[x.dtype], _p(flags), rpf), "padt_check_finite")
+    return flags
+
+
 def sigmoid_f32_(x):
     lib = _lib.load()
     assert x.dtype == torch.float32 and x.is_contiguous()
@@ -614,6 +629,38 @@ def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want
                                                up.stride(0) if up is not None else 0, up.stride(1) if up is not None else 0,
                                                n, int(max_h), int(max_w)), "padt_mask_upsample_binarize")
     return (out, up) if want_logits else out
+
+
+def mask_rle(bin_masks, dst_h, dst_w, want_counts=False):
+    """COCO RLE `counts` strings of binarised masks, computed on the device (padt_mask_rle): bin_masks (n_obj, max_h, max_w) uint8 as
+    mask_upsample_binarize returns them, dst_h / dst_w int32 device tensors (n_obj,).  → list of n_obj ASCII strings [, list of count lists].
+    Two small device-to-host copies (the offset table, then exactly the string bytes) instead of the masks themselves."""
+    lib = _lib.load()
+    assert bin_masks.dtype == torch.uint8 and bin_masks.is_cuda and bin_masks.dim() == 3 and bin_masks.stride(2) == 1
+    n, mh, mw = bin_masks.shape
+    if n == 0:
+        return ([], []) if want_counts else []
+    dev = bin_masks.device
+    cap_c = mh * mw + 2                                              # worst case: every pixel its own run (+ the zero-length first run)
+    cap_s = 2 * mh * mw + 16                                         # one byte per count + 4 more for each of the <= n / 16 counts of 16 and up
+    counts = torch.empty((n, cap_c), dtype=torch.int32, device=dev)
+    strs = torch.empty((n, cap_s), dtype=torch.uint8, device=dev)
+    n_counts = torch.empty(n, dtype=torch.int32, device=dev)
+    str_len = torch.empty(n, dtype=torch.int32, device=dev)
+    packed = torch.empty(n * cap_s, dtype=torch.uint8, device=dev)
+    offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
+    _lib.check(lib.padt_mask_rle(_stream(), _p(bin_masks), bin_masks.stride(0), bin_masks.stride(1), _p(dst_h), _p(dst_w), n, mh, _p(counts), cap_c,
+                                 _p(strs), cap_s, _p(n_counts), _p(str_len), _p(packed), packed.numel(), _p(offsets)), "padt_mask_rle")
+    off = offsets.cpu().tolist()
+    if off[-1] < 0:
+        raise _lib.PaDTHipError("padt_mask_rle: capacity exceeded (n_counts %s)" % n_counts.cpu().tolist())
+    raw = packed[: off[-1]].cpu().numpy().tobytes()
+    out = [raw[off[i]: off[i + 1]].decode("ascii") for i in range(n)]
+    if want_counts:
+        nc = n_counts.cpu().tolist()
+        cc = counts.cpu()
+        return out, [cc[i, : nc[i]].tolist() for i in range(n)]
+    return out
 
 
 def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):

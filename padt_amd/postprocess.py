@@ -84,10 +84,14 @@ def box_iou_xywh(b1: Sequence[float], b2: Sequence[float]) -> float:
     return 0.0 if union == 0 else inter / union
 
 
-def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]], rle: bool = True) -> List[Dict]:
+def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Sequence[Tuple[int, int]], rle: bool = True,
+                        want_mask: bool = True, device_rle: bool = True) -> List[Dict]:
     """decoded: vl_decode's dict; labels: parseVRTintoCompletion's per-sample label lists; image_sizes: (w, h) per sample
     (PIL order, as `images[sample_idx].size`).  → one dict per object: sample_idx, score, category, bbox, mask (uint8 numpy
-    (h, w)), rle {size, counts}."""
+    (h, w); want_mask), rle {size, counts}.
+    device_rle (default): the run lengths and the COCO counts string are computed on the GPU from the binarised masks (padt_mask_rle);
+    only the strings cross PCIe — with want_mask=False, which is the end state of the reference's eval loop (utils.py:262-265 writes the
+    RLE, not the mask), the 640 x 640 masks never leave the device.  device_rle=False: the host statement (rle_counts + rle_string)."""
     n = decoded["pred_boxes"].shape[0]
     if n == 0:
         return []
@@ -106,10 +110,14 @@ def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Seq
         dh = torch.tensor([s[1] for s in sizes], dtype=torch.int32, device=dev)
         dw = torch.tensor([s[0] for s in sizes], dtype=torch.int32, device=dev)
         mh, mw = max(s[1] for s in sizes), max(s[0] for s in sizes)
-        binm = ops.mask_upsample_binarize(masks.float().contiguous(), hs, ws, dh, dw, mh, mw).cpu().numpy()
+        bin_dev = ops.mask_upsample_binarize(masks.float().contiguous(), hs, ws, dh, dw, mh, mw)
+        strs = ops.mask_rle(bin_dev, dh, dw) if (rle and device_rle) else None
+        binm = bin_dev.cpu().numpy() if (want_mask or (rle and strs is None)) else None
         for i, r in enumerate(res):
-            m = binm[i, : sizes[i][1], : sizes[i][0]]
-            r["mask"] = m
+            if binm is not None:
+                m = binm[i, : sizes[i][1], : sizes[i][0]]
+                if want_mask:
+                    r["mask"] = m
             if rle:
-                r["rle"] = {"size": [sizes[i][1], sizes[i][0]], "counts": rle_string(rle_counts(m))}
+                r["rle"] = {"size": [sizes[i][1], sizes[i][0]], "counts": strs[i] if strs is not None else rle_string(rle_counts(m))}
     return res

@@ -116,12 +116,25 @@ def demo_max_side_size(w: int, h: int, max_side: int = 644):
 
 def fetch_image_size(w: int, h: int, factor: int = 28, min_pixels: int = 4 * 28 * 28, max_pixels: int = 16384 * 28 * 28):
     """eval/test_demo.py:61 `process_vision_info(message)` → qwen_vl_utils.vision_process.fetch_image: the decoded RGB image is resized
-    (PIL's default filter for RGB: BICUBIC) to smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28, max_pixels=16384 * 28 * 28) BEFORE
-    the demo's LANCZOS pass.  qwen_vl_utils is a third-party dependency the reference lists WITHOUT a version (setup.py:28) and that is not in the
-    build container: this restates the package's published rule (same rounding as the HF processor's smart_resize, which IS pinned here against
-    the installed transformers); parity for this one step is unpinned.  → (new_w, new_h)."""
-    nh, nw = smart_resize(h, w, factor, min_pixels, max_pixels)
-    return nw, nh
+    (PIL's default filter for RGB: BICUBIC) to the package's OWN smart_resize(height, width, factor=28, min_pixels=4 * 28 * 28,
+    max_pixels=16384 * 28 * 28) BEFORE the demo's LANCZOS pass.  qwen_vl_utils is a third-party dependency the reference lists WITHOUT a version
+    (setup.py:28) and that is not in the build container: this restates the package's published rule — which is NOT the HF processor's
+    smart_resize: it clamps each rounded side to at least `factor` BEFORE the pixel-budget branches (`max(factor, round_by_factor(side))`) and
+    refuses aspect ratios above 200 — so a 10 x 400 image becomes 392 x 28 here and would be 364 x 28 under the HF rule.  Parity
+    for this one step is unpinned against the package itself.  → (new_w, new_h)."""
+    if max(h, w) / min(h, w) > 200:
+        raise ValueError(f"absolute aspect ratio must be smaller than 200, got {max(h, w) / min(h, w)}")
+    h_bar = max(factor, round(h / factor) * factor)
+    w_bar = max(factor, round(w / factor) * factor)
+    if h_bar * w_bar > max_pixels:
+        beta = math.sqrt((h * w) / max_pixels)
+        h_bar = max(factor, math.floor(h / beta / factor) * factor)
+        w_bar = max(factor, math.floor(w / beta / factor) * factor)
+    elif h_bar * w_bar < min_pixels:
+        beta = math.sqrt(min_pixels / (h * w))
+        h_bar = math.ceil(h * beta / factor) * factor
+        w_bar = math.ceil(w * beta / factor) * factor
+    return w_bar, h_bar
 
 
 def eval_min_side_size(w: int, h: int, min_side: int = 28):

@@ -125,8 +125,9 @@ class VisionEncoder:
         else:
             ops.gemm(hbuf, W[p + "down.w"], W[p + "down.b"], out=x, epilogue=ops.EPI_RESID, residual=x)
 
-    def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None):
-        """pixel_values (P, C*T*p*p) fp32 / bf16 / fp16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd))."""
+    def __call__(self, pixel_values: torch.Tensor, grid_thw: torch.Tensor, proto_out=None, nf=None):
+        """pixel_values (P, C*T*p*p) fp32 / bf16 / fp16 on device → (image_embeds (N,D), high_res (P,vh), (cos,sin) (P,hd)).
+        nf: int32 device flag, set when the encoder's output rows are not finite (an fp16 operand overflowed in some block; ops.check_finite)."""
         cfg, W = self.cfg, self.W
         v = cfg.vision_config
         plan = self.plan(grid_thw)
@@ -157,6 +158,8 @@ class VisionEncoder:
         for i in range(v.depth):
             self.block(i, x, plan, rstd, qkv, att, hbuf, x32=x32)
         high = x32 if f32 else x                                               # the PaDT decoder reads fp32 or bf16 rows
+        if nf is not None:                                                     # inf / NaN of any block is absorbing in the residual stream
+            ops.check_finite(high, nf)
         if f32:
             ops.rmsnorm_f32(x32, W["vit.merger.ln_q"], out=n)
         else:

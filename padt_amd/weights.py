@@ -200,6 +200,10 @@ def fp8_gemm_ok(n: int, k: int) -> bool:
     return n % 256 == 0 and k % 128 == 0
 
 
+class Fp16RangeError(ValueError):
+    """A checkpoint value (or a norm-folded product) does not fit fp16: the model must multiply bf16 operands."""
+
+
 class PreparedWeights(dict):
     """name → device tensor in kernel layout (ViT / LLM / prototype tensors in the operand type `op16`, the PaDT decoder's in bf16).
     Plain dict plus a few derived sizes."""
@@ -251,9 +255,13 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
     W.fp8_prefill = llm_weights == "fp8" and W.resid_f32 and fp8_act
     op16 = W.op16
 
+    out_of_range = []                                       # (name, device bool): fp16 images holding inf / NaN, read back once at the end
+
     def put(name, t):
         # everything under "dec." belongs to the split-precision PaDT decoder, whose (hi, lo) operand pairs are bf16
         W[name] = t.to(device=dev, dtype=BF16 if name.startswith("dec.") else op16).contiguous()
+        if W[name].dtype == torch.float16:
+            out_of_range.append((name, (~torch.isfinite(W[name])).any()))
 
     def get(name):
         if name not in sd:
@@ -336,6 +344,13 @@ def prepare_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device="cuda",
         put("proto.norm.b", get("vis_norm.bias"))
         put("proto.0.w", get("vis_proj.0.weight"))
         put("proto.1.w", get("vis_proj.1.weight"))
+
+    if out_of_range:
+        bad = torch.stack([b for _, b in out_of_range]).cpu().tolist()
+        names = [n for (n, _), b in zip(out_of_range, bad) if b]
+        if names:
+            raise Fp16RangeError("values outside fp16's range (65504) in the fp16 images of %s%s: build the model with operands='bf16' "
+                                 "(operands='auto' does so by itself)" % (", ".join(names[:4]), " ..." if len(names) > 4 else ""))
 
     dh, di = cfg.vl_decoder["hidden_size"], cfg.vl_decoder["intermediate_size"]
     di_pad = _pad_to(di, 64)

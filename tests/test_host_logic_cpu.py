@@ -283,3 +283,41 @@ def test_processor_and_parser_on_a_real_bpe_tokenizer(golden_dir):
     assert got["vrt_encode_ids"].tolist()[-5:-1:1].count(got["vocab_after_prepare"] + 15) == 1
     assert json.loads(got["ovd.labels"]) == [["person", "traffic light", "bus"], []] and json.loads(got["truncated.labels"]) == [[], ["bus"]]
     assert json.loads(got["think.labels"]) == [["cat"], ["cat"]] and json.loads(got["rec.n_feats"]) == [[3], [2]]
+
+
+# ------------------------------------------------------------------------------------------------ generate() argument policy
+_REJECTED_WITH_VALUES = [("stopping_criteria", [object()]), ("logits_processor", [object()]), ("streamer", object()), ("min_length", 5),
+                         ("min_new_tokens", 3), ("num_beams", 4), ("pixel_values_videos", torch.zeros(1)), ("video_grid_thw", torch.zeros(1, 3)),
+                         ("inputs_embeds", torch.zeros(1, 2, 4)), ("prefix_allowed_tokens_fn", lambda *a: [0]), ("assistant_model", object()),
+                         ("negative_prompt_ids", torch.zeros(1, 2)), ("output_scores", True), ("output_logits", True), ("output_attentions", True),
+                         ("stop_strings", ["x"]), ("num_return_sequences", 2), ("generation_config", object())]
+
+
+@pytest.mark.parametrize("name,value", _REJECTED_WITH_VALUES, ids=[n for n, _ in _REJECTED_WITH_VALUES])
+def test_generate_rejects_arguments_it_does_not_implement(name, value):
+    """padt.py:414-434,445,511-533,570-580: the reference honours these; the MI355X path must say so instead of ignoring them.  The check
+    runs before anything touches the model, so an uninitialised instance is enough (no GPU, no library)."""
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    m = PaDTForConditionalGeneration.__new__(PaDTForConditionalGeneration)
+    with pytest.raises(NotImplementedError, match=name):
+        m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), max_new_tokens=4, **{name: value})
+
+
+def test_generate_argument_policy_defaults_unknowns_and_max_length():
+    from padt_amd.modeling import PaDTForConditionalGeneration, check_generate_kwargs
+    # the callers' own call (eval/test_demo.py:96-103, utils.py:224-232) and the reference's default-valued arguments pass
+    ok = dict(attn_implementation="flash_attention_2", tokenizer=None, stopping_criteria=None, logits_processor=[], streamer=None, num_beams=1,
+              min_length=0, output_scores=False, generation_config=None, pixel_values_videos=None)
+    assert check_generate_kwargs(dict(ok), 16, None, 9) == 16
+    assert check_generate_kwargs({}, None, None, 9) == 1024
+    # max_length counts the (padded) prompt (padt.py:511-520); max_new_tokens wins when both are given
+    assert check_generate_kwargs({}, None, 40, 9) == 31
+    assert check_generate_kwargs({}, 7, 40, 9) == 7
+    with pytest.raises(ValueError, match="max_length"):
+        check_generate_kwargs({}, None, 9, 9)
+    # an unknown keyword: HF's _validate_model_kwargs error (padt.py:440), not silence
+    with pytest.raises(ValueError, match="not used by the model.*max_new_token"):
+        check_generate_kwargs({"max_new_token": 3}, None, None, 9)
+    m = PaDTForConditionalGeneration.__new__(PaDTForConditionalGeneration)
+    with pytest.raises(NotImplementedError, match="synced_gpus"):
+        m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), synced_gpus=True)

@@ -1089,3 +1089,56 @@ def test_gemm_fp8_mfma_against_fp32_on_the_dequantised_operands(ops, M, N, K, mf
                f"fp8 swiglu {M}x{N}x{K}")
     with pytest.raises(Exception, match="padt_gemm_fp8"):
         ops.gemm_fp8(a8[:, :64], w8[:, :64], ws, rs)
+
+
+def test_mask_rle_on_the_device_is_the_host_statement_byte_for_byte(ops):
+    """padt_mask_rle (column-major run lengths + COCO rleToString in one block per object) against padt_amd.postprocess.rle_counts /
+    rle_string — the restatement of cocoapi's rleEncode / rleToString that tests/golden/postprocess.npz pins (make_golden_post.py) — on the
+    golden masks, on noise-like and blob-like masks of ragged sizes in ONE padded batch, and on the edge cases: all zeros, all ones, a leading
+    one (zero-length first run), a single pixel, one column, one row, heights that need the narrower LDS strips."""
+    import numpy as np
+    from padt_amd import postprocess as P
+    z = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "postprocess.npz"))
+    sizes = [tuple(int(v) for v in r) for r in z["image_sizes"]]
+    sidx = z["sample_idx"].tolist()
+    lens = z["exp_bits_len"].tolist()
+    cases, exp_golden, o = [], [], 0
+    for i, s in enumerate(sidx):
+        w, h = sizes[s]
+        cases.append(np.unpackbits(z["exp_bits"][o:o + lens[i]])[: h * w].reshape(h, w))
+        o += lens[i]
+        exp_golden.append(z["exp_str"].tolist()[i])
+    rng = np.random.default_rng(7)
+    for (h, w, p) in [(640, 640, 0.5), (640, 640, 0.03), (480, 640, 0.3), (37, 5, 0.5), (1, 97, 0.4), (97, 1, 0.4), (1, 1, 1.0), (1000, 130, 0.2), (2000, 40, 0.5)]:
+        cases.append((rng.random((h, w)) < p).astype(np.uint8))
+    yy, xx = np.mgrid[0:427, 0:640]
+    cases.append((((yy - 200) ** 2 + (xx - 300) ** 2) < 150 ** 2).astype(np.uint8))        # a blob: long runs, multi-byte counts, negative differences
+    cases += [np.zeros((33, 65), np.uint8), np.ones((33, 65), np.uint8), np.ones((640, 640), np.uint8)]
+    lead = np.zeros((64, 64), np.uint8)
+    lead[0, 0] = 1
+    cases.append(lead)
+    # groups of similar height share a launch (the LDS strip width follows the tallest mask of the launch)
+    groups = {}
+    for k, m in enumerate(cases):
+        groups.setdefault(0 if m.shape[0] <= 700 else (1 if m.shape[0] <= 1200 else 2), []).append(k)
+    got_s, got_c = {}, {}
+    for ks in groups.values():
+        mh, mw = max(cases[k].shape[0] for k in ks), max(cases[k].shape[1] for k in ks)
+        buf = torch.zeros((len(ks), mh, mw), dtype=torch.uint8)
+        for j, k in enumerate(ks):
+            buf[j, : cases[k].shape[0], : cases[k].shape[1]] = torch.from_numpy(cases[k])
+            buf[j, cases[k].shape[0]:, :] = 1                          # padding must not be read
+            buf[j, :, cases[k].shape[1]:] = 1
+        dh = torch.tensor([cases[k].shape[0] for k in ks], dtype=torch.int32, device="cuda")
+        dw = torch.tensor([cases[k].shape[1] for k in ks], dtype=torch.int32, device="cuda")
+        ss, cc = ops.mask_rle(buf.cuda(), dh, dw, want_counts=True)
+        for j, k in enumerate(ks):
+            got_s[k], got_c[k] = ss[j], cc[j]
+    for k, m in enumerate(cases):
+        counts = P.rle_counts(m)
+        assert got_c[k] == counts, f"case {k} {m.shape}: counts differ ({len(got_c[k])} vs {len(counts)})"
+        assert got_s[k] == P.rle_string(counts), f"case {k} {m.shape}: string differs"
+        assert sum(got_c[k]) == m.size
+    for k, s in enumerate(exp_golden):
+        assert got_s[k] == s                                          # the reference-side fixture itself
+    assert ops.mask_rle(torch.zeros((0, 4, 4), dtype=torch.uint8, device="cuda"), None, None) == []

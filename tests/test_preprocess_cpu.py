@@ -3,6 +3,7 @@ image processor (tests/golden/make_golden_pre.py)."""
 import os
 
 import numpy as np
+import pytest
 import torch
 
 HERE = os.path.dirname(os.path.abspath(__file__))
@@ -109,6 +110,12 @@ def test_demo_front_end_plan_is_the_callers_pil_sequence():
     from padt_amd import preprocess as P
     assert P.fetch_image_size(640, 427) == (644, 420) and P.fetch_image_size(333, 500) == (336, 504) and P.fetch_image_size(20, 96) == (28, 140)
     assert P.fetch_image_size(644, 644) == (644, 644) and P.fetch_image_size(5000, 4000) == (4004, 3192)      # 16384 * 28^2 pixels cap
+    # the package's OWN rule, not the HF processor's: a side below 14 px is clamped to 28 BEFORE the pixel-budget branches —
+    # 10 x 400: round(10 / 28) * 28 = 0 → 28, 400 → 392, 28 * 392 >= 4 * 28^2: done; the HF smart_resize scales both sides instead
+    assert P.fetch_image_size(400, 10) == (392, 28) and P.fetch_image_size(10, 400) == (28, 392)
+    assert P.smart_resize(10, 400, 28, 4 * 28 * 28, 16384 * 28 * 28) == (28, 364)
+    with pytest.raises(ValueError, match="aspect ratio"):
+        P.fetch_image_size(4030, 20)
     fe = P.ImageFrontEnd("cpu", dtype=torch.float32, resize="pil", pre_resize="demo")
     assert fe._plan_sizes(640, 427) == [(644, 420, "bicubic"), (644, 420, "lanczos")]          # already a multiple of 28 afterwards: no third pass
     assert fe._plan_sizes(1700, 1100) == [(1708, 1092, "bicubic"), (644, 411, "lanczos"), (644, 420, "bicubic")]
