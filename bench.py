@@ -488,6 +488,39 @@ def bf16_twin_leg(cfg, args, grid_hw, device):
     return out
 
 
+def reference_precision_leg(cfg, args, grid_hw, device):
+    """The SAME workload with precision="reference" (padt_amd/reference.py: ViT / LLM on (hi, lo) bf16 GEMM operands at twice the MFMA work,
+    fp32 ViT attention, eager decode steps): the mode that meets the north star's 1e-3 on EVERY float output, mask logits included
+    (tests/test_reference_mode_gpu.py: full-depth 3B boxes / mask logits asserted <= 1e-3, tokens equal) — its price next to the headline."""
+    import copy
+    from padt_amd import pipeline
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    a = copy.copy(args)
+    a.cap = 0
+    m2 = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device, llm_weights="bf16", operands="fp16", precision="reference")
+    inp2 = make_inputs(cfg, a, grid_hw, device, seed=1234, dtype=torch.float16)
+    r2 = pipeline.PipelinedRunner(m2, inp2["proc"], depth=2, merge=2)
+
+    def rs(k):
+        for _ in range(k):
+            ids, am, pix = next_batch(inp2)
+            r2.submit(ids, am, pix, inp2["grid"], max_new_tokens=a.tnew, schedule=inp2["sched"])
+        r2.flush()
+    rs(4)
+    torch.cuda.synchronize()
+    steps = 8
+    t0 = time.perf_counter()
+    rs(steps)
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    del r2, m2, inp2
+    torch.cuda.empty_cache()
+    return {"value": round(a.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3),
+            "note": "precision='reference': split-precision (hi, lo) bf16 GEMM operands through ViT / merger / prototypes / LLM (2x the MFMA work), fp32 ViT "
+                    "attention, fp16 MFMA attention in the LLM, eager decode steps in groups of 2 batches; full-depth 3B parity: boxes AND mask logits <= 1e-3, "
+                    "tokens equal (tests/test_reference_mode_gpu.py)"}
+
+
 def extra_workloads(args, device, model3b, cfg3b, grid3b):
     """BASELINE configs[3] and [4] per-GPU shapes, driver-timed as extra keys of the one JSON line (short runs, no side legs).  The OVD run
     uses the headline's own PaDT_Pro_3B weights; the 7B model is built (random init, fp8 e4m3 decode weights) after the 3B one is released."""
@@ -809,7 +842,7 @@ def main():
         if exchange is not None:
             line["exchange"] = {"all_gathers": exchange.n_gathers, "batches_per_gather": args.merge, "bytes_per_rank_per_gather": exchange.words * 4 * args.merge,
                                 "continuation_gathers": exchange.n_continuation_gathers, "backend": os.environ.get("PADT_DIST_BACKEND", "nccl"),
-                                "world_size": world, "ranks_seen_by_the_last_gather": int(gathered[-1].shape[0]) if gathered else None,
+                                "world_size": world, "ranks_seen_by_the_last_gather": int(gathered[-1].world) if gathered else None,
                                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if os.environ.get("PADT_DIST_BACKEND", "nccl") == "nccl" else None),
                                 "note": "device-side pack (one kernel per batch) + one asynchronous all_gather_into_tensor per decode group"}
         if steady is not None:
@@ -836,6 +869,8 @@ def main():
             leg("roofline", roofs)
         if not dist_on and args.bf16_twin and runner is not None and args.operands == "fp16" and args.extras:
             leg("operands_bf16", lambda: bf16_twin_leg(cfg, args, grid_hw, device))
+        if not dist_on and args.extras and runner is not None and args.operands == "fp16":
+            leg("reference_precision", lambda: reference_precision_leg(cfg, args, grid_hw, device))
         if not dist_on and args.from_images and runner is not None:
             leg("from_images", lambda: from_images_leg(model, inp, args, grid_hw, min(args.steps, 24)))
             leg("to_rle", lambda: to_rle_leg(model, inp, args, min(args.steps, 24)))

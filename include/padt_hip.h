@@ -230,6 +230,12 @@ int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long
 int padt_norm_split(void* stream, const void* x, long ldx, int x_f32, const int* idx, const void* add_f32, long ld_add, int add_div,
                     const void* w, float eps, int act, const void* pos_f32, long ld_pos, long pos_rows, void* y0, long ld_y0,
                     int y0_mode, void* y1, long ld_y1, int y1_mode, long rows, long D, long chunk);
+/* Reference-precision mode of ViT / LLM (round 5; padt_amd/reference.py: the SAME split-precision machinery — fp32 streams, (hi, lo) bf16 GEMM
+ * operands at K' = 2K — applied to the 68 upstream layers, so that every float output meets the north star's 1e-3):
+ * y = split(silu(g) * u) for fp32 rows [g(I) | u(I)] (the SwiGLU of HF:85-96 / :545-553 between two split GEMMs; y rows are [hi(I) | lo(I)]) */
+int padt_swiglu_split(void* stream, const void* gu_f32, long ld_gu, long I, void* y_split, long ld_y, long rows);
+/* fp32 LayerNorm with bf16 weight and bias → fp32 rows (vis_norm of the prototype projection, padt.py:187-191). */
+int padt_layernorm_f32(void* stream, const void* x_f32, long ldx, const void* w, const void* b, float eps, void* y_f32, long ldy, long rows, long D);
 /* In-place rotate-half rotary on fp32 rows (padt_decoder.py:38-51, flash-attn apply_rotary_emb, non-interleaved). */
 int padt_rope_half_f32(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T, int n_heads,
                        int head_dim);

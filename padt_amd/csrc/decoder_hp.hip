@@ -107,6 +107,53 @@ __global__ __launch_bounds__(256) void norm_split_kernel(NormSplitArgs p) {
     }
 }
 
+// SwiGLU of fp32 rows [gate(I) | up(I)] → split rows [hi(I) | lo(I)] of silu(gate) * up (HF:85-96, 545-553 at fp32-class precision: the
+// "reference" precision mode of ViT / LLM, padt_amd/reference.py); exact expf and an IEEE division, one rounding pair per element.
+__global__ __launch_bounds__(256) void swiglu_split_kernel(const float* __restrict__ gu, long ld_gu, int I, x16_t* __restrict__ y, long ld_y, long rows) {
+    const long total = rows * (I / 4);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / (I / 4);
+        const int c = (int)(i % (I / 4)) * 4;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(gu + r * ld_gu + c);
+        const f32x4 u = *reinterpret_cast<const f32x4*>(gu + r * ld_gu + I + c);
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = g[e] / (1.0f + expf(-g[e])) * u[e];
+        split_store4(y, r * ld_y, c, I, v);
+    }
+}
+
+// LayerNorm (with bias) of fp32 rows → fp32 rows: the prototype projection's vis_norm (padt.py:187-191) in the reference precision mode.
+// One wave per row; mean and variance as torch.nn.functional.layer_norm defines them (biased variance, eps inside the root).
+__global__ __launch_bounds__(256) void layernorm_f32_kernel(const float* __restrict__ x, long ldx, const x16_t* __restrict__ w, const x16_t* __restrict__ b,
+                                                            float eps, float* __restrict__ y, long ldy, int rows, int D) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (long)row * ldx;
+    float s = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        s += v[0] + v[1] + v[2] + v[3];
+    }
+    const float mean = wave_sum(s) / (float)D;
+    float q = 0.f;
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) q += (v[e] - mean) * (v[e] - mean);
+    }
+    const float rstd = rsqrtf(wave_sum(q) / (float)D + eps);
+    for (int c = lane * 4; c < D; c += 256) {
+        const f32x4 v = *reinterpret_cast<const f32x4*>(xr + c);
+        float wv[4], bv[4];
+        unpack4h(*reinterpret_cast<const u32x2*>(w + c), wv);
+        unpack4h(*reinterpret_cast<const u32x2*>(b + c), bv);
+        *reinterpret_cast<f32x4*>(y + (long)row * ldy + c) = f32x4{(v[0] - mean) * rstd * wv[0] + bv[0], (v[1] - mean) * rstd * wv[1] + bv[1],
+                                                                   (v[2] - mean) * rstd * wv[2] + bv[2], (v[3] - mean) * rstd * wv[3] + bv[3]};
+    }
+}
+
 // rotate-half rotary in place on fp32 rows: nh heads of width D per token, pairs (d, d + D/2); tables fp32 [T][ld_cs]
 __global__ __launch_bounds__(256) void rope_half_f32_kernel(float* __restrict__ x, long ldx, const float* __restrict__ cs,
                                                             const float* __restrict__ sn, long ld_cs, long T, int nh, int D) {
@@ -370,6 +417,31 @@ extern "C" int padt_norm_split(void* stream, const void* x, long ldx, int x_f32,
                     pos_rows, y0, ld_y0, y0_mode, y1, ld_y1, y1_mode, (int)rows, (int)D, (int)chunk};
     hipLaunchKernelGGL(norm_split_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, a);
     PADT_CHECK_LAUNCH("norm_split");
+    return 0;
+}
+
+extern "C" int padt_swiglu_split(void* stream, const void* gu_f32, long ld_gu, long I, void* y_split, long ld_y, long rows) {
+    if (rows <= 0 || I <= 0) return 0;
+    if ((I & 3) || (ld_gu & 3) || (ld_y & 3) || ld_gu < 2 * I || ld_y < 2 * I || ((uintptr_t)gu_f32 & 15) || ((uintptr_t)y_split & 7)) {
+        padt_set_error("padt_swiglu_split: I and strides multiples of 4, ld_gu / ld_y >= 2 I, 16-byte aligned rows");
+        return -1;
+    }
+    long blocks = (rows * (I / 4) + 255) / 256;
+    if (blocks > 32768) blocks = 32768;
+    hipLaunchKernelGGL(swiglu_split_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)gu_f32, ld_gu, (int)I, (x16_t*)y_split, ld_y, rows);
+    PADT_CHECK_LAUNCH("swiglu_split");
+    return 0;
+}
+
+extern "C" int padt_layernorm_f32(void* stream, const void* x_f32, long ldx, const void* w, const void* b, float eps, void* y_f32, long ldy, long rows, long D) {
+    if (rows <= 0) return 0;
+    if ((D & 3) || (ldx & 3) || (ldy & 3) || w == nullptr || b == nullptr || ((uintptr_t)x_f32 & 15) || ((uintptr_t)y_f32 & 15) || ((uintptr_t)w & 7) || ((uintptr_t)b & 7)) {
+        padt_set_error("padt_layernorm_f32: D and strides multiples of 4, bf16 weight and bias, 16-byte aligned rows");
+        return -1;
+    }
+    hipLaunchKernelGGL(layernorm_f32_kernel, dim3((unsigned)((rows + 3) / 4)), dim3(256), 0, (hipStream_t)stream, (const float*)x_f32, ldx, (const x16_t*)w,
+                       (const x16_t*)b, eps, (float*)y_f32, ldy, (int)rows, (int)D);
+    PADT_CHECK_LAUNCH("layernorm_f32");
     return 0;
 }
 

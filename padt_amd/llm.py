@@ -178,6 +178,9 @@ class DecodeSession:
         self.do_sample = False
         self.logits = None               # fp32 [B][V + np_max] rows for the sampling kernel, allocated on first use
         self.np_cur = np_max
+        self.step_fn = None              # precision="reference": the eager split-precision decode step (reference.ReferencePath.step) instead of step_kernels
+        self.hid32 = None                # ... and its fp32 per-step hidden rows [t_max][B][D]
+        self.ref_step = 0
 
     # one decode step, all on the current stream (eager or under capture)
     def step_kernels(self):
@@ -267,6 +270,10 @@ class DecodeSession:
 
     def run_steps(self, n: int, use_graph: bool = True):
         if n <= 0:
+            return
+        if self.step_fn is not None:                         # reference-precision mode: eager by construction
+            for _ in range(n):
+                self.step_fn(self)
             return
         if not use_graph:
             for _ in range(n):

@@ -133,7 +133,7 @@ def check_generate_kwargs(kwargs: dict, max_new_tokens, max_length, prompt_len) 
 
 class PaDTForConditionalGeneration:
     def __init__(self, config: PaDTConfig, state_dict, device="cuda", dtype=torch.bfloat16, llm_weights: str = "bf16", operands=None,
-                 state_dict_factory=None):
+                 state_dict_factory=None, precision: str = "default"):
         """dtype: the checkpoint's (the reference's torch_dtype argument; PaDT checkpoints are bf16).  operands: the 16-bit MFMA operand type
         ViT / LLM compute in, fp32 accumulation either way (weights.prepare_weights):
           "auto" (default; env PADT_OPERANDS) — fp16 operands (8x closer to the fp32 reference than bf16 at the same MFMA rate) UNDER A RANGE
@@ -144,7 +144,11 @@ class PaDTForConditionalGeneration:
           "fp16" — the same guard, but a flagged batch raises PaDTHipError (no second weight set is ever built);
           "bf16" — bf16 operands (the reference's own dtype): nothing to guard but NaN weights; a flagged batch raises.
         state_dict_factory: callable returning the checkpoint's state dict again (from_pretrained / from_synthetic pass one so that the
-        fallback does not have to keep a second copy of the checkpoint alive); default: the dict given here is retained."""
+        fallback does not have to keep a second copy of the checkpoint alive); default: the dict given here is retained.
+        precision: "default" — 16-bit MFMA operands as above (boxes within the north star's 1e-3 of the fp32 reference, mask logits at the
+        3.7e-3 floor of the operand type); "reference" — ViT / LLM on the split-precision machinery of the PaDT decoder (fp32 streams,
+        (hi, lo) bf16 GEMM operands at twice the MFMA work, fp32 ViT attention: padt_amd/reference.py): every float output within 1e-3, at
+        roughly a third of the default throughput (bench.py `reference_precision`); needs 16-bit LLM weights."""
         if dtype != torch.bfloat16:
             raise ValueError("PaDT checkpoints are bf16: pass torch_dtype=torch.bfloat16 (the MFMA operand type is chosen with operands=)")
         _lib.load()                                            # fail loudly before touching any weight
@@ -169,6 +173,15 @@ class PaDTForConditionalGeneration:
         self.dtype = self.W.op16                               # what pixel_values / hidden_states / past_image_embeds are held in
         self.visual = VisionEncoder(config, self.W, self.device)
         self.lm = LanguageModel(config, self.W, self.device)
+        if precision not in ("default", "reference"):
+            raise ValueError("precision must be 'default' or 'reference'")
+        self.precision = precision
+        self.ref = None
+        if precision == "reference":
+            if llm_weights != "bf16" or self.dtype != torch.float16:
+                raise ValueError("precision='reference' needs 16-bit LLM weights and fp16 attention operands (operands='auto' or 'fp16')")
+            from .reference import ReferencePath
+            self.ref = ReferencePath(config, state_dict, self)
         self.vl_decoder = PaDTDecoder(config, self.W, self.device, torch.bfloat16)
         self.model = SimpleNamespace(embed_tokens=SimpleNamespace(weight=self.W["llm.embed"]))
         self.use_visual_prototype_projection = config.use_visual_prototype_projection
@@ -182,7 +195,7 @@ class PaDTForConditionalGeneration:
     # ------------------------------------------------------------------ construction
     @classmethod
     def from_pretrained(cls, pretrained_model_name_or_path, torch_dtype=torch.bfloat16, attn_implementation=None,
-                        device_map=None, config=None, llm_weights: str = "bf16", operands=None, **_):
+                        device_map=None, config=None, llm_weights: str = "bf16", operands=None, precision: str = "default", **_):
         """Loads ``config.json`` + ``*.safetensors`` (checkpoint key layout of PaDT-MLLM/PaDT_*).  ``attn_implementation``
         is accepted and ignored: attention is always the HIP flash kernel."""
         path = str(pretrained_model_name_or_path)
@@ -199,7 +212,7 @@ class PaDTForConditionalGeneration:
         elif isinstance(device_map, (str, torch.device)):
             device = str(device_map)
         model = cls(config, load_checkpoint_state_dict(path), device=device, dtype=torch_dtype, llm_weights=llm_weights, operands=operands,
-                    state_dict_factory=lambda: load_checkpoint_state_dict(path))
+                    state_dict_factory=lambda: load_checkpoint_state_dict(path), precision=precision)
         gpath = os.path.join(path, "generation_config.json")
         if os.path.exists(gpath):
             model.load_generation_config(json.load(open(gpath)))
@@ -224,9 +237,9 @@ class PaDTForConditionalGeneration:
     @classmethod
     def from_synthetic(cls, config: PaDTConfig, seed=0, device="cuda", state_dict=None, **kw):
         """Random-init weights of the given architecture (no checkpoints offline)."""
-        kw_llm, kw_op = kw.pop("llm_weights", "bf16"), kw.pop("operands", None)
+        kw_llm, kw_op, kw_prec = kw.pop("llm_weights", "bf16"), kw.pop("operands", None), kw.pop("precision", "default")
         make = (lambda: state_dict) if state_dict is not None else (lambda: synthetic_state_dict(config, seed=seed, device=device, dtype=torch.bfloat16, **kw))
-        return cls(config, make(), device=device, llm_weights=kw_llm, operands=kw_op, state_dict_factory=make)
+        return cls(config, make(), device=device, llm_weights=kw_llm, operands=kw_op, state_dict_factory=make, precision=kw_prec)
 
     def fallback_model(self):
         """The bf16-operand twin of an operands="auto" model (same checkpoint, same kernels in their bf16 instantiation: fp32 range), built on
@@ -234,6 +247,8 @@ class PaDTForConditionalGeneration:
         if self._fallback is None:
             if self.operands != "auto" or self._sd_factory is None:
                 raise _lib.PaDTHipError("no bf16 fallback: the model was built with operands=%r" % self.operands)
+            if self.precision != "default":
+                raise _lib.PaDTHipError("precision='reference' has no bf16 twin: a non-finite batch is an error there")
             fb = PaDTForConditionalGeneration(self.config, self._sd_factory(), device=self.device, llm_weights=self._llm_weights, operands="bf16")
             fb.generation_config = self.generation_config
             self._fallback = fb
@@ -354,6 +369,11 @@ class PaDTForConditionalGeneration:
             sess.pos3.zero_()
             sess.cur_tok.fill_(cfg.pad_token_id)
             sess.vrt_off.zero_()
+            if self.ref is not None:                              # reference precision: eager split-precision steps + fp32 hidden rows
+                sess.step_fn = self.ref.step
+                if sess.hid32 is None or sess.hid32.shape[0] < T_max:
+                    sess.hid32 = torch.zeros((sess.t_max, sess.B, cfg.hidden_size), device=dev, dtype=torch.float32)
+                sess.ref_step = 1                                 # row 0 = the last prompt position (written by each batch's prompt pass)
         else:
             sess = group["sess"]
             if (group["launched"] or k >= group["n_slots"] or B != group["B"] or T_max != group["T_max"]
@@ -365,7 +385,10 @@ class PaDTForConditionalGeneration:
         nf = torch.zeros(1, dtype=torch.int32, device=dev)       # this batch's range guard: ViT rows, prototypes, prompt-pass hidden rows
 
         # ---- ViT → prototypes → session table
-        if vit_stream is None:
+        if self.ref is not None:
+            low, high, pe = self.ref.visual(pixel_values.to(dev), grid, nf=nf)
+            proto = self.ref.prototypes(low, sess, proto_row0, nf=nf)     # fp32 rows (→ past_image_embeds); sess.proto gets their fp16 image
+        elif vit_stream is None:
             low, high, pe = self.visual(pixel_values.to(dev), grid, nf=nf)
             proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto], nf=nf)
         else:
@@ -405,8 +428,13 @@ class PaDTForConditionalGeneration:
             ops.seen_init(ids_full.reshape(-1).contiguous(), rws.reshape(-1), sess.seen)
 
         # ---- prefill; the first token is selected together with the other batches of the group (launch_decode)
-        hn_all = self.lm.prefill(plan, low, sess, nf=nf)
-        ops.gather_rows(hn_all, plan.last_idx, out=sess.hn_first[rows])
+        if self.ref is not None:
+            hn_all = self.ref.prefill(plan, low, sess, nf=nf)             # fp32 rows
+            ops.gather_rows(hn_all, plan.last_idx, out=sess.hid32[0, rows])
+            ops.cast_f32_x16(sess.hid32[0, rows], out=sess.hn_first[rows])
+        else:
+            hn_all = self.lm.prefill(plan, low, sess, nf=nf)
+            ops.gather_rows(hn_all, plan.last_idx, out=sess.hn_first[rows])
         group["subs"].append(dict(plan=plan, low=low, high=high, pe=pe, proto=proto, hn_all=hn_all, input_ids=input_ids,
                                   n_proto=n_proto, row0=row0, proto_row0=proto_row0, nf=nf,
                                   inputs=(attention_mask, pixel_values, image_grid_thw)))       # what a re-run on the bf16 twin needs
@@ -474,7 +502,8 @@ class PaDTForConditionalGeneration:
             n_steps = toks.shape[1]
             sequences = torch.cat([sub["input_ids"].to(dev), toks], dim=1)
             # clone: the session's hidden_buf is reused by the lane's next generate(); the caller owns what it gets back
-            hidden = StepHiddenStates(sess.hidden_buf[:n_steps, row0: row0 + B].clone(), n_steps, sub["hn_all"],
+            hbuf = sess.hid32 if self.ref is not None else sess.hidden_buf      # reference precision keeps the per-step rows in fp32
+            hidden = StepHiddenStates(hbuf[:n_steps, row0: row0 + B].clone(), n_steps, sub["hn_all"],
                                       plan.lens, plan.L_pad)
             table_rows = cfg.vocab_size + sub["n_proto"]
 

@@ -736,6 +736,26 @@ def norm_split(x, w=None, eps=1e-6, act=0, idx=None, add=None, add_div=1, pos=No
     return y0, y1
 
 
+def swiglu_split(gu, I, out=None):
+    """fp32 rows [gate(I) | up(I)] → split rows [hi(I) | lo(I)] of silu(gate) * up (padt_swiglu_split)."""
+    assert gu.dtype == F32 and gu.stride(-1) == 1 and gu.shape[1] >= 2 * I
+    if out is None:
+        out = torch.empty((gu.shape[0], 2 * I), device=gu.device, dtype=BF16)
+    _lib.check(_lib.load().padt_swiglu_split(_stream(), _p(gu), gu.stride(0), int(I), _p(out), out.stride(0), gu.shape[0]), "padt_swiglu_split")
+    return out
+
+
+def layernorm_f32(x, w, b, eps=1e-5, out=None):
+    """fp32 LayerNorm rows (bf16 weight / bias) → fp32 rows (padt_layernorm_f32)."""
+    assert x.dtype == F32 and x.stride(-1) == 1
+    _chk_bf16(w, b)
+    if out is None:
+        out = torch.empty(x.shape, device=x.device, dtype=F32)
+    _lib.check(_lib.load().padt_layernorm_f32(_stream(), _p(x), x.stride(0), _p(w), _p(b), float(eps), _p(out), out.stride(0), x.shape[0], x.shape[1]),
+               "padt_layernorm_f32")
+    return out
+
+
 def rope_half_f32_(x, cos, sin, n_heads, head_dim):
     """in place on the first n_heads*head_dim columns of the fp32 rows x (T, row)."""
     assert x.dtype == F32 and cos.dtype == F32 and sin.dtype == F32 and cos.stride(-1) == 1 and sin.stride() == cos.stride()

@@ -272,6 +272,45 @@ def _split_decoded(decoded: dict, cap: int) -> List[dict]:
     return chunks
 
 
+class GatheredGroup:
+    """What ONE completed gather delivered to this rank: `records` (world, per_gather, words) int32 — slot b of rank r is the record of that
+    rank's b-th batch of the group (at most `cap` objects) — and, only when some rank had a batch over capacity, `continuation`
+    (world, k, words): the overflow records (word 3 of their header carries 1 + the slot they continue in bits 8 and up).  Always read a
+    batch through batch_record(): it re-assembles slot + continuation records; indexing `records` alone drops the objects beyond `cap`.
+    `records` is a view of the exchange's double buffer: consume (unpack / clone()) it before the second-next gather is issued."""
+
+    def __init__(self, records: torch.Tensor, continuation: Optional[torch.Tensor] = None):
+        self.records, self.continuation = records, continuation
+
+    @property
+    def world(self) -> int:
+        return self.records.shape[0]
+
+    @property
+    def per(self) -> int:
+        return self.records.shape[1]
+
+    def clone(self) -> "GatheredGroup":
+        return GatheredGroup(self.records.clone(), None if self.continuation is None else self.continuation.clone())
+
+    def cpu(self) -> "GatheredGroup":
+        return GatheredGroup(self.records.cpu(), None if self.continuation is None else self.continuation.cpu())
+
+    def batch_record(self, src_rank: int, slot: int) -> dict:
+        """One batch's results as rank `src_rank` computed them: the slot's record with its continuation records (if any) appended in order."""
+        parts = [unpack_results(self.records[src_rank, slot][None], batch_per_rank=0)[0]]
+        if self.continuation is not None:
+            for j in range(self.continuation.shape[1]):
+                if (int(self.continuation[src_rank, j, 3]) >> 8) == slot + 1:
+                    parts.append(unpack_results(self.continuation[src_rank, j][None], batch_per_rank=0)[0])
+        if len(parts) == 1:
+            return parts[0]
+        masks = [p["masks"] for p in parts]
+        return {"sample_idx": torch.cat([p["sample_idx"] for p in parts]), "boxes": torch.cat([p["boxes"] for p in parts]),
+                "scores": torch.cat([p["scores"] for p in parts]), "valid_hw": torch.cat([p["valid_hw"] for p in parts]),
+                "masks": torch.cat(masks) if all(m is not None for m in masks) else None}
+
+
 class ResultExchange:
     """The data-parallel exchange without lock-step: every rank packs `per_gather` consecutive batch records (normally one decode group)
     into one buffer and issues ONE asynchronous all_gather_into_tensor for them (RCCL runs it on its own stream); the handle is only waited
@@ -279,18 +318,17 @@ class ResultExchange:
     Every rank must add() the same number of batches.
 
         ex = ResultExchange(cap, mask_hw, per_gather=8, device=dev)
-        for decoded in ...: done += ex.add(decoded)        # → list of (world, per_gather [+ k], words) int32 tensors whose gather completed
+        for decoded in ...: done += ex.add(decoded)        # → list of GatheredGroup whose gather completed
         done += ex.flush()
-        for t in done: for b in range(ex.per): rec = ex.batch_record(t, src_rank, b)
+        for g in done: for b in range(g.per): rec = g.batch_record(src_rank, b)
 
     A batch with more objects than `cap` (an OVD image can carry tens of objects, padt.py:370) does NOT raise — on one rank that would leave
     the other ranks waiting in the gather for ever: its first `cap` objects travel in the batch's slot, the rest as CONTINUATION records.  The
     gather buffer's last word announces how many continuation records the rank holds for this gather; when the gather completes every rank
     sees every rank's count, so all ranks agree — without a further message — on k = the largest count and run ONE more (synchronous)
-    gather of k records per rank.  The k continuation records are appended to the returned tensor (slots per_gather … per_gather + k − 1; word 3
-    of their header carries 1 + the batch slot they continue in bits 8 and up).  With no rank over capacity (the normal case) nothing changes:
-    one collective per decode group, the returned tensors are views of a double buffer — consume (unpack / copy) them before the second-next
-    gather is issued."""
+    gather of k records per rank (GatheredGroup.continuation).  With no rank over capacity (the normal case) nothing changes: one collective
+    per decode group.  The announced counts reach the host through a pinned buffer filled on a side stream behind the gather (round 5): the
+    common k = 0 case costs no synchronisation of the caller's stream."""
 
     def __init__(self, cap: int, mask_hw: int, per_gather: int, device, group=None):
         import torch.distributed as dist
@@ -304,11 +342,15 @@ class ResultExchange:
         self._cont = []                                                # continuation records of the gather being filled
         self.n_gathers = 0
         self.n_continuation_gathers = 0
+        self._cuda = torch.device(device).type == "cuda"
+        if self._cuda:
+            self._side = torch.cuda.Stream(device=device)
+            self._counts = [torch.zeros(self.world, dtype=torch.int32).pin_memory() for _ in range(2)]
 
     def _slots(self, flat: torch.Tensor) -> torch.Tensor:
         return flat[..., : self.per * self.words].unflatten(-1, (self.per, self.words))
 
-    def add(self, decoded: dict) -> List[torch.Tensor]:
+    def add(self, decoded: dict) -> List[GatheredGroup]:
         chunks = _split_decoded(decoded, self.cap) if decoded["pred_boxes"].shape[0] > self.cap else [decoded]
         pack_results(chunks[0], self.cap, self.mask_hw, self.device, out=self._slots(self._bufs[self._cur])[self._fill])
         for c in chunks[1:]:
@@ -318,15 +360,20 @@ class ResultExchange:
         self._fill += 1
         return self._launch() if self._fill == self.per else []
 
-    def _wait(self) -> List[torch.Tensor]:
+    def _wait(self) -> List[GatheredGroup]:
         if self._inflight is None:
             return []
         import torch.distributed as dist
-        work, out, cont = self._inflight
-        work.wait()
+        work, out, cont, ev, counts = self._inflight
         self._inflight = None
-        res = self._slots(out)
-        k = int(out[:, -1].max().item())                               # every rank computes the same k from the same gathered words
+        if ev is not None:
+            ev.synchronize()                                           # the gather and the copy of the announced counts behind it are done
+            torch.cuda.current_stream().wait_event(ev)                 # ... and the caller's stream may read the gathered records
+            k = int(counts.max())
+        else:
+            work.wait()
+            k = int(out[:, -1].max().item())                           # every rank computes the same k from the same gathered words
+        more = None
         if k:
             mine = torch.zeros((k, self.words), dtype=torch.int32, device=self.device)
             for i, rec in enumerate(cont):
@@ -334,10 +381,9 @@ class ResultExchange:
             more = torch.empty((self.world, k, self.words), dtype=torch.int32, device=self.device)
             dist.all_gather_into_tensor(more.view(-1), mine.view(-1), group=self.group)
             self.n_continuation_gathers += 1
-            res = torch.cat([res, more], dim=1)
-        return [res]
+        return [GatheredGroup(self._slots(out), more)]
 
-    def _launch(self) -> List[torch.Tensor]:
+    def _launch(self) -> List[GatheredGroup]:
         import torch.distributed as dist
         done = self._wait()                                            # at most one gather in flight: its buffers are free again
         buf, out = self._bufs[self._cur], self._outs[self._cur]
@@ -345,27 +391,23 @@ class ResultExchange:
             self._slots(buf)[self._fill:].zero_()                      # partially filled last group: n = 0 records
         buf[-1:].fill_(len(self._cont))
         work = dist.all_gather_into_tensor(out.view(-1), buf, group=self.group, async_op=True)
-        self._inflight = (work, out, self._cont)
+        ev, counts = None, None
+        if self._cuda:
+            counts = self._counts[self._cur]
+            with torch.cuda.stream(self._side):
+                work.wait()                                            # orders the SIDE stream behind the collective; the caller's stream goes on
+                counts.copy_(out[:, -1], non_blocking=True)
+                ev = self._side.record_event()
+        self._inflight = (work, out, self._cont, ev, counts)
         self._cont = []
         self.n_gathers += 1
         self._cur ^= 1
         self._fill = 0
         return done
 
-    def flush(self) -> List[torch.Tensor]:
+    def flush(self) -> List[GatheredGroup]:
         done = self._launch() if self._fill else []
         return done + self._wait()
 
-    def batch_record(self, gathered: torch.Tensor, src_rank: int, slot: int) -> dict:
-        """One batch's results as rank `src_rank` computed them, from a tensor add() / flush() returned: the slot's record with its
-        continuation records (if any) appended in order."""
-        parts = [unpack_results(gathered[src_rank, slot][None], batch_per_rank=0)[0]]
-        for j in range(self.per, gathered.shape[1]):
-            if (int(gathered[src_rank, j, 3]) >> 8) == slot + 1:
-                parts.append(unpack_results(gathered[src_rank, j][None], batch_per_rank=0)[0])
-        if len(parts) == 1:
-            return parts[0]
-        masks = [p["masks"] for p in parts]
-        return {"sample_idx": torch.cat([p["sample_idx"] for p in parts]), "boxes": torch.cat([p["boxes"] for p in parts]),
-                "scores": torch.cat([p["scores"] for p in parts]), "valid_hw": torch.cat([p["valid_hw"] for p in parts]),
-                "masks": torch.cat(masks) if all(m is not None for m in masks) else None}
+    def batch_record(self, gathered: GatheredGroup, src_rank: int, slot: int) -> dict:
+        return gathered.batch_record(src_rank, slot)

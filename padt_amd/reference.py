@@ -1,0 +1,234 @@
+"""``precision="reference"`` — the split-precision machinery of the PaDT decoder (csrc/decoder_hp.hip) applied to the 68 upstream layers.
+
+The default path multiplies 16-bit MFMA operands (fp16: 11 mantissa bits) and lands AT the attributed floor of that operand type — boxes
+1.3e-4, mask logits 3.7e-3 of their range at full PaDT_Pro_3B depth: the north star's 1e-3 holds for the boxes and not for the mask logits.
+This mode meets it on every float output, at 2x the MFMA work:
+
+  * every GEMM A operand of ViT, merger, prototype projection and LLM is a bf16 (hi, lo) pair — hi = bf16(x), lo = bf16(x − hi): 16 mantissa
+    bits — against the weight image [W | W] (``padt_gemm_bf16_ex`` at K' = 2K; checkpoints are bf16, so W itself is exact; NO norm folding:
+    the normalised rows are produced explicitly by ``padt_norm_split``), fp32 accumulation, fp32 residual streams, fp32 SwiGLU
+    (``padt_swiglu_split``), fp32 LayerNorm of the prototypes (``padt_layernorm_f32``);
+  * ViT attention in fp32 (``padt_attn_f32``, the decoder's varlen kernel: 64-token windows and the four 2116 x 2116 full layers);
+  * LLM attention on the fp16 MFMA kernels as they are (q / k / v and the attention output in fp16, KV cache fp16, decode steps through
+    ``padt_decode_attn_rope``) — what tests/studies/reference_mode_floor.py shows to be affordable: with ONLY the LLM's attention internals
+    at fp16 the full-depth oracle sits at boxes 7e-6 / mask logits 3.4e-4 (profiles/r05_reference_mode_floor.md); the logit head stays the
+    fp16 ``padt_vrt_head`` (it selects tokens; no float output depends on it);
+  * token / image / prototype embeddings are gathered from ONE fp32 table [E ‖ prototypes ‖ image rows] (no 16-bit rounding on the way in),
+    the per-step hidden rows are kept in fp32 for ``parseVRTintoCompletion`` → ``vl_decode``.
+
+Decode steps run eagerly (11 launches per layer); this is a precision mode, not the throughput path: bench.py prints its rate next to the
+headline (``reference_precision``).  Everything below is kernel sequencing — no arithmetic in PyTorch.
+"""
+from typing import Dict
+
+import torch
+
+from . import ops
+from .config import PaDTConfig
+from .weights import _pad_cols, _pad_rows, _pad_to
+
+BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
+
+
+def _dbl(t: torch.Tensor) -> torch.Tensor:
+    """[W | W] along K: the image a (hi | lo) row multiplies."""
+    return torch.cat([t, t], dim=1).contiguous()
+
+
+def prepare_reference_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device) -> dict:
+    """Checkpoint → bf16 weight images of the reference-precision path: plain nn.Linear matrices doubled along K, nothing folded, gate / up
+    stacked [gate(I_pad) ; up(I_pad)] (un-interleaved: the SwiGLU is its own fp32 kernel), MLP intermediates zero-padded to a multiple of 64."""
+    dev = torch.device(device)
+    R = {}
+
+    def g(name):
+        if name not in sd:
+            raise KeyError(f"checkpoint is missing '{name}'")
+        return sd[name].to(device=dev, dtype=BF16)
+    v = cfg.vision_config
+    vi_pad = _pad_to(v.intermediate_size, 64)
+    R["vi_pad"] = vi_pad
+    R["vit.patch.hp"] = _dbl(g("visual.patch_embed.proj.weight").reshape(v.hidden_size, -1))
+    for i in range(v.depth):
+        s, d = f"visual.blocks.{i}.", f"vit.{i}."
+        R[d + "norm1"], R[d + "norm2"] = g(s + "norm1.weight").contiguous(), g(s + "norm2.weight").contiguous()
+        R[d + "qkv.hp"], R[d + "qkv.b"] = _dbl(g(s + "attn.qkv.weight")), g(s + "attn.qkv.bias").contiguous()
+        R[d + "proj.hp"], R[d + "proj.b"] = _dbl(g(s + "attn.proj.weight")), g(s + "attn.proj.bias").contiguous()
+        R[d + "gu.hp"] = _dbl(torch.cat([_pad_rows(g(s + "mlp.gate_proj.weight"), vi_pad), _pad_rows(g(s + "mlp.up_proj.weight"), vi_pad)], 0))
+        R[d + "gu.b"] = torch.cat([_pad_rows(g(s + "mlp.gate_proj.bias"), vi_pad), _pad_rows(g(s + "mlp.up_proj.bias"), vi_pad)], 0).contiguous()
+        R[d + "down.hp"], R[d + "down.b"] = _dbl(_pad_cols(g(s + "mlp.down_proj.weight"), vi_pad)), g(s + "mlp.down_proj.bias").contiguous()
+    R["vit.ln_q"] = g("visual.merger.ln_q.weight").contiguous()
+    mu, vh = cfg.merge_unit, v.hidden_size
+    m0 = g("visual.merger.mlp.0.weight")                              # (mu*vh, mu*vh): its input row is mu ViT rows side by side,
+    R["vit.m0.hp"] = torch.stack([m0.view(-1, mu, vh)] * 2, dim=2).reshape(m0.shape[0], 2 * mu * vh).contiguous()   # each as its own [hi | lo] pair
+    R["vit.m0.b"] = g("visual.merger.mlp.0.bias").contiguous()
+    R["vit.m2.hp"], R["vit.m2.b"] = _dbl(g("visual.merger.mlp.2.weight")), g("visual.merger.mlp.2.bias").contiguous()
+    li_pad = _pad_to(cfg.intermediate_size, 64)
+    R["li_pad"] = li_pad
+    for i in range(cfg.num_hidden_layers):
+        s, d = f"model.layers.{i}.", f"llm.{i}."
+        R[d + "in_norm"], R[d + "post_norm"] = g(s + "input_layernorm.weight").contiguous(), g(s + "post_attention_layernorm.weight").contiguous()
+        R[d + "qkv.hp"] = _dbl(torch.cat([g(s + "self_attn.q_proj.weight"), g(s + "self_attn.k_proj.weight"), g(s + "self_attn.v_proj.weight")], 0))
+        R[d + "qkv.b"] = torch.cat([g(s + "self_attn.q_proj.bias"), g(s + "self_attn.k_proj.bias"), g(s + "self_attn.v_proj.bias")], 0).contiguous()
+        R[d + "o.hp"] = _dbl(g(s + "self_attn.o_proj.weight"))
+        R[d + "gu.hp"] = _dbl(torch.cat([_pad_rows(g(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(g(s + "mlp.up_proj.weight"), li_pad)], 0))
+        R[d + "down.hp"] = _dbl(_pad_cols(g(s + "mlp.down_proj.weight"), li_pad))
+    R["llm.norm"] = g("model.norm.weight").contiguous()
+    R["llm.embed32"] = sd["model.embed_tokens.weight"].to(device=dev, dtype=F32).contiguous()
+    if cfg.use_visual_prototype_projection:
+        R["proto.norm.w"], R["proto.norm.b"] = g("vis_norm.weight").contiguous(), g("vis_norm.bias").contiguous()
+        R["proto.0.hp"], R["proto.1.hp"] = _dbl(g("vis_proj.0.weight")), _dbl(g("vis_proj.1.weight"))
+    return R
+
+
+class ReferencePath:
+    """ViT, prototypes, prompt pass and decode step of a ``precision="reference"`` model (modeling.PaDTForConditionalGeneration routes its
+    generate_launch / decode steps here; sessions, greedy bookkeeping, VRT head and parse / vl_decode are the default path's)."""
+
+    def __init__(self, cfg: PaDTConfig, state_dict, model):
+        self.cfg, self.m, self.device = cfg, model, model.device
+        assert model.dtype == F16, "the reference-precision path runs its LLM attention on the fp16 instantiation"
+        self.R = prepare_reference_weights(state_dict, cfg, self.device)
+        self._tables = {}
+
+    # ------------------------------------------------------------------ ViT (padt.py:48-106)
+    def visual(self, pixel_values, grid_thw, nf=None):
+        cfg, R = self.cfg, self.R
+        v = cfg.vision_config
+        plan = self.m.visual.plan(grid_thw)
+        P, vh, H = plan.P, v.hidden_size, v.num_heads
+        hd = vh // H
+        if pixel_values.shape[0] != P:
+            raise ValueError(f"pixel_values has {pixel_values.shape[0]} rows, image_grid_thw implies {P}")
+        pix = pixel_values.contiguous()
+        if pix.dtype != F32:
+            pix = ops.cast_x16_f32(pix)
+        S, F = ops.OUT_SPLIT, ops.OUT_F32
+        ps, _ = ops.norm_split(pix)                                            # pixel rows as (hi, lo) pairs
+        x0 = ops.gemm_hp(ps, R["vit.patch.hp"])                              # conv3d-as-GEMM (HF:116-122), fp32 out
+        x32 = ops.gather_rows(x0, plan.patch_perm, D=vh)                       # window order
+        for i in range(v.depth):
+            d = f"vit.{i}."
+            full = i in v.fullatt_block_indexes
+            cu, mx = (plan.cu_full, plan.max_full) if full else (plan.cu_win, plan.max_win)
+            n, _ = ops.norm_split(x32, R[d + "norm1"], eps=1e-6)
+            qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"])             # (P, 3 vh) fp32
+            ops.rope_half_f32_(qkv, plan.cos, plan.sin, 2 * H, hd)             # q and k are adjacent in the fused row
+            a = ops.attn_f32(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:3 * vh], cu, cu, mx, mx, H, hd)
+            ops.gemm_hp(a, R[d + "proj.hp"], R[d + "proj.b"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+            n, _ = ops.norm_split(x32, R[d + "norm2"], eps=1e-6)
+            gu = ops.gemm_hp(n, R[d + "gu.hp"], R[d + "gu.b"])
+            h = ops.swiglu_split(gu, R["vi_pad"])
+            ops.gemm_hp(h, R[d + "down.hp"], R[d + "down.b"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+        if nf is not None:
+            ops.check_finite(x32, nf)
+        n, _ = ops.norm_split(x32, R["vit.ln_q"], eps=1e-6)                    # (P, 2 vh): mu consecutive rows = one merger input row of mu pairs
+        mu = cfg.merge_unit
+        m = ops.gemm_hp(n.view(plan.N, 2 * vh * mu), R["vit.m0.hp"], R["vit.m0.b"], epilogue=ops.EPI_GELU, out_mode=S)
+        low_win = ops.gemm_hp(m, R["vit.m2.hp"], R["vit.m2.b"])
+        low = ops.gather_rows(low_win, plan.reverse, D=cfg.hidden_size)        # raster order (padt.py:103-104)
+        return low, x32, (plan.cos.clone(), plan.sin.clone())
+
+    # ------------------------------------------------------------------ the fp32 embedding table of a session
+    def table(self, sess):
+        """[E ‖ prototypes (np_max rows) ‖ image rows (np_max rows: a batch has as many merged image tokens as prototypes)] in fp32, one per
+        decode session: every embedding the LLM consumes is a row of it."""
+        cfg = self.cfg
+        key = id(sess)
+        t = self._tables.get(key)
+        need = cfg.vocab_size + 2 * sess.np_max
+        if t is None or t[0] is not sess or t[1].shape[0] < need:
+            buf = torch.empty((need, cfg.hidden_size), device=self.device, dtype=F32)
+            buf[: cfg.vocab_size].copy_(self.R["llm.embed32"])
+            if len(self._tables) >= 8:
+                self._tables.pop(next(iter(self._tables)))
+            t = (sess, buf)
+            self._tables[key] = t
+        return t[1]
+
+    def prototypes(self, low32, sess, proto_row0, nf=None):
+        """padt.py:187-191 in fp32 / split precision → the session's fp32 table rows AND its fp16 prototype table (head, range checks)."""
+        cfg, R = self.cfg, self.R
+        n = low32.shape[0]
+        tab = self.table(sess)
+        dst = tab[cfg.vocab_size + proto_row0: cfg.vocab_size + proto_row0 + n]
+        if not cfg.use_visual_prototype_projection:
+            dst.copy_(low32)
+        else:
+            p = ops.layernorm_f32(low32, R["proto.norm.w"], R["proto.norm.b"], eps=1e-5)
+            ps, _ = ops.norm_split(p)
+            t = ops.gemm_hp(ps, R["proto.0.hp"], out_mode=ops.OUT_SPLIT)
+            ops.gemm_hp(t, R["proto.1.hp"], out=dst, epilogue=ops.EPI_RESID, residual=p)
+        ops.cast_f32_x16(dst, out=sess.proto[proto_row0: proto_row0 + n])
+        if nf is not None:
+            ops.check_finite(dst, nf)
+        return dst
+
+    # ------------------------------------------------------------------ one LLM layer on fp32 rows x32 (in place)
+    def _layer(self, i, x32, attention):
+        cfg, R = self.cfg, self.R
+        d = f"llm.{i}."
+        n, _ = ops.norm_split(x32, R[d + "in_norm"], eps=cfg.rms_norm_eps)
+        qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"])
+        att16 = attention(ops.cast_f32_x16(qkv, dtype=F16))                    # fp16 MFMA attention (rope + KV append inside)
+        a, _ = ops.norm_split(ops.cast_x16_f32(att16))
+        ops.gemm_hp(a, R[d + "o.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+        n, _ = ops.norm_split(x32, R[d + "post_norm"], eps=cfg.rms_norm_eps)
+        gu = ops.gemm_hp(n, R[d + "gu.hp"])
+        h = ops.swiglu_split(gu, R["li_pad"])
+        ops.gemm_hp(h, R[d + "down.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+
+    def prefill(self, plan, low32, sess, nf=None):
+        """Packed prompt pass; fills the session's fp16 KV caches; → post-norm hidden rows of all prompt tokens, fp32 (T, D)."""
+        cfg = self.cfg
+        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        T = plan.ids.numel()
+        dev = self.device
+        n_img = low32.shape[0]
+        tab = self.table(sess)
+        img0 = cfg.vocab_size + sess.np_max
+        assert n_img <= sess.np_max, (n_img, sess.np_max)
+        tab[img0: img0 + n_img].copy_(low32)
+        ops.embed_tokens(plan.ids, plan.img_index, self.m.W["llm.embed"], sess.proto, None if n_img == 0 else ops.cast_f32_x16(low32, dtype=F16),
+                         err_flag=sess.err)                                   # the table-range assert of padt.py:203 (its rows are not used)
+        idx = torch.where(plan.img_index >= 0, plan.img_index + img0, plan.ids.to(torch.int32)).to(torch.int32).contiguous()
+        x32 = ops.gather_rows(tab, idx, D=cfg.hidden_size)
+        q = torch.empty((T, Hq * hd), device=dev, dtype=F16)
+        kp = torch.empty((T, Hkv * hd), device=dev, dtype=F16)
+        att = torch.empty((T, Hq * hd), device=dev, dtype=F16)
+        mx = max(plan.lens)
+        for i in range(cfg.num_hidden_layers):
+            def attention(qkv16, i=i):
+                ops.llm_qkv_post(qkv16, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max, cfg.mrope_section,
+                                 sample=plan.sample, slot=plan.slot, k_pack=kp)
+                ops.attn_varlen(q, kp, qkv16[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
+                return att
+            self._layer(i, x32, attention)
+        hn, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
+        if nf is not None:
+            ops.check_finite(hn, nf)
+        return hn
+
+    def step(self, sess):
+        """One decode step for every row of the session (eager; the default path's step_kernels with split-precision projections)."""
+        cfg = self.cfg
+        Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
+        B = sess.B
+        ops.embed_tokens(sess.cur_tok, None, self.m.W["llm.embed"], sess.proto, None, out=sess.x_rm, err_flag=sess.err)   # range assert only
+        tab = self.table(sess)
+        x32 = ops.gather_rows(tab, sess.cur_tok.to(torch.int32), D=cfg.hidden_size)
+        ops.rope_table(sess.pos3, sess.inv_freq, sess.rope_cs, hd, cfg.mrope_section)
+        att = torch.empty((B, Hq * hd), device=self.device, dtype=F16)
+        for i in range(cfg.num_hidden_layers):
+            def attention(qkv16, i=i):
+                ops.decode_attn_rope(qkv16, sess.rope_cs, sess.slot, sess.kc[i], sess.vtc[i], att, sess.attn_ws, Hq, Hkv, hd, sess.s_max, sess.s_max)
+                return att
+            self._layer(i, x32, attention)
+        hn32, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
+        ops.cast_f32_x16(hn32, out=sess.hn)
+        ops.check_finite(hn32, sess.nf, rows_per_flag=1, rows=B)
+        t = sess.ref_step
+        if t < sess.hid32.shape[0]:
+            sess.hid32[t].copy_(hn32)
+        sess.ref_step = t + 1
+        sess.head_and_select(sess.hn, advance=True)

@@ -100,7 +100,7 @@ def _worker_exchange(rank, world, port, q):
                                                          "pred_mask": torch.zeros(0, 8, 8), "sample_idx": [], "pred_mask_valid_hw": ()}
         done += [t.clone() for t in ex.add(dec)]
     done += [t.clone() for t in ex.flush()]
-    q.put(_ship((rank, ex.n_gathers, [d.clone() for d in done])))
+    q.put(_ship((rank, ex.n_gathers, [d.records.clone() for d in done])))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -120,7 +120,7 @@ def test_result_exchange_groups_gather_asynchronously_and_in_order():
         assert p.exitcode == 0
     for rank, n_gathers, done in got:
         assert n_gathers == 3 and len(done) == 3
-        recs = torch.cat(done, dim=1)                           # (world, 9, words): 7 real batches + 2 zero records
+        recs = torch.cat(done, dim=1)                           # (world, 9, words): 7 real batches + 2 zero records (GatheredGroup.records)
         assert recs.shape[:2] == (2, 9)
         for r in range(2):
             for b in range(9):
@@ -148,7 +148,7 @@ def _worker_overflow(rank, world, port, q):
                 rec = ex.batch_record(t, src, slot)
                 # numpy: pickled by value (tensors travel as shared-memory handles the parent may open after this process is gone)
                 out.append((g, src, slot, rec["boxes"].numpy().copy(), rec["sample_idx"].tolist(), rec["masks"].numpy().copy() if rec["masks"] is not None else None))
-    q.put((rank, ex.n_gathers, ex.n_continuation_gathers, [t.shape[1] for t in done], out))
+    q.put((rank, ex.n_gathers, ex.n_continuation_gathers, [t.per + (t.continuation.shape[1] if t.continuation is not None else 0) for t in done], out))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -847,7 +847,8 @@ def test_bench_ranks_exchange_delivers_every_ranks_results(tmp_path, world):
     assert covered == list(range(0, 8 * steps * world, 8))
     dumps = [torch.load(os.path.join(str(tmp_path), f"rank{k}.pt")) for k in range(world)]
     for me in range(world):
-        recs = torch.cat([g[:, :2] for g in dumps[me]["gathered"]], dim=1)    # (world, batches rounded up to whole gathers, words)
+        recs = torch.cat([g.records for g in dumps[me]["gathered"]], dim=1)   # (world, batches rounded up to whole gathers, words)
+        assert all(g.continuation is None for g in dumps[me]["gathered"])
         assert recs.shape[0] == world and recs.shape[1] >= steps
         for src in range(world):
             local = dumps[src]["local"]

@@ -392,7 +392,8 @@ def test_full_depth_3b_teacher_forced_against_oracle():
     if model.W.resid_f32:
         assert db < 1e-3 and iou > 0.99                              # north star on the box coordinates, end to end at full depth
     if op == torch.float16:
-        assert mx < max(5e-3, 1.5 * fmx), f"mask logits {mx:.3e} of their range (attributed floor {fmx:.3e})"
+        # round 5: sized to what is MEASURED (3.7e-3 = x1.04 of the floor re-run above), not to a round number
+        assert mx < 1.25 * fmx and mx < 4.6e-3, f"mask logits {mx:.3e} of their range (attributed floor {fmx:.3e})"
 
 
 def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
@@ -498,11 +499,14 @@ def test_3b_batch8_merged_runner_is_what_the_oracle_computes():
     print(f"[3B batch 8] tokens: {n_arg}/{B * T} the oracle's arg-max, {n_tie} inside the logit noise; box |d|max per sample "
           f"{[f'{x:.1e}' for x in db.tolist()]} (operand floor {[f'{x:.1e}' for x in fdb.tolist()]}); IoU min {min(ious):.4f}; "
           f"mask logits rel max {mx:.3e} (floor {fmx:.3e}) rms {rms:.3e} (floor {frms:.3e})")
-    assert n_arg >= int(0.85 * B * T)
+    if op == torch.float16:
+        assert n_arg == B * T, f"{n_arg}/{B * T} tokens are the oracle's arg-max (measured since round 4: all of them)"
+    else:
+        assert n_arg >= int(0.85 * B * T)                              # bf16 operands (PADT_OPERANDS=bf16 hand runs): 123 / 128, the rest inside the noise bound
     assert float(db.max()) < 3 * float(fdb.max()) + 2e-4 and mx < 3 * fmx and rms < 3 * frms
     if op == torch.float16:
         assert float(db.max()) < 1e-3, f"box coordinates of {int((db >= 1e-3).sum())} of {B} samples beyond 1e-3"
-        assert min(ious) > 0.995 and mx < max(5e-3, 1.5 * fmx)
+        assert min(ious) > 0.995 and mx < 1.3 * fmx and mx < 6e-3          # measured 5.1e-3 = x1.13 of the floor of these samples
     else:
         assert min(ious) > 0.98
 
@@ -739,8 +743,8 @@ def test_3b_ovd_geometry_merged_runner_against_oracle():
     mx, rms = rel(decm["pred_mask"][sel], odec["pred_mask"])
     print(f"\n[3B OVD geometry, {model.dtype}] L = {L}, T = {T}, {NB} batches in a 16-batch decode group; oracle on {NS} samples {t_or:.1f} s; "
           f"tokens {n_arg}/{NS * T} the oracle's arg-max (rest inside the bound); 14 boxes |d|max {float(db.max()):.3e}; mask logits rel max {mx:.3e} rms {rms:.3e}")
-    assert n_arg >= int(0.9 * NS * T)
-    assert float(db.max()) < 1e-3 and mx < 8e-3
+    assert n_arg == NS * T, f"{n_arg}/{NS * T} tokens are the oracle's arg-max (measured: 240/240)"
+    assert float(db.max()) < 1e-3 and mx < 7.5e-3                        # measured 6.5-6.8e-3 behind 950 cached keys
 
 
 @pytest.mark.parametrize("llm_weights", ["bf16", "fp8+act"])
@@ -831,4 +835,4 @@ def test_7b_full_depth_single_image_against_oracle(llm_weights):
     if act8:
         assert db < 1e-2 and min(ious) > 0.95 and n_out <= T // 4
     else:
-        assert db < 1e-3 and min(ious) > 0.995 and mx < 5e-3
+        assert db < 1e-3 and min(ious) > 0.995 and mx < 4.8e-3           # measured 4.1e-3
