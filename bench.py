@@ -15,7 +15,10 @@ Extra objects on that line (N=1): "roofline" (bf16 MFMA tile-GEMM family: in-ker
 running pipeline — HIP-event pairs around 290 launches per step cost 10 % throughput and count the dispatch gaps; frac_replay = the same
 launches replayed alone between one event pair), "roofline_decode" (HBM bytes of a decode step / its in-situ and stand-alone
 duration), "from_images" (the same pipeline fed from uint8 host images), "cpu_baseline" (the fp32 CPU oracle timed on this host, with the
-parity read-out), "extra_workloads" (BASELINE configs[3] OVD and configs[4] 7B RIC fp8 per-GPU shapes, short runs).
+parity read-out), "extra_workloads" (BASELINE configs[3] OVD and configs[4] 7B RIC fp8 per-GPU shapes, short runs), "steady_state" (64 steps of the
+same runner), "operands_bf16" (the bf16 instantiation, same steps), "reference_precision" (precision="reference": every float output within 1e-3).
+bench.py (like __graft_entry__.smoke) is a SOURCE-CHECKOUT tool: the synthetic workload (prompts, pixel rows, scripted schedules, tokenizer stand-in)
+lives in tests/synthetic_workload.py and the CPU baseline in oracle/ — test infrastructure, deliberately not shipped inside the padt_amd package.
 """
 import argparse
 import json
@@ -599,10 +602,12 @@ def to_rle_leg(model, inp, args, steps):
     r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
     sizes = [(640, 640)] * args.batch
     n_rec = [0]
+    post_stream = torch.cuda.Stream(device=inp["pix"].device, priority=-1)    # the records' small kernels + copies: not behind the caller's stream
 
     def post(done):
         for decoded, completions, labels, vrts in done:
-            n_rec[0] += len(postprocess.postprocess_results(decoded, labels, sizes, want_mask=False))   # the loop's end state is the RLE (utils.py:263-265)
+            with torch.cuda.stream(post_stream):                       # (the runner synchronised the lane's decode stream before returning `decoded`)
+                n_rec[0] += len(postprocess.postprocess_results(decoded, labels, sizes, want_mask=False))   # the loop's end state is the RLE (utils.py:263-265)
 
     def go(k):
         for _ in range(k):

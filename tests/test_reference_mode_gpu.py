@@ -147,3 +147,62 @@ def test_reference_precision_full_depth_3b_meets_the_north_star_on_every_float_o
     print(f"[reference precision, full 3B] end to end: box |d|max {db:.3e}  score |d| {ds:.3e}  mask logits max / range {mx:.3e} rms {rms:.3e}  "
           f"(default fp16 path on the same inputs: 1.3e-4 / 3.7e-3; oracle floor of 'LLM attention internals at fp16, everything else exact': 7e-6 / 3.4e-4)")
     assert db < 1e-3 and mx < 1e-3, f"north star missed: boxes {db:.3e}, mask logits {mx:.3e}"
+
+
+def test_reference_precision_batch8_every_sample_within_1e3():
+    """What bench.py's `reference_precision` leg times — PaDT_Pro_3B, batches of 8 different 46 x 46 images, 16 REC tokens with a run of 5 VRT,
+    two batches sharing one decode session through PipelinedRunner(depth=2, merge=2) — against the fp32 oracle for ALL 8 samples of a batch
+    (≈1.5 min of host CPU): every token the oracle's arg-max, EVERY sample's box within 1e-3 and the mask logits within 1e-3 of their range
+    (the default path on the same batch: boxes 0.7-3.4e-4, mask logits 5.1e-3); merged == un-merged bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import padt_amd
+    import parity_util as U
+    from padt_amd import pipeline
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    O = U.O
+    cfg = padt_amd.padt_pro_3b()
+    sd = synthetic_state_dict(cfg, seed=3, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda", precision="reference")
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    oc = U.oracle_config(cfg)
+    B, T, NB = 8, 16, 3
+    sched = U.rec_schedule(T, vrt_at=range(6, 11))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = [U.synthetic_batch(cfg, [[1, 46, 46]] * B, n_pre=15, n_post=33, seed=500 + i) for i in range(NB)]
+    runner = pipeline.PipelinedRunner(model, proc, depth=2, merge=2)
+    res = []
+    for grid, pix, ids, am in batches:
+        res += runner.submit(ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+    res += runner.flush()
+    assert len(res) == NB
+    grid, pix, ids, am = batches[1]                                   # the second batch of a merged group: row offset 8, prototype offset 8 x 529
+    dec1, comp1, lab1, vrt1 = pipeline.rec_batch(model, proc, ids.clone().cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, schedule=sched)
+    decm, compm, labm, vrtm = res[1]
+    assert compm == comp1 and vrtm == vrt1
+    for k in ("pred_boxes", "pred_score", "pred_mask"):
+        assert torch.equal(decm[k], dec1[k]), f"{k} differs between merged and un-merged decode"
+    out = model.generate(input_ids=proc.assign_to_global_vrt_id(ids.clone(), grid).cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(),
+                         image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    toks = out.sequences[:, L:].cpu()
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        gids = proc.assign_to_global_vrt_id(ids.clone(), grid)
+        ores = O.generate(w, oc, gids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        ost = ores["state"]
+        odec = O.vl_decode(w, oc, [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in range(6, 11)], 0)] for b in range(B)], ost.proto, ost.high_res, grid, ost.visual_pe)
+    n_eq = sum(int(torch.argmax(ores["logits"][t][b])) == int(toks[b, t]) for b in range(B) for t in range(T))
+    db = (decm["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().amax(dim=1)
+    rng = odec["pred_mask"].abs().max().item()
+    dm = (decm["pred_mask"].cpu().float() - odec["pred_mask"]).abs().flatten(1).amax(dim=1) / rng
+    print(f"\n[reference precision, 3B batch 8] oracle {time.perf_counter() - t0:.1f} s; tokens {n_eq}/{B * T} the oracle's arg-max; box |d|max per sample "
+          f"{[f'{x:.1e}' for x in db.tolist()]}; mask logits max / range per sample {[f'{x:.1e}' for x in dm.tolist()]}")
+    assert n_eq == B * T
+    assert float(db.max()) < 1e-3 and float(dm.max()) < 1e-3
