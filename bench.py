@@ -754,7 +754,8 @@ def main():
     assert decoded["pred_boxes"].shape == (args.batch * inp["n_obj"], 4) and torch.isfinite(decoded["pred_boxes"]).all()
     if args.dump_exchange:                                             # tests: what this rank computed and what it received from everybody
         os.makedirs(args.dump_exchange, exist_ok=True)
-        torch.save({"local": dump, "gathered": [g.cpu() for g in gathered], "cap": args.cap, "batch": args.batch},
+        torch.save({"local": dump, "gathered": [g.records.cpu() for g in gathered], "cap": args.cap, "batch": args.batch,      # plain tensors: torch.load(weights_only)
+                    "continuation": [None if g.continuation is None else g.continuation.cpu() for g in gathered]},
                    os.path.join(args.dump_exchange, f"rank{rank}.pt"))
 
     side = not dist_on and rank == 0 and not args.no_alt
@@ -850,6 +851,9 @@ def main():
                                 "world_size": world, "ranks_seen_by_the_last_gather": int(gathered[-1].world) if gathered else None,
                                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if os.environ.get("PADT_DIST_BACKEND", "nccl") == "nccl" else None),
                                 "note": "device-side pack (one kernel per batch) + one asynchronous all_gather_into_tensor per decode group"}
+        line["range_guard"] = {"operands_policy": getattr(args, "policy", args.operands), "batches_rerun_on_bf16": int(getattr(model, "overflow_reruns", 0)),
+                               "note": "fp16 operands under the device-side range guard: every batch's ViT rows, prototypes and prompt-pass / decode-step hidden rows are "
+                                       "checked for inf / NaN inside the timed region (padt_check_finite); a flagged batch would be re-run on the bf16 instantiation"}
         if steady is not None:
             line["steady_state"] = steady
         if lat is not None:

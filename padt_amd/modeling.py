@@ -162,6 +162,8 @@ class PaDTForConditionalGeneration:
         self._sd_factory = state_dict_factory if state_dict_factory is not None else (lambda sd=state_dict: sd) if operands == "auto" else None
         self._fallback = None                                  # the bf16-operand twin, built on the first flagged batch (operands="auto")
         self.overflow_reruns = 0                               # batches answered by the twin so far
+        self._batches_seen = 0
+        self.prefers_bf16 = False                              # "auto": set once most batches overflow — new decode groups then start on the twin directly
         try:
             self.W = prepare_weights(state_dict, config, self.device, llm_weights=llm_weights, operands="bf16" if operands == "bf16" else "fp16")
         except Fp16RangeError as e:                            # a weight fp16 cannot hold: "auto" multiplies bf16 operands from the start
@@ -311,6 +313,13 @@ class PaDTForConditionalGeneration:
         decode kernel); the weights are streamed once per step for all rows.  Returns None instead of adding when the
         batch does not fit the group's session (caller closes the group and starts a new one).
         """
+        # operands="auto" whose checkpoint keeps overflowing fp16: new decode groups start on the bf16 twin (a group stays with its owner)
+        owner = group["owner"] if group is not None else (self.fallback_model() if self.prefers_bf16 else self)
+        if owner is not self:
+            return owner.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample, schedule, sync_every,
+                                         use_graph, lane, decode_stream, group, n_slots, repetition_penalty, eos_token_id, temperature, top_k, top_p,
+                                         seed, vit_stream, inputs_ready)
+        self._batches_seen += 1
         gc = self.generation_config
         do_sample = gc.do_sample if do_sample is None else do_sample
         repetition_penalty = gc.repetition_penalty if repetition_penalty is None else repetition_penalty
@@ -348,7 +357,7 @@ class PaDTForConditionalGeneration:
             sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
                          use_graph=use_graph, decode_stream=decode_stream, done=0, launched=False, schedule=schedule,
-                         gen_key=gen_key, eos_list=eos_list, lane=lane)
+                         gen_key=gen_key, eos_list=eos_list, lane=lane, owner=self)
             sess.gen_cfg.copy_(ops.gen_cfg_tensor(gen_key[0], gen_key[1], "cpu", do_sample=samp is not None, seed=samp[3] if samp else 0,
                                                   temperature=samp[0] if samp else 1.0, top_k=samp[1] if samp else 0,
                                                   top_p=samp[2] if samp else 1.0).to(dev, non_blocking=True))
@@ -447,6 +456,8 @@ class PaDTForConditionalGeneration:
     def launch_decode(self, group):
         """First-token selection + the first chunk of decode steps (hipGraph replays, no host sync) for every batch of the
         group; ordered after their prefills (current stream) by an event when a decode stream is used."""
+        if group["owner"] is not self:
+            return group["owner"].launch_decode(group)
         if group["launched"]:
             return
         group["launched"] = True
@@ -470,6 +481,8 @@ class PaDTForConditionalGeneration:
     def generate_collect(self, group, output_hidden_states=True, return_dict_in_generate=True, all_batches=False):
         """Synchronising half of generate(): remaining decode chunks (host checks `unfinished` between chunks), trimming
         to the reference's stop rule, output object — of the group's only batch, or a list over its batches."""
+        if group["owner"] is not self:
+            return group["owner"].generate_collect(group, output_hidden_states, return_dict_in_generate, all_batches)
         cfg, dev = self.config, self.device
         self.launch_decode(group)
         sess, T_max = group["sess"], group["T_max"]
@@ -536,6 +549,11 @@ class PaDTForConditionalGeneration:
         self.overflow_reruns += 1
         warnings.warn("padt_amd: " + what + " — fp16 range exceeded; the batch is re-run on the bf16-operand instantiation "
                       "(%d so far; operands='bf16' avoids the second pass)" % self.overflow_reruns, RuntimeWarning, stacklevel=3)
+        if not self.prefers_bf16 and self.overflow_reruns >= 3 and 2 * self.overflow_reruns >= self._batches_seen:
+            # this checkpoint's activations do not fit fp16 as a rule, not as an exception: stop paying for two passes
+            self.prefers_bf16 = True
+            warnings.warn("padt_amd: %d of %d batches exceeded fp16's range — operands='auto' now starts every new decode group on the bf16 "
+                          "instantiation" % (self.overflow_reruns, self._batches_seen), RuntimeWarning, stacklevel=3)
         am, pix, grid = sub["inputs"]
         pen, eos, samp = group["gen_key"]
         kw = dict(do_sample=False)

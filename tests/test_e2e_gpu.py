@@ -774,8 +774,10 @@ def test_bench_contract_small_config():
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
-              "data", "config", "roofline", "roofline_decode", "from_images", "to_rle", "cpu_baseline", "parity_vs_oracle"):
+              "data", "config", "roofline", "roofline_decode", "from_images", "to_rle", "cpu_baseline", "parity_vs_oracle", "steady_state", "range_guard"):
         assert k in d, k
+    assert d["range_guard"]["operands_policy"] == "auto" and d["range_guard"]["batches_rerun_on_bf16"] == 0 and d["steady_state"]["value"] > 0
+    assert d["cpu_baseline"]["cores"] == min(32, os.cpu_count() or 1)
     assert d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1 and d["value"] > 0 and d["higher_is_better"] is True
     assert d["unit"] == "images/s" and d["scaling"] == "weak" and d["data"] == "synthetic" and "workload" in d["config"]
     rf = d["roofline"]
@@ -847,8 +849,8 @@ def test_bench_ranks_exchange_delivers_every_ranks_results(tmp_path, world):
     assert covered == list(range(0, 8 * steps * world, 8))
     dumps = [torch.load(os.path.join(str(tmp_path), f"rank{k}.pt")) for k in range(world)]
     for me in range(world):
-        recs = torch.cat([g.records for g in dumps[me]["gathered"]], dim=1)   # (world, batches rounded up to whole gathers, words)
-        assert all(g.continuation is None for g in dumps[me]["gathered"])
+        recs = torch.cat(dumps[me]["gathered"], dim=1)                          # GatheredGroup.records: (world, batches rounded up to whole gathers, words)
+        assert all(c is None for c in dumps[me]["continuation"])
         assert recs.shape[0] == world and recs.shape[1] >= steps
         for src in range(world):
             local = dumps[src]["local"]

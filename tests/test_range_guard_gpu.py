@@ -172,6 +172,32 @@ def test_range_guard_is_per_batch_inside_a_merged_decode_group():
         assert torch.isfinite(d1["pred_boxes"]).all()
 
 
+def test_auto_stops_paying_twice_when_most_batches_overflow():
+    """A checkpoint whose activations exceed fp16 on EVERY batch: after three re-runs (and at least half of the batches seen) an operands="auto"
+    model starts new decode groups on its bf16 twin directly — one pass per batch again, results = the bf16 model's, no further warnings."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    cfg, w, U = _weights("llm_swiglu")
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=8, ragged=True, seed=41)
+    T = 6
+    sched = U.rec_schedule(T, vrt_at=range(2, 4))
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    auto = PaDTForConditionalGeneration(cfg, w, device="cuda", operands="auto")
+    with warnings.catch_warnings(record=True) as rec:
+        warnings.simplefilter("always")
+        outs = [auto.generate(**kw) for _ in range(3)]
+    assert auto.overflow_reruns == 3 and auto.prefers_bf16
+    assert sum("now starts every new decode group on the bf16" in str(r.message) for r in rec) == 1
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")                             # fourth batch: straight to the twin, nothing to warn about
+        out4 = auto.generate(**kw)
+    assert auto.overflow_reruns == 3
+    ref = PaDTForConditionalGeneration(cfg, w, device="cuda", operands="bf16").generate(**kw)
+    for o in outs + [out4]:
+        assert torch.equal(o.sequences, ref.sequences) and torch.equal(o.hidden_states.last_layer_rows(), ref.hidden_states.last_layer_rows())
+
+
 def test_checkpoint_value_outside_fp16_is_caught_at_load():
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
