@@ -27,6 +27,11 @@ import sys
 import time
 
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # multi-process GPU work: the host driver only supports dmabuf IPC (RCCL needs it)
+# HIP maps streams onto HSA hardware queues, 4 by default: the runner's streams (caller's, prefill, two decode lanes) fill them, and a fifth
+# stream — the post-processing stream of the to_rle leg, RCCL's and the exchange's side stream with world > 1 — shares a queue with a busy one:
+# its first submission after an idle phase then waits for that queue's backlog (measured: 90 ms once per run, tools/diag/to_rle_timing.py;
+# gone with 8 queues).  Read by the ROCm runtime when it initialises; padt_amd/__init__.py sets the same default for other callers.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 import torch
 

@@ -80,7 +80,7 @@ class PaDTDecoder:
         key = (tuple(n_vp), tuple(obj_sample), tuple(patch_off), tuple(patch_num), tuple(tuple(g) for g in grids))
         pl = self._plans.get(key)
         if pl is not None:
-            self.last_sample_t = pl["sample_t"]
+            self.last_sample_t, self.last_src_hw = pl["sample_t"], (pl["Hs4"], pl["Ws4"])
             return pl
         dev, mu = self.device, self.cfg.merge_unit
         n_obj = len(n_vp)
@@ -105,12 +105,15 @@ class PaDTDecoder:
             tok_idx=torch.tensor([cu_q[o] + j for j in range(3) for o in range(n_obj)], dtype=I32, device=dev),
             Hs=torch.tensor(hs, dtype=torch.int64, device=dev), Ws=torch.tensor(ws, dtype=torch.int64, device=dev),
             Ws32=torch.tensor(ws, dtype=I32, device=dev), Hm=max(hs), Wm=max(ws),
+            # valid extent of each object's mask logits (4 x the patch grid) as int32: what padt_mask_upsample_binarize reads — kept with the
+            # plan so that the callers' post-processing needs no ATen arithmetic on the way (a first-use ATen kernel costs ≈90 ms of lazy load)
+            Hs4=torch.tensor([4 * h for h in hs], dtype=I32, device=dev), Ws4=torch.tensor([4 * w for w in ws], dtype=I32, device=dev),
             sample_t=torch.tensor(obj_sample, dtype=I32, device=dev))
         torch.cuda.current_stream().synchronize()                  # tables are shared by every stream that decodes this signature
         if len(self._plans) >= 64:
             self._plans.pop(next(iter(self._plans)))
         self._plans[key] = pl
-        self.last_sample_t = pl["sample_t"]
+        self.last_sample_t, self.last_src_hw = pl["sample_t"], (pl["Hs4"], pl["Ws4"])
         return pl
 
     def forward_objects(self, feats_cat, n_vp: List[int], low_img, high_img, pe_img, obj_sample: List[int],

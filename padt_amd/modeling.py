@@ -601,8 +601,10 @@ class PaDTForConditionalGeneration:
         bbox, score, masks, hw = self.vl_decoder.forward_objects(
             feats_cat, n_vp, low_res_image_embeds, high_res_image_embeds, visual_pes, obj_sample, patch_off, patch_num, grids)
         # "sample_idx_t": the same list as a device tensor (cached with the decoder's plan) for the device-side result pack
+        # "sample_idx_t" / "pred_mask_src_hw": device copies for the device-side consumers (result pack, mask post-processing) — shared with the
+        # decoder's cached plan: read-only
         return {"pred_boxes": bbox, "pred_score": score, "pred_mask": masks, "pred_mask_valid_hw": hw,
-                "sample_idx": obj_sample, "sample_idx_t": self.vl_decoder.last_sample_t}
+                "sample_idx": obj_sample, "sample_idx_t": self.vl_decoder.last_sample_t, "pred_mask_src_hw": self.vl_decoder.last_src_hw}
 
     def forward(self, *args, is_main=True, **kwargs):
         if is_main:

@@ -631,36 +631,48 @@ def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want
     return (out, up) if want_logits else out
 
 
-def mask_rle(bin_masks, dst_h, dst_w, want_counts=False):
-    """COCO RLE `counts` strings of binarised masks, computed on the device (padt_mask_rle): bin_masks (n_obj, max_h, max_w) uint8 as
-    mask_upsample_binarize returns them, dst_h / dst_w int32 device tensors (n_obj,).  → list of n_obj ASCII strings [, list of count lists].
-    Two small device-to-host copies (the offset table, then exactly the string bytes) instead of the masks themselves."""
+def mask_rle_launch(bin_masks, dst_h, dst_w):
+    """Enqueue padt_mask_rle for (n_obj, max_h, max_w) uint8 masks on the current stream; → handle for mask_rle_fetch (no host sync here, so a
+    caller can put its other device work and copies behind the same single wait)."""
     lib = _lib.load()
     assert bin_masks.dtype == torch.uint8 and bin_masks.is_cuda and bin_masks.dim() == 3 and bin_masks.stride(2) == 1
     n, mh, mw = bin_masks.shape
     if n == 0:
-        return ([], []) if want_counts else []
+        return None
     dev = bin_masks.device
     cap_c = mh * mw + 2                                              # worst case: every pixel its own run (+ the zero-length first run)
     cap_s = 2 * mh * mw + 16                                         # one byte per count + 4 more for each of the <= n / 16 counts of 16 and up
-    counts = torch.empty((n, cap_c), dtype=torch.int32, device=dev)
-    strs = torch.empty((n, cap_s), dtype=torch.uint8, device=dev)
-    n_counts = torch.empty(n, dtype=torch.int32, device=dev)
-    str_len = torch.empty(n, dtype=torch.int32, device=dev)
-    packed = torch.empty(n * cap_s, dtype=torch.uint8, device=dev)
-    offsets = torch.empty(n + 1, dtype=torch.int32, device=dev)
-    _lib.check(lib.padt_mask_rle(_stream(), _p(bin_masks), bin_masks.stride(0), bin_masks.stride(1), _p(dst_h), _p(dst_w), n, mh, _p(counts), cap_c,
-                                 _p(strs), cap_s, _p(n_counts), _p(str_len), _p(packed), packed.numel(), _p(offsets)), "padt_mask_rle")
-    off = offsets.cpu().tolist()
+    h = dict(n=n, counts=torch.empty((n, cap_c), dtype=torch.int32, device=dev), strs=torch.empty((n, cap_s), dtype=torch.uint8, device=dev),
+             n_counts=torch.empty(n, dtype=torch.int32, device=dev), str_len=torch.empty(n, dtype=torch.int32, device=dev),
+             packed=torch.empty(n * cap_s, dtype=torch.uint8, device=dev), offsets=torch.empty(n + 1, dtype=torch.int32, device=dev), masks=bin_masks)
+    _lib.check(lib.padt_mask_rle(_stream(), _p(bin_masks), bin_masks.stride(0), bin_masks.stride(1), _p(dst_h), _p(dst_w), n, mh, _p(h["counts"]), cap_c,
+                                 _p(h["strs"]), cap_s, _p(h["n_counts"]), _p(h["str_len"]), _p(h["packed"]), h["packed"].numel(), _p(h["offsets"])),
+               "padt_mask_rle")
+    return h
+
+
+def mask_rle_fetch(h, want_counts=False):
+    """→ list of n_obj ASCII COCO `counts` strings [, list of count lists]: the offset table, then exactly the string bytes."""
+    if h is None:
+        return ([], []) if want_counts else []
+    n = h["n"]
+    off = h["offsets"].cpu().tolist()
     if off[-1] < 0:
-        raise _lib.PaDTHipError("padt_mask_rle: capacity exceeded (n_counts %s)" % n_counts.cpu().tolist())
-    raw = packed[: off[-1]].cpu().numpy().tobytes()
+        raise _lib.PaDTHipError("padt_mask_rle: capacity exceeded (n_counts %s)" % h["n_counts"].cpu().tolist())
+    raw = h["packed"][: off[-1]].cpu().numpy().tobytes()
     out = [raw[off[i]: off[i + 1]].decode("ascii") for i in range(n)]
     if want_counts:
-        nc = n_counts.cpu().tolist()
-        cc = counts.cpu()
+        nc = h["n_counts"].cpu().tolist()
+        cc = h["counts"].cpu()
         return out, [cc[i, : nc[i]].tolist() for i in range(n)]
     return out
+
+
+def mask_rle(bin_masks, dst_h, dst_w, want_counts=False):
+    """COCO RLE `counts` strings of binarised masks, computed on the device (padt_mask_rle): bin_masks (n_obj, max_h, max_w) uint8 as
+    mask_upsample_binarize returns them, dst_h / dst_w int32 device tensors (n_obj,).  → list of n_obj ASCII strings [, list of count lists].
+    Two small device-to-host copies (the offset table, then exactly the string bytes) instead of the masks themselves."""
+    return mask_rle_fetch(mask_rle_launch(bin_masks, dst_h, dst_w), want_counts)
 
 
 def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):

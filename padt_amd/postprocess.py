@@ -95,23 +95,32 @@ def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Seq
     n = decoded["pred_boxes"].shape[0]
     if n == 0:
         return []
-    boxes = decoded["pred_boxes"].float().cpu()
-    scores = decoded["pred_score"].float().sigmoid().reshape(-1).cpu()
-    flat_labels = sum(labels, [])
     sidx = list(decoded["sample_idx"])
     sizes = [image_sizes[s] for s in sidx]
-    res = [{"sample_idx": int(s), "score": scores[i].item(), "category": flat_labels[i],
-            "bbox": box_to_pixels(boxes[i].tolist(), sizes[i][0], sizes[i][1])} for i, s in enumerate(sidx)]
     masks = decoded.get("pred_mask")
+    bin_dev = rle_h = None
     if masks is not None:
+        # device work first — mask up-sampling + threshold, run lengths + counts strings — so that the host waits ONCE (at the first copy below)
         dev = masks.device
-        hs = (decoded["pred_mask_valid_hw"][0].to(torch.int32) * 4).to(dev)
-        ws = (decoded["pred_mask_valid_hw"][1].to(torch.int32) * 4).to(dev)
+        src = decoded.get("pred_mask_src_hw")                          # vl_decode's int32 device copy of 4 x valid_hw (no ATen kernels on this path)
+        if src is not None and src[0].numel() == n:
+            hs, ws = src
+        else:                                                          # a dict that did not come from vl_decode
+            hs = (decoded["pred_mask_valid_hw"][0].to(torch.int32) * 4).to(dev)
+            ws = (decoded["pred_mask_valid_hw"][1].to(torch.int32) * 4).to(dev)
         dh = torch.tensor([s[1] for s in sizes], dtype=torch.int32, device=dev)
         dw = torch.tensor([s[0] for s in sizes], dtype=torch.int32, device=dev)
         mh, mw = max(s[1] for s in sizes), max(s[0] for s in sizes)
         bin_dev = ops.mask_upsample_binarize(masks.float().contiguous(), hs, ws, dh, dw, mh, mw)
-        strs = ops.mask_rle(bin_dev, dh, dw) if (rle and device_rle) else None
+        if rle and device_rle:
+            rle_h = ops.mask_rle_launch(bin_dev, dh, dw)
+    boxes = decoded["pred_boxes"].float().cpu()
+    scores = decoded["pred_score"].float().reshape(-1).cpu().sigmoid()     # n numbers: on the host (fp32, what the oracle does)
+    flat_labels = sum(labels, [])
+    res = [{"sample_idx": int(s), "score": scores[i].item(), "category": flat_labels[i],
+            "bbox": box_to_pixels(boxes[i].tolist(), sizes[i][0], sizes[i][1])} for i, s in enumerate(sidx)]
+    if masks is not None:
+        strs = ops.mask_rle_fetch(rle_h) if rle_h is not None else None
         binm = bin_dev.cpu().numpy() if (want_mask or (rle and strs is None)) else None
         for i, r in enumerate(res):
             if binm is not None:
