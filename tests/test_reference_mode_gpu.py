@@ -261,3 +261,54 @@ def test_reference_precision_ovd_geometry_mask_logits_within_1e3():
           f"arg-max; 14 boxes |d|max {float(db.max()):.3e}; mask logits max / range {mx:.3e} rms {rms:.3e}  (default path: 4.1e-4 / 6.8e-3)")
     assert n_eq == NS * T
     assert float(db.max()) < 1e-3 and mx < 1e-3
+
+
+def test_reference_precision_7b_full_depth_within_1e3():
+    """BASELINE configs[4]'s model at FULL depth — padt_pro_7b(): 28 layers at D = 3584 / 28:4 heads / MLP 18944, untied 152 064-row head, 32
+    ViT blocks — one 46 x 46 image, a RIC-shaped completion (2 VRT runs of 3), precision="reference": tokens equal, boxes and mask logits
+    within 1e-3 (the default path on the same inputs: boxes 3.8e-4, mask logits 4.1e-3).  33 GB of fp32 oracle weights on the host, ≈40 s."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import time
+    import padt_amd
+    import parity_util as U
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    from padt_amd.weights import synthetic_state_dict
+    from synthetic_workload import multi_object_schedule
+    O = U.O
+    cfg = padt_amd.padt_pro_7b()
+    sd = synthetic_state_dict(cfg, seed=41, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
+    model = PaDTForConditionalGeneration(cfg, sd, device="cuda", precision="reference")
+    w = {k: v.float().cpu() for k, v in sd.items()}
+    del sd
+    torch.cuda.empty_cache()
+    oc = U.oracle_config(cfg)
+    grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 46, 46]], n_pre=15, n_post=33, seed=78)
+    T, n_obj, n_vrt = 14, 2, 3
+    sched = multi_object_schedule(T, n_obj=n_obj, n_vrt=n_vrt)
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    L = ids.shape[1]
+    seq = out.sequences.cpu()
+    toks = seq[:, L:]
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    local = proc.assign_to_local_vrt_id(seq.clone(), grid)[:, L:]
+    comps, feats, labels, vrts, _ = padt_amd.parseVRTintoCompletion(proc, local, out["hidden_states"], torch.Tensor([False]))
+    assert len(feats[0]) == n_obj
+    dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks)
+        runs = [[t for t in range(T) if sched[t] == "v"][k * n_vrt: (k + 1) * n_vrt] for k in range(n_obj)]
+        st = ores["state"]
+        odec = O.vl_decode(w, oc, [[torch.cat([ores["hidden"][t][0:1, -1] for t in r], 0) for r in runs]], st.proto, st.high_res, grid, st.visual_pe)
+    n_eq = sum(int(torch.argmax(ores["logits"][t][0])) == int(toks[0, t]) for t in range(T))
+    hid = out.hidden_states.last_layer_rows()
+    worst = max(rel(hid[t], ores["hidden"][t][:, -1])[1] for t in range(T))
+    db = (dec["pred_boxes"].cpu().float() - odec["pred_boxes"]).abs().max().item()
+    mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
+    print(f"\n[reference precision, 7B full depth] oracle {time.perf_counter() - t0:.1f} s; tokens {n_eq}/{T} the oracle's arg-max; hidden rows rel rms worst {worst:.3e}; "
+          f"boxes |d|max {db:.3e}; mask logits max / range {mx:.3e} rms {rms:.3e}  (default path: 3.8e-4 / 4.1e-3)")
+    assert n_eq == T
+    assert db < 1e-3 and mx < 1e-3
