@@ -178,6 +178,8 @@ int padt_rope_half(void* stream, void* x, long ldx, const void* cos_t, const voi
 /* dst[i] = src[idx[i]] (bf16 / f32 rows).  padt.py:70-75,103-104 (window order), padt.py:365-373 (per-object copies). */
 int padt_gather_rows(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D);
 int padt_gather_rows_f32(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D);
+/* dst[idx[i]] = src[i], fp32 rows, distinct indices: the KV-cache update of a decode step (HF:641-689) for the fp32 cache of the reference-precision mode. */
+int padt_scatter_rows_f32(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D);
 /* y = a + b[row % b_rows].  padt_decoder.py:30-31 (additive positional queries), :202 (vp_embedding). */
 int padt_add_rows(void* stream, const void* a, long lda, const void* b, long ldb, long b_rows, void* y, long ldy, long n,
                   long D);
@@ -239,11 +241,13 @@ int padt_layernorm_f32(void* stream, const void* x_f32, long ldx, const void* w,
 /* In-place rotate-half rotary on fp32 rows (padt_decoder.py:38-51, flash-attn apply_rotary_emb, non-interleaved). */
 int padt_rope_half_f32(void* stream, void* x, long ldx, const void* cos_t, const void* sin_t, long ld_cs, long T, int n_heads,
                        int head_dim);
-/* fp32 varlen non-causal attention (padt_decoder.py:52-58): q/k/v fp32 rows with the heads contiguous, exact expf softmax,
- * output as split rows (chunk as above) for the out-projection.  head_dim 32 / 64 / 80 / 128. */
+/* fp32 varlen attention (padt_decoder.py:52-58): q/k/v fp32 rows with the heads contiguous, exact expf softmax,
+ * output as split rows (chunk as above) for the out-projection.  head_dim 32 / 64 / 80 / 128.  Round 5 (the reference-precision LLM, HF:641-689):
+ * kv_group (q head h reads kv head h / kv_group; 1 = the decoder's), causal (bottom-right aligned mask of the prompt pass; 0 = the decoder's),
+ * len_k (nullable: per-segment key counts for segments at fixed strides cu_k[s] with room to grow — the fp32 KV cache of the decode steps). */
 int padt_attn_f32(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split, long ldo,
                   long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k, int n_heads,
-                  int head_dim, float scale);
+                  int head_dim, float scale, int kv_group, int causal, const int* len_k);
 /* padt_mask_scatter on fp32 e2 / mask tokens. */
 int padt_mask_scatter_f32(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
                           const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm);

@@ -179,6 +179,10 @@ struct AttnF32Args {
     x16_t* out; long ldo; int chunk;             // split rows: element (t, h*D + d)
     const int* cu_q; const int* cu_k;
     float scale;
+    // round 5 (the reference-precision LLM, padt_amd/reference.py): GQA — q head h reads kv head h / kv_group —, a causal mask aligned
+    // bottom-right (key j of a segment is visible to its query i iff j <= i + nk - nq: the prompt pass), and an optional per-segment key
+    // COUNT for segments that sit at fixed strides with room to grow (the fp32 KV cache of the decode steps: keys [cu_k[s], cu_k[s] + len_k[s]))
+    int kv_group; int causal; const int* len_k;
 };
 
 // ---- few queries per segment (<= QB per block; more → blockIdx.y chunks), any number of keys: self-attention of the object
@@ -199,7 +203,10 @@ __global__ __launch_bounds__(256) void attn_f32_qfew_kernel(AttnF32Args p) {
     const int q0 = p.cu_q[seg] + blockIdx.y * QB, q_end = p.cu_q[seg + 1];
     if (q0 >= q_end) return;
     const int nq = (q_end - q0) < QB ? (q_end - q0) : QB;
-    const int k0 = p.cu_k[seg], nk = p.cu_k[seg + 1] - k0;
+    const int k0 = p.cu_k[seg], nk = p.len_k ? p.len_k[seg] : p.cu_k[seg + 1] - k0;
+    const int hk = h / p.kv_group;
+    // causal: query row q0 + qi is position (q0 + qi - q_begin) of its segment and sees keys 0 .. position + shift
+    const int shift = p.causal ? nk - (q_end - p.cu_q[seg]) + (q0 - p.cu_q[seg]) : nk;     // + qi → last visible key of query qi
     for (int i = tid; i < QB * D; i += 256) {
         const int qi = i / D, d = i % D;
         qs[qi][d] = qi < nq ? p.q[(long)(q0 + qi) * p.ldq + (long)h * D + d] * p.scale : 0.f;
@@ -215,7 +222,7 @@ __global__ __launch_bounds__(256) void attn_f32_qfew_kernel(AttnF32Args p) {
         const int n = (nk - kc) < KC ? (nk - kc) : KC;
         __syncthreads();                                          // qs / state ready; previous chunk's P·V done with sc
         if (tid < n) {
-            const float* kr = p.k + (long)(k0 + kc + tid) * p.ldk + (long)h * D;
+            const float* kr = p.k + (long)(k0 + kc + tid) * p.ldk + (long)hk * D;
             float kreg[D];
 #pragma unroll
             for (int c = 0; c < D; c += 4) {
@@ -228,7 +235,7 @@ __global__ __launch_bounds__(256) void attn_f32_qfew_kernel(AttnF32Args p) {
                     float s = 0.f;
 #pragma unroll
                     for (int c = 0; c < D; ++c) s += qs[qi][c] * kreg[c];
-                    sc[qi][tid] = s;
+                    sc[qi][tid] = (p.causal && kc + tid > shift + qi) ? -INFINITY : s;      // exp(-inf - m) = 0: the key is not there
                 }
             }
         }
@@ -253,7 +260,7 @@ __global__ __launch_bounds__(256) void attn_f32_qfew_kernel(AttnF32Args p) {
         if (active) {
 #pragma unroll
             for (int qi = 0; qi < QB; ++qi) if (qi < nq) o[qi] *= al_s[qi];
-            const float* vb = p.v + (long)(k0 + kc) * p.ldv + (long)h * D + d;
+            const float* vb = p.v + (long)(k0 + kc) * p.ldv + (long)hk * D + d;
             int j = part;
             for (; j + 3 * PARTS < n; j += 4 * PARTS) {           // 4 independent V loads in flight
                 const float v0 = vb[(long)j * p.ldv], v1 = vb[(long)(j + PARTS) * p.ldv];
@@ -307,7 +314,9 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
     if (q_begin + (int)blockIdx.x * 256 >= q_end) return;
     const int row = q_begin + blockIdx.x * 256 + tid;
     const bool valid = row < q_end;
-    const int k0 = p.cu_k[seg], nk = p.cu_k[seg + 1] - k0;
+    const int k0 = p.cu_k[seg], nk = p.len_k ? p.len_k[seg] : p.cu_k[seg + 1] - k0;
+    const int hk = h / p.kv_group;
+    const int lim = p.causal ? (row - q_begin) + nk - (q_end - q_begin) : nk - 1;          // last key this query row sees
     const float* qr = p.q + (long)(valid ? row : q_begin) * p.ldq + (long)h * D;
     float o[D];
 #pragma unroll
@@ -318,10 +327,12 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
         __syncthreads();
         for (int i = tid; i < n * (D / 4); i += 256) {
             const int j = i / (D / 4), c = (i % (D / 4)) * 4;
-            *reinterpret_cast<f32x4*>(&ks[j][c]) = *reinterpret_cast<const f32x4*>(p.k + (long)(k0 + kc + j) * p.ldk + (long)h * D + c);
-            *reinterpret_cast<f32x4*>(&vs[j][c]) = *reinterpret_cast<const f32x4*>(p.v + (long)(k0 + kc + j) * p.ldv + (long)h * D + c);
+            *reinterpret_cast<f32x4*>(&ks[j][c]) = *reinterpret_cast<const f32x4*>(p.k + (long)(k0 + kc + j) * p.ldk + (long)hk * D + c);
+            *reinterpret_cast<f32x4*>(&vs[j][c]) = *reinterpret_cast<const f32x4*>(p.v + (long)(k0 + kc + j) * p.ldv + (long)hk * D + c);
         }
         __syncthreads();
+        const int nv = (lim - kc + 1) < n ? (lim - kc + 1) : n;      // keys of this chunk the row sees (all of them without a causal mask)
+        if (nv <= 0) continue;                                        // (the barrier at the loop head keeps the block together)
         float s[KB];
 #pragma unroll
         for (int j = 0; j < KB; ++j) s[j] = 0.f;
@@ -331,7 +342,7 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
             q4 *= p.scale;
 #pragma unroll
             for (int j = 0; j < KB; ++j) {
-                if (j < n) {
+                if (j < nv) {
                     const f32x4 k4 = *reinterpret_cast<const f32x4*>(&ks[j][c]);
                     s[j] += q4[0] * k4[0] + q4[1] * k4[1] + q4[2] * k4[2] + q4[3] * k4[3];
                 }
@@ -339,7 +350,7 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
         }
         float mx = -INFINITY;
 #pragma unroll
-        for (int j = 0; j < KB; ++j) if (j < n) mx = fmaxf(mx, s[j]);
+        for (int j = 0; j < KB; ++j) if (j < nv) mx = fmaxf(mx, s[j]);
         const float m_new = fmaxf(m, mx);
         const float alpha = expf(m - m_new);
         l *= alpha;
@@ -349,11 +360,11 @@ __global__ __launch_bounds__(256) void attn_f32_kfew_kernel(AttnF32Args p) {
         // registers: every o index is a compile-time constant)
 #pragma unroll
         for (int j = 0; j < KB; ++j) {
-            const float pj = j < n ? expf(s[j] - m_new) : 0.f;
+            const float pj = j < nv ? expf(s[j] - m_new) : 0.f;
             l += pj;
             ps[j][tid] = pj;
         }
-        for (int j = 0; j < n; ++j) {
+        for (int j = 0; j < nv; ++j) {
             const float pj = ps[j][tid];
 #pragma unroll
             for (int c = 0; c < D; c += 4) {
@@ -470,14 +481,16 @@ static void launch_attn_f32(const AttnF32Args& a, int nseg, int max_q, int max_k
 // exact expf, fp32 accumulation; output as split (hi | lo) rows for the out-projection.  q/k/v rows hold the heads contiguously.
 extern "C" int padt_attn_f32(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split,
                              long ldo, long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k,
-                             int n_heads, int head_dim, float scale) {
+                             int n_heads, int head_dim, float scale, int kv_group, int causal, const int* len_k) {
     if (nseg <= 0 || max_seqlen_q <= 0) return 0;
+    if (kv_group < 1 || n_heads % kv_group) { padt_set_error("padt_attn_f32: kv_group must divide n_heads"); return -1; }
     if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (chunk & 3) || chunk <= 0 || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
         ((uintptr_t)v & 15) || ((uintptr_t)out_split & 7) || max_seqlen_k <= 0 || nseg > 65535 || n_heads > 65535) {
         padt_set_error("padt_attn_f32: strides / chunk multiples of 4, 16-byte aligned q/k/v, nseg and n_heads <= 65535");
         return -1;
     }
-    AttnF32Args a{(const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (x16_t*)out_split, ldo, (int)chunk, cu_q, cu_k, scale};
+    AttnF32Args a{(const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (x16_t*)out_split, ldo, (int)chunk, cu_q, cu_k, scale, kv_group,
+                  causal ? 1 : 0, len_k};
     hipStream_t s = (hipStream_t)stream;
     switch (head_dim) {
         case 32: launch_attn_f32<32>(a, nseg, max_seqlen_q, max_seqlen_k, n_heads, s); break;

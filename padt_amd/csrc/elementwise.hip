@@ -304,6 +304,32 @@ extern "C" int padt_gather_rows_f32(void* stream, const void* src, long ld_src, 
     return 0;
 }
 
+// dst[idx[i]] = src[i] for fp32 rows: the decode step's new K | V row of every sample into its slot of the fp32 KV cache (reference-precision
+// LLM, padt_amd/reference.py; HF:641-689 cache update).  Indices must be distinct.
+__global__ __launch_bounds__(256) void scatter_rows_f32_kernel(const float* __restrict__ src, long ld_src, const int* __restrict__ idx,
+                                                               float* __restrict__ dst, long ld_dst, long n, int vec_per_row) {
+    const long total = n * vec_per_row;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / vec_per_row;
+        const int c = (int)(i % vec_per_row) * 4;
+        *reinterpret_cast<f32x4*>(dst + (long)idx[r] * ld_dst + c) = *reinterpret_cast<const f32x4*>(src + r * ld_src + c);
+    }
+}
+
+extern "C" int padt_scatter_rows_f32(void* stream, const void* src, long ld_src, const int* idx, void* dst, long ld_dst, long n, long D) {
+    if (n <= 0) return 0;
+    if ((D & 3) || (ld_src & 3) || (ld_dst & 3) || ((uintptr_t)src & 15) || ((uintptr_t)dst & 15) || idx == nullptr) {
+        padt_set_error("padt_scatter_rows_f32: D and strides multiples of 4, 16-byte aligned rows");
+        return -1;
+    }
+    long blocks = (n * (D / 4) + 255) / 256;
+    if (blocks > 16384) blocks = 16384;
+    hipLaunchKernelGGL(scatter_rows_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src, ld_src, idx, (float*)dst,
+                       ld_dst, n, (int)(D / 4));
+    PADT_CHECK_LAUNCH("scatter_rows_f32");
+    return 0;
+}
+
 #endif
 
 // y = a + b[row % b_rows]   (decoder: key/query + positional query, padt_decoder.py:30-31; b_rows == rows → plain add)

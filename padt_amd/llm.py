@@ -75,6 +75,7 @@ class PromptPlan:
     next_pos: List[int]
     rope_deltas: torch.Tensor        # (B,1) int64, 4.50 convention: max+1 - L_pad
     vrt_off: List[int]               # (B+1) prototype row offsets
+    first_row: int = 0               # decode-session row of this batch's first sample (merged decode groups)
 
 
 def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Optional[torch.Tensor],
@@ -111,7 +112,7 @@ def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Option
         B=B, L_pad=L, lens=lens, ids=ids.to(device), img_index=img_index.to(device),
         pos3=torch.cat(pos, dim=1).to(I32).contiguous().to(device), sample=sample.to(device), slot=slot.to(device),
         cu=torch.tensor(cu, dtype=I32, device=device), last_idx=torch.tensor([c - 1 for c in cu[1:]], dtype=I32, device=device),
-        next_pos=nxt, rope_deltas=torch.tensor([[n - L] for n in nxt], dtype=torch.int64), vrt_off=off)
+        next_pos=nxt, rope_deltas=torch.tensor([[n - L] for n in nxt], dtype=torch.int64), vrt_off=off, first_row=row0)
 
 
 # ------------------------------------------------------------------------------------------------ decode session

@@ -776,15 +776,25 @@ def rope_half_f32_(x, cos, sin, n_heads, head_dim):
     return x
 
 
-def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, out=None):
-    """fp32 varlen attention → split rows (Tq, 2*n_heads*head_dim) bf16."""
+def scatter_rows_f32(src, idx, dst, D=None):
+    """dst[idx[i]] = src[i] for fp32 rows (distinct int32 indices)."""
+    assert src.dtype == F32 and dst.dtype == F32 and idx.dtype == torch.int32 and src.stride(-1) == 1 and dst.stride(-1) == 1
+    D = src.shape[1] if D is None else D
+    _lib.check(_lib.load().padt_scatter_rows_f32(_stream(), _p(src), src.stride(0), _p(idx), _p(dst), dst.stride(0), idx.numel(), D), "padt_scatter_rows_f32")
+    return dst
+
+
+def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, out=None, kv_group=1, causal=False, len_k=None):
+    """fp32 varlen attention → split rows (Tq, 2*n_heads*head_dim) bf16.  kv_group: q heads per kv head (GQA); causal: bottom-right aligned
+    mask; len_k (int32 device, per segment): key counts for segments that start at cu_k[s] and are not packed back to back (a KV cache)."""
     assert q.dtype == F32 and k.dtype == F32 and v.dtype == F32 and cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
     Dm = n_heads * head_dim
     if out is None:
         out = torch.empty((q.shape[0], 2 * Dm), device=q.device, dtype=BF16)
     scale = head_dim ** -0.5 if scale is None else scale
     _lib.check(_lib.load().padt_attn_f32(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), Dm,
-                                         _p(cu_q), _p(cu_k), cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, float(scale)),
+                                         _p(cu_q), _p(cu_k), cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, float(scale), int(kv_group),
+                                         1 if causal else 0, _p(len_k)),
                "padt_attn_f32")
     return out
 

@@ -8,15 +8,17 @@ This mode meets it on every float output, at 2x the MFMA work:
     bits — against the weight image [W | W] (``padt_gemm_bf16_ex`` at K' = 2K; checkpoints are bf16, so W itself is exact; NO norm folding:
     the normalised rows are produced explicitly by ``padt_norm_split``), fp32 accumulation, fp32 residual streams, fp32 SwiGLU
     (``padt_swiglu_split``), fp32 LayerNorm of the prototypes (``padt_layernorm_f32``);
-  * ViT attention in fp32 (``padt_attn_f32``, the decoder's varlen kernel: 64-token windows and the four 2116 x 2116 full layers);
-  * LLM attention on the fp16 MFMA kernels as they are (q / k / v and the attention output in fp16, KV cache fp16, decode steps through
-    ``padt_decode_attn_rope``) — what tests/studies/reference_mode_floor.py shows to be affordable: with ONLY the LLM's attention internals
-    at fp16 the full-depth oracle sits at boxes 7e-6 / mask logits 3.4e-4 (profiles/r05_reference_mode_floor.md); the logit head stays the
-    fp16 ``padt_vrt_head`` (it selects tokens; no float output depends on it);
+  * ALL attention in fp32 (``padt_attn_f32``, the decoder's varlen kernel): the ViT's 64-token windows and 2116 x 2116 full layers, the LLM's
+    causal GQA prompt pass (kv_group / causal arguments, round 5) and its decode steps over an fp32 [K | V] cache per layer (one row per cached
+    token, samples at a fixed stride; ``len_k`` = the valid keys; the step's new rows land by ``padt_scatter_rows_f32``); rotary in fp32
+    (``padt_rope_half_f32`` on tables from ``padt_rope_table``).  (The first version of this mode kept the LLM's attention on the fp16 MFMA kernels —
+    tests/studies/reference_mode_floor.py: 3.4e-4 on the 3B's mask logits, measured 3.3e-4 — which left PaDT_Pro_7B at 9.8e-4, inside 1e-3 with 2 % to
+    spare; with fp32 attention nothing of the LLM is rounded below 16 mantissa bits.)  The logit head stays the fp16 ``padt_vrt_head`` (it selects
+    tokens; no float output depends on it);
   * token / image / prototype embeddings are gathered from ONE fp32 table [E ‖ prototypes ‖ image rows] (no 16-bit rounding on the way in),
     the per-step hidden rows are kept in fp32 for ``parseVRTintoCompletion`` → ``vl_decode``.
 
-Decode steps run eagerly (11 launches per layer); this is a precision mode, not the throughput path: bench.py prints its rate next to the
+Decode steps run eagerly (10 launches per layer); this is a precision mode, not the throughput path: bench.py prints its rate next to the
 headline (``reference_precision``).  Everything below is kernel sequencing — no arithmetic in PyTorch.
 """
 from typing import Dict
@@ -164,14 +166,32 @@ class ReferencePath:
             ops.check_finite(dst, nf)
         return dst
 
+    # ------------------------------------------------------------------ fp32 KV cache + rotary tables of a session
+    def _kv(self, sess):
+        """Per layer one fp32 tensor (B * S_max, 2 * Hkv * hd): row b * S_max + s = [K | V] of sample b's token s."""
+        cfg = self.cfg
+        if getattr(sess, "kv32", None) is None:
+            w = 2 * cfg.num_key_value_heads * cfg.head_dim
+            sess.kv32 = [torch.zeros((sess.B * sess.s_max, w), device=self.device, dtype=F32) for _ in range(cfg.num_hidden_layers)]
+            sess.cu_q1 = torch.arange(sess.B + 1, dtype=torch.int32, device=self.device)
+            sess.cu_k32 = (torch.arange(sess.B + 1, dtype=torch.int32, device=self.device) * sess.s_max).contiguous()
+            sess.row_base = sess.cu_k32[: sess.B].contiguous()
+        return sess.kv32
+
+    def _rope_tables(self, pos3, sess):
+        """mRoPE cos / sin [tokens][hd / 2] in fp32 for padt_rope_half_f32 (HF:557-599), from the decode path's own table kernel."""
+        cfg = self.cfg
+        cs = torch.empty((pos3.shape[1], cfg.head_dim // 2, 2), device=self.device, dtype=F32)
+        ops.rope_table(pos3, sess.inv_freq, cs, cfg.head_dim, cfg.mrope_section)
+        return cs[..., 0].contiguous(), cs[..., 1].contiguous()          # planar copies (no arithmetic)
+
     # ------------------------------------------------------------------ one LLM layer on fp32 rows x32 (in place)
     def _layer(self, i, x32, attention):
         cfg, R = self.cfg, self.R
         d = f"llm.{i}."
         n, _ = ops.norm_split(x32, R[d + "in_norm"], eps=cfg.rms_norm_eps)
         qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"])
-        att16 = attention(ops.cast_f32_x16(qkv, dtype=F16))                    # fp16 MFMA attention (rope + KV append inside)
-        a, _ = ops.norm_split(ops.cast_x16_f32(att16))
+        a = attention(qkv)                                                     # fp32 rotary + fp32 attention → (hi, lo) rows
         ops.gemm_hp(a, R[d + "o.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
         n, _ = ops.norm_split(x32, R[d + "post_norm"], eps=cfg.rms_norm_eps)
         gu = ops.gemm_hp(n, R[d + "gu.hp"])
@@ -179,11 +199,9 @@ class ReferencePath:
         ops.gemm_hp(h, R[d + "down.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
 
     def prefill(self, plan, low32, sess, nf=None):
-        """Packed prompt pass; fills the session's fp16 KV caches; → post-norm hidden rows of all prompt tokens, fp32 (T, D)."""
+        """Packed prompt pass; fills the session's fp32 KV cache; → post-norm hidden rows of all prompt tokens, fp32 (T, D)."""
         cfg = self.cfg
         Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
-        T = plan.ids.numel()
-        dev = self.device
         n_img = low32.shape[0]
         tab = self.table(sess)
         img0 = cfg.vocab_size + sess.np_max
@@ -193,16 +211,23 @@ class ReferencePath:
                          err_flag=sess.err)                                   # the table-range assert of padt.py:203 (its rows are not used)
         idx = torch.where(plan.img_index >= 0, plan.img_index + img0, plan.ids.to(torch.int32)).to(torch.int32).contiguous()
         x32 = ops.gather_rows(tab, idx, D=cfg.hidden_size)
-        q = torch.empty((T, Hq * hd), device=dev, dtype=F16)
-        kp = torch.empty((T, Hkv * hd), device=dev, dtype=F16)
-        att = torch.empty((T, Hq * hd), device=dev, dtype=F16)
+        kvc = self._kv(sess)
+        cos, sin = self._rope_tables(plan.pos3, sess)
         mx = max(plan.lens)
+        S, B = sess.s_max, plan.B
+        # prompt K | V rows → the cache: cache row (row0 + b) * S + s  <-  packed row cu[b] + min(s, len_b - 1)  (rows past len_b are never read)
+        cu = [0]
+        for l in plan.lens:
+            cu.append(cu[-1] + l)
+        src = torch.cat([torch.clamp(torch.arange(S), max=l - 1) + c for l, c in zip(plan.lens, cu[:-1])]).to(torch.int32).to(self.device)
+        first_row = plan.first_row
         for i in range(cfg.num_hidden_layers):
-            def attention(qkv16, i=i):
-                ops.llm_qkv_post(qkv16, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max, cfg.mrope_section,
-                                 sample=plan.sample, slot=plan.slot, k_pack=kp)
-                ops.attn_varlen(q, kp, qkv16[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
-                return att
+            def attention(qkv, i=i):
+                ops.rope_half_f32_(qkv, cos, sin, Hq + Hkv, hd)                # q and k heads are adjacent in the fused row
+                kv = qkv[:, Hq * hd:]
+                ops.gather_rows(kv, src, out=kvc[i][first_row * S: (first_row + B) * S], D=2 * Hkv * hd)
+                return ops.attn_f32(qkv[:, : Hq * hd], kv[:, : Hkv * hd], kv[:, Hkv * hd:], plan.cu, plan.cu, mx, mx, Hq, hd,
+                                    kv_group=Hq // Hkv, causal=True)
             self._layer(i, x32, attention)
         hn, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
         if nf is not None:
@@ -210,19 +235,22 @@ class ReferencePath:
         return hn
 
     def step(self, sess):
-        """One decode step for every row of the session (eager; the default path's step_kernels with split-precision projections)."""
+        """One decode step for every row of the session (eager; the default path's step_kernels with split-precision projections and fp32 attention)."""
         cfg = self.cfg
         Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         B = sess.B
         ops.embed_tokens(sess.cur_tok, None, self.m.W["llm.embed"], sess.proto, None, out=sess.x_rm, err_flag=sess.err)   # range assert only
         tab = self.table(sess)
         x32 = ops.gather_rows(tab, sess.cur_tok.to(torch.int32), D=cfg.hidden_size)
-        ops.rope_table(sess.pos3, sess.inv_freq, sess.rope_cs, hd, cfg.mrope_section)
-        att = torch.empty((B, Hq * hd), device=self.device, dtype=F16)
+        kvc = self._kv(sess)
+        cos, sin = self._rope_tables(sess.pos3, sess)
+        where = (sess.row_base + sess.slot).contiguous()                       # cache row of each sample's new token (index arithmetic only)
         for i in range(cfg.num_hidden_layers):
-            def attention(qkv16, i=i):
-                ops.decode_attn_rope(qkv16, sess.rope_cs, sess.slot, sess.kc[i], sess.vtc[i], att, sess.attn_ws, Hq, Hkv, hd, sess.s_max, sess.s_max)
-                return att
+            def attention(qkv, i=i):
+                ops.rope_half_f32_(qkv, cos, sin, Hq + Hkv, hd)
+                ops.scatter_rows_f32(qkv[:, Hq * hd:], where, kvc[i], D=2 * Hkv * hd)
+                return ops.attn_f32(qkv[:, : Hq * hd], kvc[i][:, : Hkv * hd], kvc[i][:, Hkv * hd:], sess.cu_q1, sess.cu_k32, 1, sess.s_max, Hq, hd,
+                                    kv_group=Hq // Hkv, len_k=sess.lens)
             self._layer(i, x32, attention)
         hn32, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
         ops.cast_f32_x16(hn32, out=sess.hn)

@@ -136,6 +136,61 @@ def test_attn_f32(ops, D, H, lq, lk):
     split_close(got[rows], ref[rows], f"attn_f32 {lq}x{lk}")
 
 
+@pytest.mark.parametrize("D,Hq,Hkv,lq,lk", [
+    (128, 16, 2, [577, 570, 33], [577, 570, 33]),    # the prompt pass: causal GQA self-attention, thread-per-row kernel (two key-chunk regimes)
+    (128, 4, 2, [40, 7, 64], [40, 7, 64]),           # short prompts: the few-queries kernel with the causal mask
+    (128, 28, 4, [5, 3], [300, 9]),                  # more keys than queries: bottom-right alignment (a query block appended to a cache)
+    (80, 4, 1, [100], [100]),
+])
+def test_attn_f32_causal_gqa(ops, D, Hq, Hkv, lq, lk):
+    """Round 5 (the reference-precision LLM, HF:641-689): kv_group + causal against the fp64 statement — key j visible to query i iff j <= i + nk - nq."""
+    cq, ck = [0], [0]
+    for a, b in zip(lq, lk):
+        cq.append(cq[-1] + a)
+        ck.append(ck[-1] + b)
+    g = Hq // Hkv
+    qkv = rndf(max(cq[-1], ck[-1]), (Hq + 2 * Hkv) * D, seed=41)   # one fused row buffer: q | k | v column slices (strided views)
+    q, k, v = qkv[: cq[-1], : Hq * D], qkv[: ck[-1], Hq * D: (Hq + Hkv) * D], qkv[: ck[-1], (Hq + Hkv) * D:]
+    out = ops.attn_f32(q, k, v, torch.tensor(cq, dtype=torch.int32, device="cuda"), torch.tensor(ck, dtype=torch.int32, device="cuda"),
+                       max(lq), max(lk), Hq, D, kv_group=g, causal=True)
+    ref = torch.zeros(cq[-1], Hq * D, dtype=torch.float64, device="cuda")
+    for i in range(len(lq)):
+        qs = q[cq[i]:cq[i + 1]].double().view(-1, Hq, D)
+        ks = k[ck[i]:ck[i + 1]].double().view(-1, Hkv, D).repeat_interleave(g, 1)
+        vs = v[ck[i]:ck[i + 1]].double().view(-1, Hkv, D).repeat_interleave(g, 1)
+        sc = torch.einsum("qhd,khd->hqk", qs, ks) * D ** -0.5
+        vis = torch.arange(lk[i], device="cuda")[None, :] <= torch.arange(lq[i], device="cuda")[:, None] + (lk[i] - lq[i])
+        sc = sc.masked_fill(~vis[None], float("-inf"))
+        ref[cq[i]:cq[i + 1]] = torch.einsum("hqk,khd->qhd", sc.softmax(-1), vs).reshape(-1, Hq * D)
+    split_close(join(out, Hq * D), ref, f"attn_f32 causal GQA {lq}x{lk}")
+
+
+def test_attn_f32_over_a_strided_kv_cache_and_scatter_rows(ops):
+    """The decode step of the reference-precision LLM: one query row per sample against an fp32 [K | V] cache whose samples sit S_max rows apart
+    (len_k = valid keys), after the new row was scattered into its slot (padt_scatter_rows_f32)."""
+    B, S, Hq, Hkv, D = 5, 96, 16, 2, 128
+    lens = [37, 96, 1, 64, 80]
+    cache = rndf(B * S, 2 * Hkv * D, seed=51)
+    new = rndf(B, (Hq + 2 * Hkv) * D, seed=52)
+    where = torch.tensor([b * S + lens[b] - 1 for b in range(B)], dtype=torch.int32, device="cuda")
+    expect = cache.clone()
+    expect[where.long()] = new[:, Hq * D:]
+    ops.scatter_rows_f32(new[:, Hq * D:], where, cache, D=2 * Hkv * D)
+    assert torch.equal(cache, expect)
+    cu_q = torch.arange(B + 1, dtype=torch.int32, device="cuda")
+    cu_k = (torch.arange(B + 1, dtype=torch.int32, device="cuda") * S).contiguous()
+    len_k = torch.tensor(lens, dtype=torch.int32, device="cuda")
+    out = ops.attn_f32(new[:, : Hq * D], cache[:, : Hkv * D], cache[:, Hkv * D:], cu_q, cu_k, 1, S, Hq, D, kv_group=Hq // Hkv, len_k=len_k)
+    ref = torch.zeros(B, Hq * D, dtype=torch.float64, device="cuda")
+    for b in range(B):
+        qs = new[b: b + 1, : Hq * D].double().view(1, Hq, D)
+        ks = cache[b * S: b * S + lens[b], : Hkv * D].double().view(-1, Hkv, D).repeat_interleave(Hq // Hkv, 1)
+        vs = cache[b * S: b * S + lens[b], Hkv * D:].double().view(-1, Hkv, D).repeat_interleave(Hq // Hkv, 1)
+        sc = torch.einsum("qhd,khd->hqk", qs, ks) * D ** -0.5
+        ref[b] = torch.einsum("hqk,khd->qhd", sc.softmax(-1), vs).reshape(-1)
+    split_close(join(out, Hq * D), ref, "attn_f32 over a strided cache")
+
+
 def test_rope_half_f32_and_mask_scatter_f32(ops):
     T, H, D = 77, 16, 80
     x = rndf(T, 2 * H * D, seed=30)

@@ -1,5 +1,5 @@
 """``precision="reference"`` (padt_amd/reference.py): ViT / LLM on the split-precision machinery of the PaDT decoder — fp32 streams, (hi, lo)
-bf16 GEMM operands, fp32 ViT attention, fp16 MFMA attention in the LLM only.  The north star's letter: VRT token ids EQUAL to the fp32
+bf16 GEMM operands, fp32 attention everywhere (ViT windows / full layers, the LLM's causal GQA prompt pass, its decode steps over an fp32 KV cache).  The north star's letter: VRT token ids EQUAL to the fp32
 reference's, box coordinates AND mask logits within 1e-3 — asserted here at the full PaDT_Pro_3B depth, where the default (fp16-operand) path
 sits at 3.7e-3 on the mask logits (its operand type's floor, tests/test_real_shape_gpu.py)."""
 import os
@@ -54,7 +54,7 @@ def test_reference_precision_small_config_end_to_end():
     assert hid.dtype == torch.float32 and out.past_image_embeds.dtype == torch.float32
     worst = max(rel(hid[t], ores["hidden"][t][:, -1])[1] for t in range(T))
     print(f"[reference precision, small e2e] prototypes rel max {mxp:.3e} rms {rmsp:.3e}; hidden rows rel rms worst {worst:.3e}")
-    assert rmsp < 2e-5 and worst < 1.2e-3                                         # measured 6.0e-4: the LLM's fp16 attention internals (q, k, v, P, attention output)
+    assert rmsp < 2e-5 and worst < 5e-5                                           # measured 8.2e-6 (6.0e-4 while the LLM's attention still ran on the fp16 MFMA kernels)
     feats = [[hid[3:7, b]] for b in range(2)]
     dec = model.vl_decode(feats, out.past_image_embeds, out.past_high_res_image_embeds, grid, out.past_visual_pe)
     ofeats = [[torch.cat([ores["hidden"][t][b:b + 1, -1] for t in range(3, 7)], 0)] for b in range(2)]
@@ -63,7 +63,7 @@ def test_reference_precision_small_config_end_to_end():
     ds = (dec["pred_score"].cpu().float() - odec["pred_score"]).abs().max().item()
     mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
     print(f"[reference precision, small e2e] box |d|max {db:.3e} score |d| {ds:.3e} mask logits rel max {mx:.3e} rms {rms:.3e}")
-    assert db < 1e-4 and mx < 1e-3 and rms < 1e-3
+    assert db < 1e-5 and mx < 1e-4 and rms < 1e-4                                 # measured 1.8e-7 / 1.3e-5 / 1.2e-5
     # the runner (two batches in one decode session) on the same model: per-sample results bit-identical to batch-at-a-time
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 30), 2)
     proc.model_embed_token_size = cfg.vocab_size
@@ -133,7 +133,7 @@ def test_reference_precision_full_depth_3b_meets_the_north_star_on_every_float_o
     print(f"\n[reference precision, full 3B] generate {t_hip:.2f} s (first call), oracle {t_or:.1f} s; ViT high_res rel rms {rmsh:.3e} max {mxh:.3e}; prototypes rms {rmsp:.3e}; "
           f"hidden rows rel rms worst {worst:.3e}")
     assert rmsh < 5e-5 and rmsp < 5e-5                                            # default fp16 path: 1.09e-3
-    assert worst < 2.5e-3                                                         # the LLM's fp16 attention internals (oracle floor of that class: 1.1e-3); default: 3-4.7e-3
+    assert worst < 3e-4                                                           # measured 4.1e-5 (1.13e-3 with fp16 attention internals in the LLM; default path: 3-4.7e-3)
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 529), 2)
     proc.model_embed_token_size = cfg.vocab_size
     local = proc.assign_to_local_vrt_id(seq.clone(), grid)[:, 577:]
@@ -145,8 +145,9 @@ def test_reference_precision_full_depth_3b_meets_the_north_star_on_every_float_o
     ds = (dec["pred_score"].cpu().float() - odec["pred_score"]).abs().max().item()
     mx, rms = rel(dec["pred_mask"], odec["pred_mask"])
     print(f"[reference precision, full 3B] end to end: box |d|max {db:.3e}  score |d| {ds:.3e}  mask logits max / range {mx:.3e} rms {rms:.3e}  "
-          f"(default fp16 path on the same inputs: 1.3e-4 / 3.7e-3; oracle floor of 'LLM attention internals at fp16, everything else exact': 7e-6 / 3.4e-4)")
+          f"(default fp16 path on the same inputs: 1.3e-4 / 3.7e-3; this mode with the LLM's attention still on the fp16 MFMA kernels: 2.3e-5 / 3.3e-4)")
     assert db < 1e-3 and mx < 1e-3, f"north star missed: boxes {db:.3e}, mask logits {mx:.3e}"
+    assert db < 2e-5 and mx < 2e-4                                                # sized to what is measured: 1.8e-6 / 2.7e-5
 
 
 def test_reference_precision_batch8_every_sample_within_1e3():
@@ -312,3 +313,4 @@ def test_reference_precision_7b_full_depth_within_1e3():
           f"boxes |d|max {db:.3e}; mask logits max / range {mx:.3e} rms {rms:.3e}  (default path: 3.8e-4 / 4.1e-3)")
     assert n_eq == T
     assert db < 1e-3 and mx < 1e-3
+    assert db < 2e-5 and mx < 3e-4                                                # measured 1.3e-6 / 4.6e-5 (9.8e-4 while the LLM's attention ran on the fp16 MFMA kernels)
