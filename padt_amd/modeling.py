@@ -147,8 +147,8 @@ class PaDTForConditionalGeneration:
         fallback does not have to keep a second copy of the checkpoint alive); default: the dict given here is retained.
         precision: "default" — 16-bit MFMA operands as above (boxes within the north star's 1e-3 of the fp32 reference, mask logits at the
         3.7e-3 floor of the operand type); "reference" — ViT / LLM on the split-precision machinery of the PaDT decoder (fp32 streams,
-        (hi, lo) bf16 GEMM operands at twice the MFMA work, fp32 ViT attention: padt_amd/reference.py): every float output within 1e-3, at
-        roughly a third of the default throughput (bench.py `reference_precision`); needs 16-bit LLM weights."""
+        (hi, lo) bf16 GEMM operands at twice the MFMA work, fp32 attention and an fp32 KV cache: padt_amd/reference.py): every float output within
+        1e-3 (measured 3e-6 on boxes, 5e-5 on mask logits), at a fifth of the default throughput (bench.py `reference_precision`); needs 16-bit LLM weights."""
         if dtype != torch.bfloat16:
             raise ValueError("PaDT checkpoints are bf16: pass torch_dtype=torch.bfloat16 (the MFMA operand type is chosen with operands=)")
         _lib.load()                                            # fail loudly before touching any weight
