@@ -321,3 +321,16 @@ def test_generate_argument_policy_defaults_unknowns_and_max_length():
     m = PaDTForConditionalGeneration.__new__(PaDTForConditionalGeneration)
     with pytest.raises(NotImplementedError, match="synced_gpus"):
         m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), synced_gpus=True)
+
+
+def test_import_sets_hardware_queue_default_but_never_overrides_the_user():
+    """padt_amd/__init__.py: GPU_MAX_HW_QUEUES defaults to 8 (a fifth HIP stream must not share an HSA queue with the prefill stream:
+    profiles/r05_to_rle_hw_queue_stall.log); an explicit setting wins."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = "import os, sys; sys.path.insert(0, %r); import padt_amd; print(os.environ['GPU_MAX_HW_QUEUES'])" % root
+    env = {k: v for k, v in os.environ.items() if k != "GPU_MAX_HW_QUEUES"}
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "8"
+    env["GPU_MAX_HW_QUEUES"] = "2"
+    assert subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env).stdout.strip() == "2"
