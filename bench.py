@@ -17,8 +17,9 @@ launches replayed alone between one event pair), "roofline_decode" (HBM bytes of
 duration), "from_images" (the same pipeline fed from uint8 host images), "cpu_baseline" (the fp32 CPU oracle timed on this host, with the
 parity read-out), "extra_workloads" (BASELINE configs[3] OVD and configs[4] 7B RIC fp8 per-GPU shapes, short runs), "steady_state" (64 steps of the
 same runner), "operands_bf16" (the bf16 instantiation, same steps), "reference_precision" (precision="reference": every float output within 1e-3).
-bench.py (like __graft_entry__.smoke) is a SOURCE-CHECKOUT tool: the synthetic workload (prompts, pixel rows, scripted schedules, tokenizer stand-in)
-lives in tests/synthetic_workload.py and the CPU baseline in oracle/ — test infrastructure, deliberately not shipped inside the padt_amd package.
+The synthetic workload (prompts, pixel rows, scripted schedules, tokenizer stand-in) ships with the package (padt_amd/synthetic.py), so every
+leg except `cpu_baseline` runs from an installed package; the CPU baseline needs the source checkout (oracle/ + tests/parity_util.py are test
+infrastructure, deliberately not shipped): without them that leg reports itself as skipped.
 """
 import argparse
 import json
@@ -37,7 +38,6 @@ import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
-sys.path.insert(1, os.path.join(ROOT, "tests"))             # synthetic_workload.py: prompts / pixel rows / scripted schedules / tokenizer stand-in
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0      # MI355X dense bf16 (guides/MI355X_MICROARCH.md)
 HBM_PEAK_GBS = 8000.0
@@ -127,7 +127,7 @@ def build_model(args, device):
 
 def workload(args):
     """→ (n_post text tokens after the image, T_new, objects per image, VRTs per object, schedule)."""
-    from synthetic_workload import multi_object_schedule, rec_schedule
+    from padt_amd.synthetic import multi_object_schedule, rec_schedule
     if args.task == "ovd":
         T = args.tnew if args.tnew != 28 else 120
         return 346, T, 7, 5, multi_object_schedule(T, n_obj=7, n_vrt=5)
@@ -144,7 +144,7 @@ N_ROT = 4          # distinct input batches every timed loop cycles through
 
 
 def make_inputs(cfg, args, grid_hw, device, seed, dtype=torch.float16):
-    from synthetic_workload import FakeProcessor, synthetic_batch
+    from padt_amd.synthetic import FakeProcessor, synthetic_batch
     import padt_amd
     n_post, T, n_obj, n_vrt, sched = workload(args)
     args.tnew = T
@@ -679,7 +679,12 @@ def main():
         # driver's runs use the default: nccl = RCCL over xGMI, one GPU per rank
         backend = os.environ.get("PADT_DIST_BACKEND", "nccl")
         local = local % torch.cuda.device_count()
-        torch.cuda.set_device(local)
+        torch.cuda.set_device(local)                                   # one GPU per rank: every allocation / stream / graph below lives on cuda:<LOCAL_RANK>
+        # ... and the host cores of that GPU's NUMA node (8 ranks x an enqueue thread of ~7 ms per batch + the parser): real multi-GPU runs only
+        # (PADT_PIN=0 / 1 overrides); ranks that share one GPU under gloo keep the whole machine
+        pin = os.environ.get("PADT_PIN", "1" if (world > 1 and backend == "nccl") else "0") == "1"
+        from padt_amd.pipeline import pin_rank_to_local_cores
+        affinity = pin_rank_to_local_cores(local, int(os.environ.get("LOCAL_WORLD_SIZE", world))) if pin else {"skipped": "not a multi-GPU RCCL run"}
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"), rank=rank, world_size=world)
         else:
@@ -852,8 +857,11 @@ def main():
         }
         if exchange is not None:
             line["exchange"] = {"all_gathers": exchange.n_gathers, "batches_per_gather": args.merge, "bytes_per_rank_per_gather": exchange.words * 4 * args.merge,
-                                "continuation_gathers": exchange.n_continuation_gathers, "backend": os.environ.get("PADT_DIST_BACKEND", "nccl"),
-                                "world_size": world, "ranks_seen_by_the_last_gather": int(gathered[-1].world) if gathered else None,
+                                "continuation_gathers": exchange.n_continuation_gathers,
+                                "gather_wait_ms": {"total": round(exchange.wait_ms_total, 3), "max": round(exchange.wait_ms_max, 3),
+                                                   "note": "host time this rank spent waiting for gathers to complete (ResultExchange._wait): what the slowest rank costs the others"},
+                                "backend": os.environ.get("PADT_DIST_BACKEND", "nccl"),
+                                "world_size": world, "device": device, "host_affinity": affinity, "ranks_seen_by_the_last_gather": int(gathered[-1].world) if gathered else None,
                                 "rccl_version": (".".join(str(v) for v in torch.cuda.nccl.version()) if os.environ.get("PADT_DIST_BACKEND", "nccl") == "nccl" else None),
                                 "note": "device-side pack (one kernel per batch) + one asynchronous all_gather_into_tensor per decode group"}
         line["range_guard"] = {"operands_policy": getattr(args, "policy", args.operands), "batches_rerun_on_bf16": int(getattr(model, "overflow_reruns", 0)),

@@ -391,7 +391,11 @@ class PaDTForConditionalGeneration:
                 return None
         rows = slice(row0, row0 + B)
         sess.nf[rows].zero_()
-        nf = torch.zeros(1, dtype=torch.int32, device=dev)       # this batch's range guard: ViT rows, prototypes, prompt-pass hidden rows
+        # this batch's range guard (ViT rows, prototypes, prompt-pass hidden rows).  Its zero fill must be ordered before EVERY check that ORs
+        # into it: with a ViT stream the flag is allocated and zeroed ON that stream (the fill on the current stream would sit behind the
+        # previous batch's prefill while the ViT checks of this batch already run — ADVICE r05); the prefill's check comes after
+        # cur.wait_stream(vit_stream) below
+        nf = None if (vit_stream is not None and self.ref is None) else torch.zeros(1, dtype=torch.int32, device=dev)
 
         # ---- ViT → prototypes → session table
         if self.ref is not None:
@@ -410,10 +414,11 @@ class PaDTForConditionalGeneration:
             if k == 0 or inputs_ready is None:
                 vit_stream.wait_stream(cur)
             with torch.cuda.stream(vit_stream):
+                nf = torch.zeros(1, dtype=torch.int32, device=dev)
                 low, high, pe = self.visual(pixel_values.to(dev), grid, nf=nf)
                 proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto], nf=nf)
             cur.wait_stream(vit_stream)                           # the prefill below reads low / the prototype rows
-            for t_ in (low, high, pe[0], pe[1]):                   # allocated on vit_stream, read on the prefill / decode streams
+            for t_ in (low, high, pe[0], pe[1], nf):               # allocated on vit_stream, read on the prefill / decode streams
                 t_.record_stream(cur)
                 if decode_stream is not None:
                     t_.record_stream(decode_stream)

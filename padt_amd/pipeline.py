@@ -256,6 +256,68 @@ def rank_batches(n_items: int, batch_size: int, rank: int, world: int):
     return list(range(rank * batch_size, all_number, world * batch_size))
 
 
+def _cpulist(text: str) -> List[int]:
+    """'0-3,8,10-11' → [0, 1, 2, 3, 8, 10, 11] (the format of /sys/devices/system/node/node*/cpulist)."""
+    out = []
+    for part in text.strip().split(","):
+        if not part:
+            continue
+        a, _, b = part.partition("-")
+        out += list(range(int(a), int(b or a) + 1))
+    return out
+
+
+def plan_rank_affinity(local_rank: int, local_world: int, gpu_numa: List[int], node_cpus: dict, allowed: List[int]) -> List[int]:
+    """Host cores for one rank of a one-process-per-GPU job (the reference launches its eval the same way, eval_coco.sh:5 / utils.py:181-182):
+    the cores of the NUMA node its GPU hangs off, divided evenly among the ranks whose GPUs share that node; without topology information an
+    even slice of the allowed cores.  Pure function of its arguments (tested on CPU); every rank gets a disjoint, non-empty set when
+    len(allowed) >= local_world."""
+    allowed = sorted(allowed)
+    node = gpu_numa[local_rank] if local_rank < len(gpu_numa) else -1
+    cpus = [c for c in node_cpus.get(node, []) if c in set(allowed)] if node >= 0 else []
+    if cpus:
+        peers = [r for r in range(local_world) if r < len(gpu_numa) and gpu_numa[r] == node]
+        i, n = peers.index(local_rank), len(peers)
+    else:
+        cpus, i, n = allowed, local_rank, local_world
+    per = max(1, len(cpus) // n)
+    mine = cpus[i * per: (i + 1) * per] if i < n - 1 else cpus[i * per:]
+    return mine or cpus[i % len(cpus): i % len(cpus) + 1]
+
+
+def pin_rank_to_local_cores(local_rank: int, local_world: int) -> dict:
+    """sched_setaffinity of this process to plan_rank_affinity()'s cores, read from sysfs (GPU PCI address → numa_node → cpulist); best effort:
+    returns what was done ({'cpus': n, 'numa_node': k, 'first': c} or {'skipped': reason}).  Each rank runs a host enqueue thread of ≈7 ms per
+    batch plus the parser; 8 ranks bouncing between sockets cost the decode groups their launch cadence."""
+    import os
+    try:
+        allowed = sorted(os.sched_getaffinity(0))
+        numa = []
+        for r in range(local_world):
+            node = -1
+            try:
+                p = torch.cuda.get_device_properties(r)
+                bdf = "%04x:%02x:%02x.0" % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+                node = int(open(f"/sys/bus/pci/devices/{bdf}/numa_node").read())
+            except Exception:                                          # noqa: BLE001 — no sysfs entry / fewer devices than ranks
+                pass
+            numa.append(node)
+        nodes = {}
+        base = "/sys/devices/system/node"
+        if os.path.isdir(base):
+            for d in os.listdir(base):
+                if d.startswith("node") and d[4:].isdigit():
+                    try:
+                        nodes[int(d[4:])] = _cpulist(open(os.path.join(base, d, "cpulist")).read())
+                    except OSError:
+                        pass
+        mine = plan_rank_affinity(local_rank, local_world, numa, nodes, allowed)
+        os.sched_setaffinity(0, mine)
+        return {"cpus": len(mine), "numa_node": numa[local_rank] if local_rank < len(numa) else -1, "first": mine[0]}
+    except Exception as e:                                             # noqa: BLE001
+        return {"skipped": f"{type(e).__name__}: {e}"[:120]}
+
+
 def _split_decoded(decoded: dict, cap: int) -> List[dict]:
     """A vl_decode output with more than `cap` objects → consecutive chunks of at most `cap` objects each (views, no copies)."""
     n = decoded["pred_boxes"].shape[0]
@@ -342,6 +404,7 @@ class ResultExchange:
         self._cont = []                                                # continuation records of the gather being filled
         self.n_gathers = 0
         self.n_continuation_gathers = 0
+        self.wait_ms_total, self.wait_ms_max = 0.0, 0.0                # host time spent waiting for a gather to complete (_wait): what a straggler costs
         self._cuda = torch.device(device).type == "cuda"
         if self._cuda:
             self._side = torch.cuda.Stream(device=device)
@@ -364,8 +427,10 @@ class ResultExchange:
         if self._inflight is None:
             return []
         import torch.distributed as dist
+        import time
         work, out, cont, ev, counts = self._inflight
         self._inflight = None
+        t0 = time.perf_counter()
         if ev is not None:
             ev.synchronize()                                           # the gather and the copy of the announced counts behind it are done
             torch.cuda.current_stream().wait_event(ev)                 # ... and the caller's stream may read the gathered records
@@ -373,6 +438,9 @@ class ResultExchange:
         else:
             work.wait()
             k = int(out[:, -1].max().item())                           # every rank computes the same k from the same gathered words
+        dt = (time.perf_counter() - t0) * 1e3
+        self.wait_ms_total += dt
+        self.wait_ms_max = max(self.wait_ms_max, dt)
         more = None
         if k:
             mine = torch.zeros((k, self.words), dtype=torch.int32, device=self.device)

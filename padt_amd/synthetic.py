@@ -1,4 +1,5 @@
-"""Test / bench support (NOT part of the product package).  Synthetic inputs for a model with random-init weights (no datasets / checkpoints offline): prompts of
+"""Benchmark / self-test support shipped WITH the package (round 6: bench.py and smoke() no longer import from tests/, so an installed
+package can be benchmarked).  Nothing on the product path imports this module.  Synthetic inputs for a model with random-init weights (no datasets / checkpoints offline): prompts of
 the reference's shape, N(0,1) pixel rows, a scripted completion schedule (random weights never emit EOS), and a minimal
 tokenizer stand-in so ``parseVRTintoCompletion`` can run on generated ids."""
 import torch

@@ -38,7 +38,7 @@ def bf16_weights(cfg: PaDTConfig, seed=0, std=0.02, bias_std=0.02, norm_jitter=0
     return {k: v.to(torch.bfloat16).float() for k, v in sd.items()}
 
 
-from synthetic_workload import FakeProcessor, FakeTokenizer, rec_schedule, synthetic_batch  # noqa: E402,F401
+from padt_amd.synthetic import FakeProcessor, FakeTokenizer, rec_schedule, synthetic_batch  # noqa: E402,F401
 
 
 def effective_llm_weights(model, w):

@@ -12,7 +12,7 @@ import torch
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 import parity_util as U  # noqa: E402
-from synthetic_workload import multi_object_schedule  # noqa: E402
+from padt_amd.synthetic import multi_object_schedule  # noqa: E402
 
 O = U.O
 

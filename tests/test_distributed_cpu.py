@@ -179,3 +179,101 @@ def test_result_exchange_over_capacity_batch_is_split_not_raised():
             assert boxes.shape == (n, 4) and (boxes == ref["pred_boxes"].numpy()).all() and sidx == ref["sample_idx"]
             if n:
                 assert (masks[:, :24, :32] == ref["pred_mask"].numpy()).all()
+
+
+# ---------------------------------------------------------------------------------------------- configs[3]: 64 images per step over 8 ranks
+_OVD_ITEMS, _OVD_BS, _OVD_CAP = 150, 8, 16                       # 150 images: 3 steps of 8 ranks x 8 images, the last one ragged (items 128..149 + 42 skips)
+
+
+def _ovd_objects(item):
+    """Deterministic per-image object list of the OVD stand-in: 3..11 objects (≈7 on average) → 24..88 per batch of 8 > cap 16."""
+    g = torch.Generator().manual_seed(9000 + item)
+    n = 3 + item % 9
+    return torch.rand(n, 4, generator=g), torch.randn(n, 1, generator=g), torch.randn(n, 6, 6, generator=g)
+
+
+def _ovd_decoded(start):
+    """vl_decode stand-in for the batch of items start .. start+7 (items past the end of the dataset are skipped: utils.py:183-186)."""
+    boxes, scores, masks, sidx = [], [], [], []
+    for j in range(_OVD_BS):
+        if start + j >= _OVD_ITEMS:
+            continue
+        b, s, m = _ovd_objects(start + j)
+        boxes.append(b), scores.append(s), masks.append(m), sidx.extend([j] * b.shape[0])
+    if not boxes:
+        return {"pred_boxes": torch.zeros(0, 4), "pred_score": torch.zeros(0, 1), "pred_mask": torch.zeros(0, 8, 8), "sample_idx": [], "pred_mask_valid_hw": ()}
+    n = len(sidx)
+    return {"pred_boxes": torch.cat(boxes), "pred_score": torch.cat(scores), "pred_mask": torch.cat(masks), "sample_idx": sidx,
+            "pred_mask_valid_hw": (torch.full((n,), 6), torch.full((n,), 6))}
+
+
+def _worker_ovd(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    torch.set_num_threads(1)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    starts = pipeline.rank_batches(_OVD_ITEMS, _OVD_BS, rank, world)
+    ex = pipeline.ResultExchange(cap=_OVD_CAP, mask_hw=8, per_gather=2, device="cpu")
+    done = []
+    for st in starts:
+        done += [t.clone() for t in ex.add(_ovd_decoded(st))]
+    done += [t.clone() for t in ex.flush()]
+    # every rank re-assembles EVERY rank's batches from what the gathers delivered: item id → (boxes, scores, masks)
+    seen = {}
+    for g, t in enumerate(done):
+        for src in range(world):
+            src_starts = pipeline.rank_batches(_OVD_ITEMS, _OVD_BS, src, world)
+            for slot in range(t.per):
+                b = g * ex.per + slot
+                if b >= len(src_starts):
+                    continue
+                rec = t.batch_record(src, slot)
+                for j in sorted(set(rec["sample_idx"].tolist())):
+                    sel = rec["sample_idx"] == j
+                    item = src_starts[b] + j
+                    assert item not in seen, ("delivered twice", item)
+                    seen[item] = (rec["boxes"][sel].numpy().copy(), rec["scores"][sel].numpy().copy(), rec["masks"][sel][:, :6, :6].numpy().copy())
+    q.put((rank, len(starts), ex.n_gathers, ex.n_continuation_gathers, seen))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_ovd_step_of_64_images_is_delivered_exactly_once_across_8_ranks():
+    """BASELINE configs[3] (OVD, batch 64 = 8 ranks x 8 images) through the reference's rank-strided walk (utils.py:181-182) and the exchange:
+    every rank ends up with every image of a 150-image dataset exactly once, objects bit for bit, although every batch exceeds the record
+    capacity (24..88 objects at cap 16 → continuation records) and the last step is ragged (some ranks only skip)."""
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ovd, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    got = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    covered = sorted(s + j for r in range(world) for s in pipeline.rank_batches(_OVD_ITEMS, _OVD_BS, r, world) for j in range(_OVD_BS))
+    assert covered == list(range(192))                           # 3 steps x 64: every item index once, 150..191 are the "skip" slots
+    for rank, n_b, n_g, n_cont, seen in got:
+        assert n_b == 3 and n_g == 2 and n_cont == 2
+        assert sorted(seen) == list(range(_OVD_ITEMS)), (rank, len(seen))
+        for item, (bx, sc, mk) in seen.items():
+            b, s, m = _ovd_objects(item)
+            assert (bx == b.numpy()).all() and (sc == s.reshape(-1).numpy()).all() and (mk == m.numpy()).all()
+
+
+def test_rank_affinity_plan_gives_disjoint_numa_local_core_sets():
+    """pipeline.plan_rank_affinity: 8 ranks, GPUs 0-3 on NUMA node 0 and 4-7 on node 1 (the MI355X box's layout class) → every rank gets a
+    disjoint quarter of its GPU's node; without topology an even slice; never an empty set."""
+    nodes = {0: list(range(0, 64)) + list(range(128, 192)), 1: list(range(64, 128)) + list(range(192, 256))}
+    allowed = list(range(256))
+    numa = [0, 0, 0, 0, 1, 1, 1, 1]
+    sets = [pipeline.plan_rank_affinity(r, 8, numa, nodes, allowed) for r in range(8)]
+    assert all(len(s) == 32 for s in sets) and len(set().union(*map(set, sets))) == 256
+    for r, s in enumerate(sets):
+        assert set(s) <= set(nodes[numa[r]])
+    flat = [pipeline.plan_rank_affinity(r, 8, [-1] * 8, {}, list(range(20))) for r in range(8)]
+    assert sorted(c for s in flat for c in s) == list(range(20)) and all(flat)
+    tiny = [pipeline.plan_rank_affinity(r, 8, [-1] * 8, {}, [3, 5]) for r in range(8)]
+    assert all(len(s) >= 1 and set(s) <= {3, 5} for s in tiny)
+    assert pipeline._cpulist("0-3,8,10-11\n") == [0, 1, 2, 3, 8, 10, 11]

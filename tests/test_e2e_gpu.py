@@ -615,7 +615,7 @@ def test_ovd_shaped_completion_through_the_runner(setup):
     cfg, w, model, U, oc = setup
     import padt_amd
     from padt_amd import pipeline
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     O = U.O
     grids = [[1, 10, 12], [1, 8, 8]]
     T = 48

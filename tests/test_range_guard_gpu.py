@@ -172,6 +172,57 @@ def test_range_guard_is_per_batch_inside_a_merged_decode_group():
         assert torch.isfinite(d1["pred_boxes"]).all()
 
 
+def test_range_guard_with_a_vit_stream_flags_a_vit_overflow_in_the_second_batch_of_a_group():
+    """with PipelinedRunner(vit_stream=True) the ViT / prototype checks of batch k > 0 run on the ViT stream, which does not wait for
+    the prefill stream — the batch's flag must be zeroed on the stream that ORs into it first.  Batch B (k = 1 of a 2-batch decode group) carries
+    a pixel column that the edited patch embedding drives past 65504 (fp16 inf in the ViT stream rows); batch A does not: B is re-run on the
+    bf16 twin, A keeps its fp16 result bit for bit."""
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import padt_amd
+    import parity_util as U
+    from padt_amd import pipeline
+    from padt_amd.modeling import PaDTForConditionalGeneration
+    cfg = padt_amd.small_test_config()
+    w = U.bf16_weights(cfg, seed=23, std=0.05)
+    COL = 11
+    w["visual.patch_embed.proj.weight"] = w["visual.patch_embed.proj.weight"].clone()
+    w["visual.patch_embed.proj.weight"].view(cfg.vision_config.hidden_size, -1)[7, COL] = 8192.0
+    T = 8
+    sched = U.rec_schedule(T, vrt_at=range(2, 5))
+    proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)
+    proc.model_embed_token_size = cfg.vocab_size
+    batches = []
+    for s in range(2):
+        grid, pix, ids, am = U.synthetic_batch(cfg, [[1, 8, 8], [1, 10, 12]], n_pre=5, n_post=8, seed=310 + s, ragged=True)
+        pix = pix.clone()
+        pix[:, COL] = 16.0 if s == 1 else 0.0                     # 16 * 8192 = 1.3e5 in channel 7 of every patch row of batch B
+        batches.append((ids.cuda(), am.cuda(), pix.cuda(), grid))
+    auto = PaDTForConditionalGeneration(cfg, w, device="cuda", operands="auto")
+    for rep in range(3):                                           # the race needs the prefill stream to be busy: several groups back to back
+        runner = pipeline.PipelinedRunner(auto, proc, depth=2, merge=2, vit_stream=True)
+        before = auto.overflow_reruns
+        got = []
+        with warnings.catch_warnings(record=True) as rec:
+            warnings.simplefilter("always")
+            for b in batches:
+                got += runner.submit(b[0].clone(), b[1], b[2], b[3], max_new_tokens=T, schedule=sched)
+            got += runner.flush()
+        assert len(got) == 2 and auto.overflow_reruns == before + 1, (rep, auto.overflow_reruns)
+        assert any("re-run on the bf16" in str(r.message) for r in rec)
+    bf = PaDTForConditionalGeneration(cfg, w, device="cuda", operands="bf16")
+    ref_b = pipeline.rec_batch(bf, proc, batches[1][0].clone(), *batches[1][1:], max_new_tokens=T, schedule=sched)
+    n0 = auto.overflow_reruns
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        ref_a = pipeline.rec_batch(auto, proc, batches[0][0].clone(), *batches[0][1:], max_new_tokens=T, schedule=sched)
+    assert auto.overflow_reruns == n0
+    for (d0, c0, l0, v0), (d1, c1, l1, v1) in zip((ref_a, ref_b), got):
+        assert c0 == c1 and v0 == v1
+        assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"])
+        assert torch.isfinite(d1["pred_boxes"]).all()
+
+
 def test_auto_stops_paying_twice_when_most_batches_overflow():
     """A checkpoint whose activations exceed fp16 on EVERY batch: after three re-runs (and at least half of the batches seen) an operands="auto"
     model starts new decode groups on its bf16 twin directly — one pass per batch again, results = the bf16 model's, no further warnings."""

@@ -528,7 +528,7 @@ def test_7b_geometry_ric_schedule_against_oracle(llm_weights):
     import padt_amd
     import parity_util as U
     from padt_amd.modeling import PaDTForConditionalGeneration
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     O = U.O
     base = padt_amd.padt_pro_7b()
     cfg = dataclasses.replace(base, num_hidden_layers=2,
@@ -680,7 +680,7 @@ def test_3b_ovd_geometry_merged_runner_against_oracle():
     import parity_util as U
     from padt_amd import pipeline
     from padt_amd.modeling import PaDTForConditionalGeneration
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     from padt_amd.weights import synthetic_state_dict
     O = U.O
     cfg = padt_amd.padt_pro_3b()
@@ -762,7 +762,7 @@ def test_7b_full_depth_single_image_against_oracle(llm_weights):
     import padt_amd
     import parity_util as U
     from padt_amd.modeling import PaDTForConditionalGeneration
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     from padt_amd.weights import synthetic_state_dict
     O = U.O
     cfg = padt_amd.padt_pro_7b()

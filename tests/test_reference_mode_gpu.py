@@ -221,7 +221,7 @@ def test_reference_precision_ovd_geometry_mask_logits_within_1e3():
     import parity_util as U
     from padt_amd.modeling import PaDTForConditionalGeneration
     from padt_amd.weights import synthetic_state_dict
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     O = U.O
     cfg = padt_amd.padt_pro_3b()
     sd = synthetic_state_dict(cfg, seed=3, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)
@@ -275,7 +275,7 @@ def test_reference_precision_7b_full_depth_within_1e3():
     import parity_util as U
     from padt_amd.modeling import PaDTForConditionalGeneration
     from padt_amd.weights import synthetic_state_dict
-    from synthetic_workload import multi_object_schedule
+    from padt_amd.synthetic import multi_object_schedule
     O = U.O
     cfg = padt_amd.padt_pro_7b()
     sd = synthetic_state_dict(cfg, seed=41, std=0.02, bias_std=0.02, norm_jitter=0.1, device="cuda", dtype=torch.bfloat16)

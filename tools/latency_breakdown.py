@@ -14,7 +14,7 @@ from padt_amd import pipeline  # noqa: E402
 from padt_amd.modeling import PaDTForConditionalGeneration  # noqa: E402
 from padt_amd.processor import parseVRTintoCompletion  # noqa: E402
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
-from synthetic_workload import FakeProcessor, rec_schedule, synthetic_batch  # noqa: E402
+from padt_amd.synthetic import FakeProcessor, rec_schedule, synthetic_batch  # noqa: E402
 
 
 def main():
