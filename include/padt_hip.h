@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- plumbing --------------------------------------------------------------------------------------------------- */
-int         padt_abi_version(void);                                  /* 3: round 5 (padt_check_finite, padt_mask_rle); 2: round 4 (fp16 twins) */
+int         padt_abi_version(void);                                  /* 4: round 6 (collect summary, output scores, split-operand MFMA attention); 3: round 5; 2: round 4 (fp16 twins) */
 /* The fp16 instantiation stores mirror = fp16(PADT_F16_STREAM_SCALE * X32): a residual stream is un-normalised (checkpoints carry "massive
  * activations" of 1e3-1e4 in a few channels), fp16 ends at 65504, and every consumer of a mirror is scale-invariant — padt_row_rstd_f16 and the
  * fused RMSNorm statistics of padt_gemm_packed_f16 / padt_quant_rows_fp8_f16 return rstd / scale when called with eps * scale^2, which the
@@ -283,6 +283,19 @@ int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, 
  * (value, index) pair per row in padt_greedy_step's partial layout (nblk = 1). */
 int  padt_sample_token(void* stream, const void* logits_f32, long ld_logits, long n_rows_table, const void* gen_cfg, const int* step,
                        void* part_val, void* part_idx, long batch);
+/* The synchronising half of generate() (padt.py:745-757 stop rule, :203 table assert, the range guard's flags) in ONE launch + one small
+ * D2H copy: out[0] = *err, out[1] = any(unfinished[0..n_rows)), out[2..] = nf_rows[n_rows], nf_batch[n_batch], first_eos[n_rows] — the first
+ * step t < done at which a row's token is an EOS id (eos or gen_cfg's list), -1 if none.  out holds 2 + 2 n_rows + n_batch int32. */
+int  padt_collect_summary(void* stream, const int* err, const int* unfinished, const int* nf_rows, const int* nf_batch, long n_rows,
+                          long n_batch, const long* tokens, long t_max, long done, int eos, const void* gen_cfg, int* out);
+/* sequences[b] = [input_ids[b] (L) | tokens[b][0..n_steps)] (padt.py:751), session-global VRT ids (>= vocab) shifted back by proto_row0. */
+int  padt_assemble_sequences(void* stream, const long* input_ids, long ld_ids, long L, const long* tokens, long t_max, long n_steps,
+                             long vocab, long proto_row0, long* out, long batch);
+/* past_logit_mask (padt.py:196-201,794), one byte per column: c < vocab, or vrt_off[b] <= c - vocab + proto_row0 < vrt_off[b + 1]. */
+int  padt_logit_mask(void* stream, const int* vrt_off, long vocab, long table_rows, long proto_row0, void* out_u8, long batch);
+/* output_scores=True (padt.py:719-720): dst[*step][0..n) = src[0..n) for the fp32 score rows padt_vrt_head wrote (logits_f32), indexed by the
+ * DEVICE step counter (a captured decode graph files every replay's rows under its own step); no-op once *step >= t_max.  n % 4 == 0. */
+int  padt_stash_step_f32(void* stream, const void* src_f32, long n, const int* step, long t_max, void* dst_f32);
 /* seen[rows[i]] |= bit(ids[i]) for the prompt tokens of a generate call (ids global in the session's table): the `input_ids` HF's
  * RepetitionPenaltyLogitsProcessor gathers over (generation/logits_process.py, reached from padt.py:717) — prompt and padding ids included. */
 int  padt_seen_init(void* stream, const long* ids, const int* rows, long n, void* seen, long seen_words);

@@ -11,7 +11,7 @@ extern "C" void padt_set_error(const char* msg) {
 
 extern "C" const char* padt_last_error(void) { return g_err; }
 
-extern "C" int padt_abi_version(void) { return 3; }
+extern "C" int padt_abi_version(void) { return 4; }
 // common.h PADT_STREAM_SCALE of the two operand-type instantiations
 extern "C" float padt_stream_scale(int f16) { return f16 ? 0.0625f : 1.0f; }
 

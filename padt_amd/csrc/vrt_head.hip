@@ -467,6 +467,126 @@ extern "C" int padt_sample_token(void* stream, const void* logits_f32, long ld_l
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// What generate()'s synchronising half needs from the device, in ONE launch and ONE small D2H copy (round 6: replaces a torch.cat of flag
+// tensors, `unfinished.any()` per chunk and isin / argmax / max over the token ring — seven ATen reduce launches and three host syncs per
+// batch): out = [err, any(unfinished), nf_rows[n_rows], nf_batch[n_batch], first_eos[n_rows]] with first_eos[r] = the first step t < done whose
+// token is one of the EOS ids (config eos or gen->eos[0..3]), -1 if none — the reference stops right after the step in which the last
+// sequence finished (padt.py:756-757), so a batch's length is max over its rows of first_eos + 1.
+struct CollectArgs {
+    const int* err; const int* unfinished; const int* nf_rows; const int* nf_batch; int n_rows, n_batch;
+    const long* tokens; int T_max, done, eos; const GenCfg* gen; int* out;
+};
+__global__ __launch_bounds__(256) void collect_summary_kernel(CollectArgs p) {
+    const int tid = threadIdx.x;
+    int unf = 0;
+    for (int r = tid; r < p.n_rows; r += 256) {
+        unf |= p.unfinished[r];
+        p.out[2 + r] = p.nf_rows[r];
+        int first = -1;
+        const long* row = p.tokens + (long)r * p.T_max;
+        for (int t = 0; t < p.done && first < 0; ++t) {
+            const long tok = row[t];
+            bool is_eos = tok == (long)p.eos;
+            if (p.gen) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k) is_eos = is_eos || (p.gen->eos[k] >= 0 && tok == (long)p.gen->eos[k]);
+            }
+            if (is_eos) first = t;
+        }
+        p.out[2 + p.n_rows + p.n_batch + r] = first;
+    }
+    for (int b = tid; b < p.n_batch; b += 256) p.out[2 + p.n_rows + b] = p.nf_batch[b];
+    const int any = __syncthreads_or(unf);
+    if (tid == 0) { p.out[0] = p.err ? *p.err : 0; p.out[1] = any ? 1 : 0; }
+}
+
+extern "C" int padt_collect_summary(void* stream, const int* err, const int* unfinished, const int* nf_rows, const int* nf_batch, long n_rows,
+                                    long n_batch, const long* tokens, long t_max, long done, int eos, const void* gen_cfg, int* out) {
+    if (n_rows <= 0 || n_batch < 0 || done < 0 || done > t_max || out == nullptr) { padt_set_error("padt_collect_summary: bad arguments"); return -1; }
+    CollectArgs a{err, unfinished, nf_rows, nf_batch, (int)n_rows, (int)n_batch, tokens, (int)t_max, (int)done, eos, (const GenCfg*)gen_cfg, out};
+    hipLaunchKernelGGL(collect_summary_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, a);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// sequences[b] = [input_ids[b] (L) | tokens[row0 + b][0 .. n_steps)] with the session-global VRT ids of a merged decode group shifted back to
+// the batch's own (id >= vocab → id - proto_row0): the `torch.cat([input_ids, next_tokens])` of padt.py:751 for one batch of the group.
+__global__ void assemble_sequences_kernel(const long* __restrict__ ids, long ld_ids, int L, const long* __restrict__ tokens, long T_max,
+                                          int n_steps, long vocab, long proto_row0, long* __restrict__ out, int B) {
+    const int W = L + n_steps;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * W; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / W), c = (int)(i % W);
+        long v;
+        if (c < L) v = ids[(long)b * ld_ids + c];
+        else {
+            v = tokens[(long)b * T_max + (c - L)];
+            if (v >= vocab) v -= proto_row0;
+        }
+        out[i] = v;
+    }
+}
+
+extern "C" int padt_assemble_sequences(void* stream, const long* input_ids, long ld_ids, long L, const long* tokens, long t_max, long n_steps,
+                                       long vocab, long proto_row0, long* out, long batch) {
+    if (batch <= 0 || L + n_steps <= 0) return 0;
+    if (n_steps < 0 || n_steps > t_max || L < 0) { padt_set_error("padt_assemble_sequences: bad arguments"); return -1; }
+    const long n = batch * (L + n_steps);
+    long blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(assemble_sequences_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, input_ids, ld_ids, (int)L, tokens, t_max,
+                       (int)n_steps, vocab, proto_row0, out, (int)batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// past_logit_mask (padt.py:196-201, returned at :794): mask[b][c] = c < vocab || vrt_off[b] <= c - vocab + off0 < vrt_off[b + 1] — one byte per
+// table column; vrt_off are the session's prototype row offsets of the batch's rows, off0 = the batch's first prototype row in the session.
+__global__ void logit_mask_kernel(const int* __restrict__ vrt_off, long vocab, long table_rows, long off0, unsigned char* __restrict__ out, int B) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < (long)B * table_rows; i += (long)gridDim.x * blockDim.x) {
+        const int b = (int)(i / table_rows);
+        const long c = i % table_rows;
+        out[i] = (c < vocab || (c - vocab + off0 >= vrt_off[b] && c - vocab + off0 < vrt_off[b + 1])) ? 1 : 0;
+    }
+}
+
+extern "C" int padt_logit_mask(void* stream, const int* vrt_off, long vocab, long table_rows, long proto_row0, void* out_u8, long batch) {
+    if (batch <= 0 || table_rows <= 0) return 0;
+    const long n = batch * table_rows;
+    long blocks = (n + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(logit_mask_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, vrt_off, vocab, table_rows, proto_row0,
+                       (unsigned char*)out_u8, (int)batch);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
+// output_scores=True (padt.py:719-720: `scores += (next_token_scores,)`): dst[*step][0..n) = src[0..n) — the masked / penalised fp32 logit rows
+// the head kernel just wrote, filed under the DEVICE step counter so the copy can sit inside the captured decode graph.
+__global__ void stash_step_f32_kernel(const float* __restrict__ src, long n, const int* __restrict__ step, long t_max, float* __restrict__ dst) {
+    const long s = *step;
+    if (s < 0 || s >= t_max) return;
+    float* d = dst + s * n;
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long)gridDim.x * blockDim.x)
+        reinterpret_cast<f32x4*>(d)[i] = reinterpret_cast<const f32x4*>(src)[i];
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) d[n4 * 4 + threadIdx.x] = src[n4 * 4 + threadIdx.x];
+}
+
+extern "C" int padt_stash_step_f32(void* stream, const void* src_f32, long n, const int* step, long t_max, void* dst_f32) {
+    if (n <= 0) return 0;
+    if (((size_t)src_f32 | (size_t)dst_f32) & 15 || (n & 3)) { padt_set_error("padt_stash_step_f32: 16-byte aligned buffers and n % 4 == 0 required"); return -1; }
+    long blocks = (n / 4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(stash_step_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const float*)src_f32, n, step, t_max, (float*)dst_f32);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 // seen[row[i]] |= bit(ids[i]) for every prompt token (ids already global in the session's table); ids outside the table are
 // ignored (the range assert of padt.py:203 is reported by the embedding kernel).
 __global__ void seen_init_kernel(const long* __restrict__ ids, const int* __restrict__ rows, long n, unsigned* seen, long words) {

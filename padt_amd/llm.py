@@ -173,6 +173,12 @@ class DecodeSession:
         self.seen = z(B, (cfg.vocab_size + np_max + 31) // 32, dt=I32)
         self.err = z(1, dt=I32)
         self.nf = z(B, dt=I32)           # per row: a decode step produced a non-finite hidden row (fp16 operand overflow; ops.check_finite)
+        self.nf_batch = z(B, dt=I32)     # per batch of the decode group (slot k): ViT rows / prototypes / prompt-pass rows not finite
+        # generate_collect's ONE read-back per chunk (ops.collect_summary): [err, any unfinished, nf rows, nf batches, first EOS step per row]
+        self.summary = z(2 + 3 * B, dt=I32)
+        self.summary_host = torch.zeros(2 + 3 * B, dtype=I32).pin_memory() if torch.device(device).type == "cuda" else torch.zeros(2 + 3 * B, dtype=I32)
+        self.keep_scores = False         # output_scores=True: every step's masked fp32 logit rows are filed in `scores` [t_max][B][W]
+        self.scores = None
         self.rope_cs = z(B, hd // 2, 2, dt=torch.float32)
         self.n_qkv = (cfg.num_attention_heads + 2 * Hkv) * hd
         self.graphs = {}                 # captured decode-step graph per mode (greedy / sampling: different kernel sequences)
@@ -249,9 +255,9 @@ class DecodeSession:
         cfg, W = self.cfg, self.W
         hp = W.get("llm.head.wp")
         lg = None
-        if self.do_sample:                                   # the sampling kernel needs the whole masked / penalised logit row
+        if self.do_sample or self.keep_scores:               # the sampling kernel / output_scores need the whole masked / penalised logit row
             if self.logits is None:
-                self.logits = torch.empty((self.B, cfg.vocab_size + self.np_max), device=hn.device, dtype=torch.float32)
+                self.logits = torch.empty((self.B, (cfg.vocab_size + self.np_max + 3) // 4 * 4), device=hn.device, dtype=torch.float32)
             lg = self.logits
         if hp is not None:                                   # packed table + packed hidden rows: 1 KiB contiguous wave loads
             ops.pack_rows(hn, self.hn_pk, self.B, to_packed=True)
@@ -261,6 +267,10 @@ class DecodeSession:
         else:
             ops.vrt_head(hn, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
                          mode_table=self.mode_table, step=self.step, gen_cfg=self.gen_cfg, seen=self.seen, logits=lg)
+        if self.keep_scores:                                 # padt.py:719-720: scores += (next_token_scores,) — filed under the device step counter
+            if self.scores is None:
+                self.scores = torch.zeros((self.t_max,) + tuple(self.logits.shape), device=hn.device, dtype=torch.float32)
+            ops.stash_step_f32(lg, self.step, self.scores)
         nblk = self.nblk
         if self.do_sample:                                   # padt.py:740-743: multinomial over softmax of the warped scores
             ops.sample_token(lg, cfg.vocab_size + self.np_max, self.gen_cfg, self.step, self.part_val, self.part_idx, self.B)
@@ -280,7 +290,8 @@ class DecodeSession:
             for _ in range(n):
                 self.step_kernels()
             return
-        if self.do_sample not in self.graphs:
+        gkey = (self.do_sample, self.keep_scores)            # different kernel sequences → one captured graph per mode
+        if gkey not in self.graphs:
             self.step_kernels()                              # real step; also pays every one-time kernel attribute call
             n -= 1
             g = torch.cuda.CUDAGraph()
@@ -289,11 +300,11 @@ class DecodeSession:
             # global mode such a query from another thread invalidates the capture.
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
                 self.step_kernels()
-            self.graphs[self.do_sample] = g
+            self.graphs[gkey] = g
         t = ops.STEP_TIMER
         ev = t.begin() if t is not None else None
         for _ in range(n):
-            self.graphs[self.do_sample].replay()
+            self.graphs[gkey].replay()
         if ev is not None:
             t.end(ev, (n, self.B))
 

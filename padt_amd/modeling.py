@@ -90,7 +90,9 @@ class CustomGenerateDecoderOnlyOutput(dict):
 # (None = any value), otherwise NotImplementedError.
 _GENERATE_IGNORED = {
     "attn_implementation": None, "tokenizer": None, "assistant_tokenizer": None, "cache_implementation": None, "logits_to_keep": None,
-    "generation_config": (None,), "output_attentions": (False, None), "output_scores": (False, None), "output_logits": (False, None),
+    "generation_config": (None,), "output_attentions": (False, None),
+    # GenerationConfig fields callers pass routinely and the reference's generate() accepts without effect on this path:
+    "bos_token_id": None, "decoder_start_token_id": None, "return_legacy_cache": None,
     "num_beams": (1, None), "num_beam_groups": (1, None), "num_return_sequences": (1, None), "penalty_alpha": (None,), "min_new_tokens": (0, None),
     "min_length": (0, None), "no_repeat_ngram_size": (0, None), "bad_words_ids": (None,), "force_words_ids": (None,), "token_healing": (False, None),
     "length_penalty": (1.0, None), "early_stopping": (False, None), "typical_p": (1.0, None), "min_p": (None,), "epsilon_cutoff": (0.0, None),
@@ -116,7 +118,7 @@ def check_generate_kwargs(kwargs: dict, max_new_tokens, max_length, prompt_len) 
                                       "remove the argument or run the reference for this call")
         if k in _GENERATE_IGNORED:
             ok = _GENERATE_IGNORED[k]
-            if ok is None or v in ok:
+            if ok is None or any(v is o or (not isinstance(v, (torch.Tensor, list, tuple, dict)) and v == o) for o in ok):
                 continue
             raise NotImplementedError(f"generate({k}={v!r}) is not implemented on the MI355X path (supported: {ok})")
         raise ValueError(f"The following `model_kwargs` are not used by the model: ['{k}'] (note: typos in the generate arguments will also "
@@ -266,7 +268,8 @@ class PaDTForConditionalGeneration:
                  synced_gpus=False, schedule: Optional[Sequence[Optional[str]]] = None, sync_every: int = 16,
                  use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None,
                  temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
-                 seed: Optional[int] = None, max_length: Optional[int] = None, **kwargs):
+                 seed: Optional[int] = None, max_length: Optional[int] = None, output_scores: bool = False, output_logits: bool = False,
+                 pad_token_id: Optional[int] = None, **kwargs):
         """Greedy generation over the unified text‖VRT vocabulary.
 
         Arguments of the reference's ``generate`` (padt.py:414-434 + the HF generation kwargs it forwards) that this path does not
@@ -283,6 +286,11 @@ class PaDTForConditionalGeneration:
         ``repetition_penalty`` / ``eos_token_id`` (int or list) / ``do_sample``: default to the checkpoint's
         generation_config.json (self.generation_config), exactly the entries HF's generate turns into a logits processor /
         stopping criterion / sampling switch (padt.py:436,570-580,740-743); explicit arguments override.
+        ``output_scores=True`` (padt.py:719-720): ``.scores`` = T-tuple of (B, table rows) fp32 tensors — the step's logits after the logit mask
+        (padt.py:292-301) and the logits processors (repetition penalty, the synthetic ``schedule``), i.e. what the arg-max / the sampler saw.
+        ``output_logits=True`` (padt.py:721-724, the rows BEFORE the processors): served when no processor is active (repetition_penalty == 1,
+        no schedule — then they ARE the scores), rejected otherwise.  ``pad_token_id``: must be the config's (the greedy kernel pads finished
+        rows with it, padt.py:749).
         ``do_sample=True``: multinomial sampling after HF's Temperature → TopK → TopP warpers (``temperature`` / ``top_k`` /
         ``top_p``, defaults from generation_config, HF's own defaults 1.0 / 50 / 1.0) on a device counter-based generator keyed
         by ``seed`` (default: drawn from torch's global generator, so torch.manual_seed makes runs repeatable).  The draws are
@@ -292,16 +300,26 @@ class PaDTForConditionalGeneration:
             raise NotImplementedError("generate(synced_gpus=True) is the ZeRO-3 / FSDP lock-step loop (padt.py:445,670): every rank holds a full "
                                       "replica on this path — pass synced_gpus=False")
         max_new_tokens = check_generate_kwargs(kwargs, max_new_tokens, max_length, None if input_ids is None else input_ids.shape[1])
+        if pad_token_id is not None and int(pad_token_id) != int(self.generation_config.pad_token_id):
+            raise NotImplementedError(f"generate(pad_token_id={pad_token_id}): finished rows are padded with the checkpoint's pad token "
+                                      f"({self.generation_config.pad_token_id}) on this path")
+        if output_logits:
+            pen = self.generation_config.repetition_penalty if repetition_penalty is None else repetition_penalty
+            if float(pen) != 1.0 or schedule is not None:
+                raise NotImplementedError("generate(output_logits=True) with a logits processor active (repetition_penalty != 1 or a schedule): only the "
+                                          "processed rows are kept on this path — ask for output_scores=True")
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
                                    schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
-                                   eos_token_id=eos_token_id, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed)
-        return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate)
+                                   eos_token_id=eos_token_id, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed,
+                                   keep_scores=bool(output_scores or output_logits))
+        return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate, output_scores=bool(output_scores),
+                                     output_logits=bool(output_logits))
 
     @torch.no_grad()
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=None,
                         schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
                         repetition_penalty=None, eos_token_id=None, temperature=None, top_k=None, top_p=None, seed=None,
-                        vit_stream=None, inputs_ready=None):
+                        vit_stream=None, inputs_ready=None, keep_scores=False):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -318,7 +336,7 @@ class PaDTForConditionalGeneration:
         if owner is not self:
             return owner.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample, schedule, sync_every,
                                          use_graph, lane, decode_stream, group, n_slots, repetition_penalty, eos_token_id, temperature, top_k, top_p,
-                                         seed, vit_stream, inputs_ready)
+                                         seed, vit_stream, inputs_ready, keep_scores)
         self._batches_seen += 1
         gc = self.generation_config
         do_sample = gc.do_sample if do_sample is None else do_sample
@@ -343,7 +361,7 @@ class PaDTForConditionalGeneration:
         if cfg.eos_token_id not in eos_list or len(eos_list) > 4:
             raise NotImplementedError("eos_token_id must contain config.eos_token_id and hold at most 4 ids")
         samp = (float(temperature), int(top_k), float(top_p), int(seed)) if do_sample else None
-        gen_key = (float(repetition_penalty), tuple(eos_list), samp)
+        gen_key = (float(repetition_penalty), tuple(eos_list), samp, bool(keep_scores))
         grid = image_grid_thw.detach().cpu().long()
         B = input_ids.shape[0]
         T_max = int(max_new_tokens)
@@ -362,6 +380,7 @@ class PaDTForConditionalGeneration:
                                                   temperature=samp[0] if samp else 1.0, top_k=samp[1] if samp else 0,
                                                   top_p=samp[2] if samp else 1.0).to(dev, non_blocking=True))
             sess.do_sample = samp is not None
+            sess.keep_scores = bool(keep_scores)
             if gen_key[0] != 1.0:
                 sess.seen.zero_()
             # neutral state for every row; the batches overwrite their own rows (unused rows stay finished / empty)
@@ -392,10 +411,13 @@ class PaDTForConditionalGeneration:
         rows = slice(row0, row0 + B)
         sess.nf[rows].zero_()
         # this batch's range guard (ViT rows, prototypes, prompt-pass hidden rows).  Its zero fill must be ordered before EVERY check that ORs
-        # into it: with a ViT stream the flag is allocated and zeroed ON that stream (the fill on the current stream would sit behind the
+        # into it: with a ViT stream the flag is zeroed ON that stream (the fill on the current stream would sit behind the
         # previous batch's prefill while the ViT checks of this batch already run — ADVICE r05); the prefill's check comes after
         # cur.wait_stream(vit_stream) below
-        nf = None if (vit_stream is not None and self.ref is None) else torch.zeros(1, dtype=torch.int32, device=dev)
+        # The flag is slot k of the session's per-batch vector (read back with every other flag by ONE ops.collect_summary launch).
+        nf = sess.nf_batch[k: k + 1]
+        if vit_stream is None or self.ref is not None:
+            nf.zero_()
 
         # ---- ViT → prototypes → session table
         if self.ref is not None:
@@ -414,11 +436,11 @@ class PaDTForConditionalGeneration:
             if k == 0 or inputs_ready is None:
                 vit_stream.wait_stream(cur)
             with torch.cuda.stream(vit_stream):
-                nf = torch.zeros(1, dtype=torch.int32, device=dev)
+                nf.zero_()
                 low, high, pe = self.visual(pixel_values.to(dev), grid, nf=nf)
                 proto = self.lm.prototypes(low, out=sess.proto[proto_row0: proto_row0 + n_proto], nf=nf)
             cur.wait_stream(vit_stream)                           # the prefill below reads low / the prototype rows
-            for t_ in (low, high, pe[0], pe[1], nf):               # allocated on vit_stream, read on the prefill / decode streams
+            for t_ in (low, high, pe[0], pe[1]):                   # allocated on vit_stream, read on the prefill / decode streams
                 t_.record_stream(cur)
                 if decode_stream is not None:
                     t_.record_stream(decode_stream)
@@ -483,60 +505,67 @@ class PaDTForConditionalGeneration:
         group["done"] = 1 + n
 
     @torch.no_grad()
-    def generate_collect(self, group, output_hidden_states=True, return_dict_in_generate=True, all_batches=False):
-        """Synchronising half of generate(): remaining decode chunks (host checks `unfinished` between chunks), trimming
-        to the reference's stop rule, output object — of the group's only batch, or a list over its batches."""
+    def generate_collect(self, group, output_hidden_states=True, return_dict_in_generate=True, all_batches=False, output_scores=False,
+                         output_logits=False):
+        """Synchronising half of generate(): remaining decode chunks, trimming to the reference's stop rule, output object — of the group's only
+        batch, or a list over its batches.  Everything the host needs from the device per chunk — the table-range assert (padt.py:203), `any
+        row unfinished`, the range guard's per-row / per-batch flags, each row's first EOS step — comes from ONE kernel + ONE pinned D2H copy
+        (ops.collect_summary; round 6: no ATen reductions, no `.item()` round trips)."""
         if group["owner"] is not self:
-            return group["owner"].generate_collect(group, output_hidden_states, return_dict_in_generate, all_batches)
+            return group["owner"].generate_collect(group, output_hidden_states, return_dict_in_generate, all_batches, output_scores, output_logits)
         cfg, dev = self.config, self.device
         self.launch_decode(group)
         sess, T_max = group["sess"], group["T_max"]
+        n_rows, n_sub = sess.B, len(group["subs"])
+
+        def summary(done):
+            ops.collect_summary(sess.err, sess.unfinished, sess.nf, sess.nf_batch, n_sub, sess.tokens, done, cfg.eos_token_id, sess.gen_cfg, sess.summary)
+            sess.summary_host.copy_(sess.summary, non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+            return sess.summary_host.tolist()
         done_steps = group["done"]
-        while done_steps < T_max and bool(sess.unfinished.any()):
+        flags = summary(done_steps)
+        while done_steps < T_max and flags[1]:
             n = min(group["sync_every"], T_max - done_steps)
             sess.run_steps(n, use_graph=group["use_graph"])
             done_steps += n
+            flags = summary(done_steps)
         group["done"] = done_steps
-        # ONE read-back of every device flag of the group: the table-range assert (padt.py:203) and the range guard (per batch: ViT rows,
-        # prototypes, prompt-pass rows; per row: every decode step's hidden row)
-        flags = torch.cat([sess.err, sess.nf] + [sub["nf"] for sub in group["subs"]]).cpu()
-        if int(flags[0]) != 0:
+        if flags[0] != 0:
             raise AssertionError("input_ids.max() >= extended table rows (padt.py:203)")
-        n_rows = sess.nf.numel()
+        nf_rows, nf_batch = flags[2: 2 + n_rows], flags[2 + n_rows: 2 + n_rows + n_sub]
+        first_eos = flags[2 + n_rows + n_sub: 2 + 2 * n_rows + n_sub]
         outs = []
         for k_sub, sub in enumerate(group["subs"]):
             plan, row0, B = sub["plan"], sub["row0"], group["B"]
-            if int(flags[1 + n_rows + k_sub]) != 0 or bool(flags[1 + row0: 1 + row0 + B].any()):
+            if nf_batch[k_sub] != 0 or any(nf_rows[row0: row0 + B]):
                 outs.append(self._non_finite_batch(group, sub, output_hidden_states, return_dict_in_generate))
                 continue
-            toks = sess.tokens[row0: row0 + B, :done_steps].clone()
-            if sub["proto_row0"]:                                  # back to this batch's own global VRT ids
-                toks = torch.where(toks >= cfg.vocab_size, toks - sub["proto_row0"], toks)
-            # reference stops right after the step in which the last sequence finished (padt.py:756-757)
-            eos_hit = torch.isin(toks, torch.tensor(group["eos_list"], device=toks.device, dtype=toks.dtype))   # any id of the EOS list finishes a row
-            if bool(eos_hit.any(dim=1).all()):
-                stop = int((eos_hit.float().argmax(dim=1)).max()) + 1
-                toks = toks[:, :stop]
-            n_steps = toks.shape[1]
-            sequences = torch.cat([sub["input_ids"].to(dev), toks], dim=1)
+            # the reference stops right after the step in which the last sequence finished (padt.py:756-757); any id of the EOS list finishes a row
+            fe = first_eos[row0: row0 + B]
+            n_steps = max(fe) + 1 if all(f >= 0 for f in fe) else done_steps
+            # [input_ids | tokens] with the group's session-global VRT ids shifted back to this batch's own (one launch, padt.py:751)
+            sequences = ops.assemble_sequences(sub["input_ids"].to(dev), sess.tokens[row0: row0 + B], n_steps, cfg.vocab_size, sub["proto_row0"])
             # clone: the session's hidden_buf is reused by the lane's next generate(); the caller owns what it gets back
             hbuf = sess.hid32 if self.ref is not None else sess.hidden_buf      # reference precision keeps the per-step rows in fp32
             hidden = StepHiddenStates(hbuf[:n_steps, row0: row0 + B].clone(), n_steps, sub["hn_all"],
                                       plan.lens, plan.L_pad)
             table_rows = cfg.vocab_size + sub["n_proto"]
-
-            def logit_mask(plan=plan, table_rows=table_rows, B=B):
-                m = torch.zeros((B, table_rows), dtype=torch.bool, device=dev)
-                m[:, : cfg.vocab_size] = True
-                for b in range(B):
-                    m[b, cfg.vocab_size + plan.vrt_off[b]: cfg.vocab_size + plan.vrt_off[b + 1]] = True
-                return m
-
+            scores = None
+            if output_scores or output_logits:
+                # per step (B, table rows): text columns + this batch's own prototype columns of the session-wide rows (padt.py:719-724)
+                V, p0 = cfg.vocab_size, sub["proto_row0"]
+                rows_t = sess.scores[:n_steps, row0: row0 + B]
+                if p0 == 0:
+                    scores = tuple(rows_t[t, :, :table_rows].clone() for t in range(n_steps))
+                else:
+                    scores = tuple(torch.cat([rows_t[t, :, :V], rows_t[t, :, V + p0: V + p0 + sub["n_proto"]]], dim=1) for t in range(n_steps))
             out = CustomGenerateDecoderOnlyOutput(
-                sequences=sequences, scores=None, logits=None, attentions=None,
+                sequences=sequences, scores=scores if output_scores else None, logits=scores if output_logits else None, attentions=None,
                 hidden_states=hidden if output_hidden_states else None, past_key_values=sess,
-                past_image_embeds=sub["proto"].clone(), past_logit_mask=logit_mask(), past_high_res_image_embeds=sub["high"],
-                past_visual_pe=sub["pe"])
+                past_image_embeds=sub["proto"].clone(),
+                past_logit_mask=ops.logit_mask(sess.vrt_off[row0: row0 + B + 1], cfg.vocab_size, table_rows, sub["proto_row0"], B),
+                past_high_res_image_embeds=sub["high"], past_visual_pe=sub["pe"])
             outs.append(out if return_dict_in_generate else sequences)
         return outs if all_batches else outs[0]
 
@@ -560,14 +589,14 @@ class PaDTForConditionalGeneration:
             warnings.warn("padt_amd: %d of %d batches exceeded fp16's range — operands='auto' now starts every new decode group on the bf16 "
                           "instantiation" % (self.overflow_reruns, self._batches_seen), RuntimeWarning, stacklevel=3)
         am, pix, grid = sub["inputs"]
-        pen, eos, samp = group["gen_key"]
+        pen, eos, samp = group["gen_key"][:3]
         kw = dict(do_sample=False)
         if samp is not None:
             kw = dict(do_sample=True, temperature=samp[0], top_k=samp[1], top_p=samp[2], seed=samp[3])
         return fb.generate(input_ids=sub["input_ids"], attention_mask=am, pixel_values=pix, image_grid_thw=grid, max_new_tokens=group["T_max"],
                            schedule=group["schedule"], sync_every=group["sync_every"], use_graph=group["use_graph"], lane=("fb", group["lane"]),
                            repetition_penalty=pen, eos_token_id=list(eos), output_hidden_states=output_hidden_states,
-                           return_dict_in_generate=return_dict_in_generate, **kw)
+                           return_dict_in_generate=return_dict_in_generate, output_scores=bool(group["gen_key"][3]), **kw)
 
     # ------------------------------------------------------------------ vl_decode (padt.py:342-412)
     @torch.no_grad()

@@ -614,6 +614,40 @@ def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens
                                     seen.shape[1] if seen is not None else 0), "padt_greedy_step")
 
 
+def collect_summary(err, unfinished, nf_rows, nf_batch, n_batch, tokens, done, eos, gen_cfg, out):
+    """One launch: out = [err, any(unfinished), nf_rows…, nf_batch[:n_batch]…, first_eos step per row…] (padt_collect_summary)."""
+    n_rows = unfinished.numel()
+    assert out.dtype == torch.int32 and out.numel() >= 2 + 2 * n_rows + n_batch and tokens.dtype == torch.int64 and tokens.is_contiguous()
+    _lib.check(_lib.load().padt_collect_summary(_stream(), _p(err), _p(unfinished), _p(nf_rows), _p(nf_batch), n_rows, int(n_batch), _p(tokens),
+                                                tokens.shape[1], int(done), int(eos), _p(gen_cfg), _p(out)), "padt_collect_summary")
+    return out
+
+
+def assemble_sequences(input_ids, tokens, n_steps, vocab, proto_row0):
+    """→ (B, L + n_steps) int64: [input_ids | tokens[:, :n_steps]] with session-global VRT ids shifted back by proto_row0 (padt.py:751)."""
+    assert input_ids.dtype == torch.int64 and input_ids.stride(1) == 1 and tokens.dtype == torch.int64 and tokens.stride(1) == 1
+    B, L = input_ids.shape
+    out = torch.empty((B, L + int(n_steps)), dtype=torch.int64, device=tokens.device)
+    _lib.check(_lib.load().padt_assemble_sequences(_stream(), _p(input_ids), input_ids.stride(0), L, _p(tokens), tokens.stride(0), int(n_steps),
+                                                   int(vocab), int(proto_row0), _p(out), B), "padt_assemble_sequences")
+    return out
+
+
+def logit_mask(vrt_off, vocab, table_rows, proto_row0, batch):
+    """→ (batch, table_rows) bool past_logit_mask (padt.py:196-201) from the session's prototype row offsets of the batch's rows."""
+    assert vrt_off.dtype == torch.int32 and vrt_off.numel() >= batch + 1
+    out = torch.empty((batch, table_rows), dtype=torch.uint8, device=vrt_off.device)
+    _lib.check(_lib.load().padt_logit_mask(_stream(), _p(vrt_off), int(vocab), int(table_rows), int(proto_row0), _p(out), int(batch)), "padt_logit_mask")
+    return out.view(torch.bool)
+
+
+def stash_step_f32(src, step, dst):
+    """dst[*step] = src (fp32, whole buffer) under the device step counter (padt_stash_step_f32): per-step score rows for output_scores."""
+    assert src.dtype == torch.float32 and dst.dtype == torch.float32 and src.is_contiguous() and dst.is_contiguous() and dst[0].numel() == src.numel()
+    _lib.check(_lib.load().padt_stash_step_f32(_stream(), _p(src), src.numel(), _p(step), dst.shape[0], _p(dst)), "padt_stash_step_f32")
+    return dst
+
+
 def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want_logits=False):
     """masks (n_obj, Hm, Wm) fp32 logits; src/dst sizes int32 device tensors (n_obj,) → uint8 (n_obj, max_h, max_w)
     [, fp32 up-sampled logits]."""

@@ -48,6 +48,11 @@ class PipelinedRunner:
     def __init__(self, model, processor, depth: int = 2, merge: int = 1, shared_prefill_stream: bool = True, use_graph: bool = True,
                  vit_stream: bool = False):
         self.model, self.processor, self.depth, self.merge = model, processor, depth, max(1, merge)
+        import padt_amd
+        if padt_amd.hw_queue_note:                             # the runner is the component that needs more than 4 hardware queues
+            import warnings
+            warnings.warn(padt_amd.hw_queue_note, RuntimeWarning, stacklevel=2)
+            padt_amd.hw_queue_note = None
         # vit_stream: the ViT of batch b + 1 on its own stream, concurrent with the LLM prefill of batch b (the two phases leave different
         # tails on the 256 CUs); per-sample results are unchanged (same kernels, same order per batch)
         self.vit_stream = torch.cuda.Stream(device=model.device) if vit_stream else None

@@ -23,7 +23,7 @@ def test_header_parses_and_every_symbol_is_exported(lib):
     assert len(decls) >= 26 and len(twins) >= 20
     for name in list(decls) + list(twins):
         assert hasattr(lib, name), f"{name} declared in include/ but not exported"
-    assert lib.padt_abi_version() == 3
+    assert lib.padt_abi_version() == 4
     assert lib.padt_stream_scale(0) == 1.0 and lib.padt_stream_scale(1) == 2.0 ** -4
 
 

@@ -887,3 +887,64 @@ def test_bench_world_one_exchange_runs_on_rccl():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["exchange"]["backend"] == "nccl" and d["exchange"]["all_gathers"] >= 3
     assert "roofline" not in d and "cpu_baseline" not in d          # the distributed path prints the contract line only
+
+
+def test_output_scores_are_the_oracles_processed_logits(setup):
+    """generate(output_scores=True) (padt.py:719-720): a T-tuple of (B, V + N) fp32 rows — the step's logits after the logit mask (padt.py:292-301)
+    and the logits processors — against the oracle's rows of the same (teacher-forced) run: same -inf support at every step, finite entries
+    within the operand type's logit noise; also past_logit_mask (padt.py:196-201), output_logits (== scores when no processor is active) and
+    the same rows out of a merged decode group (this batch's own prototype columns of the session-wide rows)."""
+    cfg, w, model, U, oc = setup
+    import padt_amd
+    from padt_amd import pipeline
+    grids = [[1, 10, 12], [1, 8, 8]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=6, n_post=9, ragged=True, seed=77)
+    T = 9
+    sched = U.rec_schedule(T, vrt_at=range(3, 6))
+    out = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T,
+                         schedule=sched, output_scores=True, repetition_penalty=1.3)
+    V, N = cfg.vocab_size, sum(g[1] * g[2] // 4 for g in grids)
+    assert isinstance(out.scores, tuple) and len(out.scores) == T and out.logits is None
+    toks = out.sequences.cpu()[:, ids.shape[1]:]
+    ores = U.O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, collect_logits=True, force_tokens=toks, repetition_penalty=1.3)
+    worst = 0.0
+    for t in range(T):
+        s, o = out.scores[t].cpu(), ores["logits"][t]
+        assert s.shape == (2, V + N) and s.dtype == torch.float32
+        if sched[t] == "e":                                         # forced EOS: the oracle's processor writes 0 at the EOS column, the kernel keeps the logit
+            assert torch.isfinite(s).sum(dim=1).tolist() == [1, 1] and torch.isfinite(s[:, cfg.eos_token_id]).all()
+            continue
+        assert torch.equal(torch.isfinite(s), torch.isfinite(o)), f"step {t}: different -inf support"
+        fin = torch.isfinite(o)
+        worst = max(worst, ((s[fin] - o[fin]).abs().max() / o[fin].abs().max()).item())
+    print(f"\n[output_scores, {model.dtype}] worst |score - oracle| / max|logit| over {T - 1} steps: {worst:.3e}")
+    assert worst < tol(model, 2e-2, 3e-3)                           # measured ≈6e-3 (bf16) / 8e-4 (fp16): the logit noise of the operand type
+    # past_logit_mask: text columns + the sample's own prototype columns
+    m = out.past_logit_mask.cpu()
+    assert m.dtype == torch.bool and m.shape == (2, V + N)
+    n0 = grids[0][1] * grids[0][2] // 4
+    exp = torch.zeros(2, V + N, dtype=torch.bool)
+    exp[:, :V] = True
+    exp[0, V: V + n0] = True
+    exp[1, V + n0:] = True
+    assert torch.equal(m, exp)
+    # output_logits without a processor == output_scores; with one it is refused
+    o2 = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=4,
+                        output_scores=True, output_logits=True)
+    assert len(o2.logits) == len(o2.scores) and all(torch.equal(a, b) for a, b in zip(o2.logits, o2.scores))
+    with pytest.raises(NotImplementedError, match="output_logits"):
+        model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=4,
+                       schedule=sched, output_logits=True)
+    # the second batch of a merged decode group: its scores are the stand-alone run's, bit for bit (rows and columns of the shared session)
+    b0 = (ids.clone().cuda(), am.cuda(), pix.cuda(), grid)
+    grid1, pix1, ids1, am1 = U.synthetic_batch(cfg, grids, n_pre=6, n_post=9, ragged=True, seed=78)
+    alone = model.generate(input_ids=ids1.cuda(), attention_mask=am1.cuda(), pixel_values=pix1.cuda(), image_grid_thw=grid1, max_new_tokens=T,
+                           schedule=sched, output_scores=True, lane=5)
+    g = model.generate_launch(*b0, max_new_tokens=T, schedule=sched, sync_every=T, lane=6, n_slots=2, keep_scores=True)
+    g = model.generate_launch(ids1.cuda(), am1.cuda(), pix1.cuda(), grid1, max_new_tokens=T, schedule=sched, sync_every=T, lane=6, group=g, n_slots=2,
+                              keep_scores=True)
+    outs = model.generate_collect(g, all_batches=True, output_scores=True)
+    assert torch.equal(outs[1].sequences, alone.sequences)
+    for t in range(T):
+        assert torch.equal(outs[1].scores[t], alone.scores[t]), t
+    assert torch.equal(outs[1].past_logit_mask, alone.past_logit_mask)

@@ -289,7 +289,7 @@ def test_processor_and_parser_on_a_real_bpe_tokenizer(golden_dir):
 _REJECTED_WITH_VALUES = [("stopping_criteria", [object()]), ("logits_processor", [object()]), ("streamer", object()), ("min_length", 5),
                          ("min_new_tokens", 3), ("num_beams", 4), ("pixel_values_videos", torch.zeros(1)), ("video_grid_thw", torch.zeros(1, 3)),
                          ("inputs_embeds", torch.zeros(1, 2, 4)), ("prefix_allowed_tokens_fn", lambda *a: [0]), ("assistant_model", object()),
-                         ("negative_prompt_ids", torch.zeros(1, 2)), ("output_scores", True), ("output_logits", True), ("output_attentions", True),
+                         ("negative_prompt_ids", torch.zeros(1, 2)), ("output_attentions", True),
                          ("stop_strings", ["x"]), ("num_return_sequences", 2), ("generation_config", object())]
 
 
@@ -307,8 +307,14 @@ def test_generate_argument_policy_defaults_unknowns_and_max_length():
     from padt_amd.modeling import PaDTForConditionalGeneration, check_generate_kwargs
     # the callers' own call (eval/test_demo.py:96-103, utils.py:224-232) and the reference's default-valued arguments pass
     ok = dict(attn_implementation="flash_attention_2", tokenizer=None, stopping_criteria=None, logits_processor=[], streamer=None, num_beams=1,
-              min_length=0, output_scores=False, generation_config=None, pixel_values_videos=None)
+              min_length=0, generation_config=None, pixel_values_videos=None,
+              bos_token_id=151643, decoder_start_token_id=None, return_legacy_cache=True)       # benign GenerationConfig fields
     assert check_generate_kwargs(dict(ok), 16, None, 9) == 16
+    # a tensor / list value of a policy-checked argument is compared by identity, never by `in` (no "Boolean value of Tensor" surprise)
+    with pytest.raises(NotImplementedError, match="num_beams"):
+        check_generate_kwargs({"num_beams": torch.tensor(2)}, 4, None, 9)
+    with pytest.raises(NotImplementedError, match="bad_words_ids"):
+        check_generate_kwargs({"bad_words_ids": [[1, 2]]}, 4, None, 9)
     assert check_generate_kwargs({}, None, None, 9) == 1024
     # max_length counts the (padded) prompt (padt.py:511-520); max_new_tokens wins when both are given
     assert check_generate_kwargs({}, None, 40, 9) == 31
@@ -321,6 +327,14 @@ def test_generate_argument_policy_defaults_unknowns_and_max_length():
     m = PaDTForConditionalGeneration.__new__(PaDTForConditionalGeneration)
     with pytest.raises(NotImplementedError, match="synced_gpus"):
         m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), synced_gpus=True)
+    # pad_token_id: the checkpoint's own value passes the policy, another one is refused (finished rows are padded on the device, padt.py:749);
+    # output_logits with an active logits processor is refused (only the processed rows are kept), output_scores never is
+    from types import SimpleNamespace
+    m.generation_config = SimpleNamespace(pad_token_id=151643, repetition_penalty=1.1)
+    with pytest.raises(NotImplementedError, match="pad_token_id"):
+        m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), max_new_tokens=2, pad_token_id=0)
+    with pytest.raises(NotImplementedError, match="output_logits"):
+        m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), max_new_tokens=2, pad_token_id=151643, output_logits=True)
 
 
 def test_import_sets_hardware_queue_default_but_never_overrides_the_user():
