@@ -368,6 +368,51 @@ def replay_leg(model, inp, args, cfg):
 
 
 # ------------------------------------------------------------------------------------------------ CPU baseline leg
+def hip_sample0(model, inp, args):
+    """The HIP path's own answer for the first batch of the workload, sample 0 kept: completion tokens, boxes, score logits and mask logits (valid
+    region) — what the oracle run of cpu_baseline_leg is compared with (the timed mode AND precision="reference" go through this)."""
+    from padt_amd.processor import parseVRTintoCompletion
+    L = inp["ids"].shape[1]
+    gids = inp["proc"].assign_to_global_vrt_id(inp["ids"].clone(), inp["grid"])
+    hout = model.generate(input_ids=gids, attention_mask=inp["am"], pixel_values=inp["pix"], image_grid_thw=inp["grid"], use_cache=True,
+                          max_new_tokens=args.tnew, do_sample=False, output_hidden_states=True, return_dict_in_generate=True, schedule=inp["sched"])
+    hseq = hout["sequences"].cpu()
+    hloc = inp["proc"].assign_to_local_vrt_id(hseq.clone(), inp["grid"].cpu())
+    _, hfeats, _, _, _ = parseVRTintoCompletion(inp["proc"], hloc[:, L:], hout["hidden_states"], torch.Tensor([False] * hseq.shape[0]))
+    hdec = model.vl_decode(hfeats, hout.past_image_embeds, hout.past_high_res_image_embeds, inp["grid"], hout.past_visual_pe)
+    sel = [i for i, si in enumerate(hdec["sample_idx"]) if int(si) == 0]
+    hw = hdec["pred_mask_valid_hw"]
+    masks = [hdec["pred_mask"][i, : int(hw[0][i]), : int(hw[1][i])].float().cpu() for i in sel] if hdec.get("pred_mask") is not None and len(hw) else []
+    return {"tokens": hseq[:1, L:], "boxes": [hdec["pred_boxes"][i].float().cpu().tolist() for i in sel],
+            "scores": [float(hdec["pred_score"][i].float().cpu().reshape(-1)[0]) for i in sel], "masks": masks}
+
+
+REFERENCE_SAMPLE0 = None     # reference_precision_leg leaves its hip_sample0() here for cpu_baseline_leg's parity read-out of that mode
+
+
+def parity_readout(hip, ores, odec, n_tok, side=(640, 640)):
+    """tokens / box IoU / |d box| / |d score logit| / mask-logit distance (max |d| over the valid region ÷ the oracle's logit range) of one
+    HIP answer (hip_sample0) against the oracle run of the same sample — north_star: ids bit-exact, boxes and mask logits within 1e-3."""
+    from padt_amd.postprocess import box_iou_xywh, box_to_pixels
+    hip_tok = hip["tokens"]
+    n_steps = min(len(ores["logits"]), hip_tok.shape[1], n_tok)
+    same = sum(int(torch.argmax(ores["logits"][t][0]).item() == int(hip_tok[0, t])) for t in range(n_steps))
+    oboxes = odec["pred_boxes"].float().tolist()
+    ious = [round(box_iou_xywh(box_to_pixels(hb, side[1], side[0]), box_to_pixels(ob, side[1], side[0])), 4) for hb, ob in zip(hip["boxes"], oboxes)]
+    out = {"tokens_equal_oracle_argmax": "%d/%d" % (same, n_steps), "box_iou_vs_oracle": ious,
+           "box_abs_diff_max": round(max((abs(a - b) for hb, ob in zip(hip["boxes"], oboxes) for a, b in zip(hb, ob)), default=0.0), 6)}
+    osc = odec["pred_score"].float().reshape(-1).tolist()
+    out["score_abs_max"] = round(max((abs(a - b) for a, b in zip(hip["scores"], osc)), default=0.0), 6)
+    om, ohw = odec.get("pred_mask"), odec.get("pred_mask_valid_hw")
+    if om is not None and hip["masks"]:
+        rel = []
+        for i, hm in enumerate(hip["masks"]):
+            o = om[i, : int(ohw[0][i]), : int(ohw[1][i])].float()
+            rel.append(((hm - o).abs().max() / (o.max() - o.min())).item() if hm.shape == o.shape else float("nan"))
+        out["mask_logits_rel_max"] = float("%.3e" % max(rel))
+    return out
+
+
 def cpu_baseline_leg(cfg, args, inp, model):
     """The fp32 CPU oracle (kind "port": the reference is Python and cannot travel to the GPU box) actually RUN on a bounded sample of
     the same workload: ONE image of the batch, same prompt, same scripted schedule, same random-init architecture — generate()
@@ -391,21 +436,11 @@ def cpu_baseline_leg(cfg, args, inp, model):
     ids, am = inp["ids"][:1].cpu(), inp["am"][:1].cpu()
     pix, grid = inp["pix"][:P].float().cpu(), inp["grid"][:1]
     T, sched = args.tnew, inp["sched"]
-    # the HIP path's own tokens and boxes for the same image (sample 0 of the batch: its global VRT ids are its local ones), so that the
-    # timed oracle run doubles as the parity check of the metric's "box IoU vs ref": the oracle is TEACHER-FORCED on the HIP tokens (same
-    # work per step as free running — it still computes every logit row; only the appended token is overridden)
-    from padt_amd.processor import parseVRTintoCompletion
-    from padt_amd.postprocess import box_iou_xywh, box_to_pixels
-    L = inp["ids"].shape[1]
-    gids = inp["proc"].assign_to_global_vrt_id(inp["ids"].clone(), inp["grid"])
-    hout = model.generate(input_ids=gids, attention_mask=inp["am"], pixel_values=inp["pix"], image_grid_thw=inp["grid"], use_cache=True,
-                          max_new_tokens=T, do_sample=False, output_hidden_states=True, return_dict_in_generate=True, schedule=sched)
-    hseq = hout["sequences"].cpu()
-    hloc = inp["proc"].assign_to_local_vrt_id(hseq.clone(), inp["grid"].cpu())
-    _, hfeats, _, _, _ = parseVRTintoCompletion(inp["proc"], hloc[:, L:], hout["hidden_states"], torch.Tensor([False] * hseq.shape[0]))
-    hdec = model.vl_decode(hfeats, hout.past_image_embeds, hout.past_high_res_image_embeds, inp["grid"], hout.past_visual_pe)
-    hip_boxes = [hdec["pred_boxes"][i].float().cpu().tolist() for i, si in enumerate(hdec["sample_idx"]) if int(si) == 0]
-    hip_tok = hseq[:1, L:]
+    # the HIP path's own tokens / boxes / score / mask logits for the same image (sample 0 of the batch: its global VRT ids are its local ones),
+    # so that the timed oracle run doubles as the parity check of the metric's "box IoU vs ref": the oracle is TEACHER-FORCED on the HIP tokens
+    # (same work per step as free running — it still computes every logit row; only the appended token is overridden)
+    hip = hip_sample0(model, inp, args)
+    hip_tok = hip["tokens"]
     with torch.no_grad():
         t0 = time.perf_counter()
         ores = O.generate(w, oc, ids, am, pix, grid, T, schedule=sched, force_tokens=hip_tok, collect_logits=True)
@@ -423,16 +458,17 @@ def cpu_baseline_leg(cfg, args, inp, model):
         odec = O.vl_decode(w, oc, feats, st.proto, st.high_res, grid, st.visual_pe)
         t_dec = time.perf_counter() - t1
     t_img = t_gen + t_dec
-    # parity read-out of the same run: how many HIP tokens are the oracle's own (scheduled) arg-max, and the IoU of the boxes (xywh pixel
-    # boxes as utils.py:258-260 derives them, IoU as eval_refcoco.py:15-41)
-    n_steps = min(len(ores["logits"]), hip_tok.shape[1])
-    same = sum(int(torch.argmax(ores["logits"][t][0]).item() == int(hip_tok[0, t])) for t in range(n_steps))
-    side = 640, 640                                                  # the synthetic image's own size (boxes are normalised; utils.py:258 scales by it)
-    ious = [round(box_iou_xywh(box_to_pixels(hb, side[1], side[0]), box_to_pixels(ob, side[1], side[0])), 4)
-            for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist())]
-    parity = {"tokens_equal_oracle_argmax": "%d/%d" % (same, n_steps), "box_iou_vs_oracle": ious,
-              "box_abs_diff_max": round(max((abs(a - b) for hb, ob in zip(hip_boxes, odec["pred_boxes"].float().tolist()) for a, b in zip(hb, ob)), default=0.0), 5),
-              "note": "sample 0 of the batch, oracle teacher-forced on the HIP tokens (%s-operand HIP path vs fp32 oracle, random-init weights)" % args.operands}
+    # parity read-out of the same run: how many HIP tokens are the oracle's own (scheduled) arg-max, the IoU of the boxes (xywh pixel boxes as
+    # utils.py:258-260 derives them, IoU as eval_refcoco.py:15-41), |d box|, |d score logit| and the mask-logit distance (the mask head is ON in
+    # the timed workload: padt_decoder.py:241-274) — for the timed mode and, when that leg ran, for precision="reference" on the same sample
+    parity = parity_readout(hip, ores, odec, hip_tok.shape[1])
+    parity["mode"] = "timed mode: %s MFMA operands (operands=%r), fp32 residual streams, split-precision PaDT decoder" % (args.operands, getattr(args, "policy", args.operands))
+    parity["note"] = "sample 0 of the batch, oracle teacher-forced on the HIP tokens (HIP path vs fp32 CPU oracle, random-init weights); mask_logits_rel_max = max |d| over the valid region / the oracle's logit range"
+    if REFERENCE_SAMPLE0 is not None:
+        rp = parity_readout(REFERENCE_SAMPLE0, ores, odec, hip_tok.shape[1])
+        rp["tokens_equal_timed_mode"] = bool(torch.equal(REFERENCE_SAMPLE0["tokens"], hip_tok))
+        rp["mode"] = "precision='reference' (the mode that keeps north_star's 1e-3 on every float output), same sample, same oracle run"
+        parity["reference_precision"] = rp
     return {"value": round(1.0 / t_img, 5), "unit": "images/s", "cores": cores, "kind": "port", "parity": parity,
             "sample": "1 image of the workload (L=%d, T_new=%d, %d object(s) x %d VRT), fp32 CPU oracle run end to end: generate %.2f s "
                       "(ViT + prefill + %d decode steps) + vl_decode %.2f s = %.2f s/image on %d threads of %d host cores"
@@ -498,8 +534,9 @@ def bf16_twin_leg(cfg, args, grid_hw, device):
 
 def reference_precision_leg(cfg, args, grid_hw, device):
     """The SAME workload with precision="reference" (padt_amd/reference.py: ViT / LLM on (hi, lo) bf16 GEMM operands at twice the MFMA work,
-    fp32 attention throughout incl. an fp32 KV cache, eager decode steps): the mode that meets the north star's 1e-3 on EVERY float output, mask
-    logits included (tests/test_reference_mode_gpu.py: full-depth 3B boxes 1.8e-6 / mask logits 2.7e-5, tokens equal) — its price next to the headline."""
+    exact-fp32 attention on the f32-input MFMA incl. an fp32 KV cache, captured decode steps): the mode that meets the north star's 1e-3 on EVERY
+    float output, mask logits included (tests/test_reference_mode_gpu.py: full-depth 3B boxes 1.8e-6 / mask logits 2.7e-5, tokens equal) — its
+    price next to the headline, same runner shape (depth x merge) as the headline."""
     import copy
     from padt_amd import pipeline
     from padt_amd.modeling import PaDTForConditionalGeneration
@@ -507,26 +544,29 @@ def reference_precision_leg(cfg, args, grid_hw, device):
     a.cap = 0
     m2 = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device=device, llm_weights="bf16", operands="fp16", precision="reference")
     inp2 = make_inputs(cfg, a, grid_hw, device, seed=1234, dtype=torch.float16)
-    r2 = pipeline.PipelinedRunner(m2, inp2["proc"], depth=2, merge=2)
+    r2 = pipeline.PipelinedRunner(m2, inp2["proc"], depth=a.depth, merge=a.merge)
 
     def rs(k):
         for _ in range(k):
             ids, am, pix = next_batch(inp2)
             r2.submit(ids, am, pix, inp2["grid"], max_new_tokens=a.tnew, schedule=inp2["sched"])
         r2.flush()
-    rs(4)
+    rs(a.depth * a.merge)                                              # priming: every lane allocates its session and captures its decode graph
     torch.cuda.synchronize()
-    steps = 8
+    steps = 2 * a.merge
     t0 = time.perf_counter()
     rs(steps)
     torch.cuda.synchronize()
     e = time.perf_counter() - t0
+    global REFERENCE_SAMPLE0
+    REFERENCE_SAMPLE0 = hip_sample0(m2, inp2, a)                       # same first batch as the headline's (seed 1234): cpu_baseline_leg compares it with the oracle
     del r2, m2, inp2
     torch.cuda.empty_cache()
     return {"value": round(a.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3),
-            "note": "precision='reference': split-precision (hi, lo) bf16 GEMM operands through ViT / merger / prototypes / LLM (2x the MFMA work), fp32 "
-                    "attention throughout (ViT, causal GQA prompt pass, decode steps over an fp32 KV cache), eager decode steps in groups of 2 batches; "
-                    "full-depth parity: boxes <= 3e-6 and mask logits <= 5e-5 on 3B / OVD geometry / 7B, tokens equal (tests/test_reference_mode_gpu.py)"}
+            "note": "precision='reference': split-precision (hi, lo) bf16 GEMM operands through ViT / merger / prototypes / LLM (2x the MFMA work), exact-fp32 "
+                    "attention on the f32-input MFMA (v_mfma_f32_16x16x4_f32: ViT windows / full layers, causal GQA prompt pass, decode steps over an fp32 KV "
+                    "cache), hipGraph-captured decode steps in groups of %d batches (round 5: VALU attention, eager steps, groups of 2: 24.3 images/s); parity of "
+                    "THIS run's first batch against the oracle: cpu_baseline.parity.reference_precision; full-depth suites: tests/test_reference_mode_gpu.py" % a.merge}
 
 
 def extra_workloads(args, device, model3b, cfg3b, grid3b):

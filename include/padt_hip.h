@@ -248,6 +248,14 @@ int padt_rope_half_f32(void* stream, void* x, long ldx, const void* cos_t, const
 int padt_attn_f32(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split, long ldo,
                   long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k, int n_heads,
                   int head_dim, float scale, int kv_group, int causal, const int* len_k);
+/* The same attention on the f32-input matrix cores (v_mfma_f32_16x16x4_f32: exact fp32 products and sums — an fmaf chain — at the fp32
+ * vector peak, VALU free for the softmax): same arguments and semantics, results equal up to fp32 summation order; head_dim 80 or 128.
+ * The reference-precision mode's ViT windows / full layers (HF:211-245), causal GQA prompt pass and decode steps over the fp32 cache
+ * (HF:641-689); with kv_group > 1 and fewer than 16 queries per segment the G heads of a group share one tile and the block's four
+ * waves split the keys. */
+int padt_attn_f32_mfma(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split, long ldo,
+                  long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k, int n_heads,
+                  int head_dim, float scale, int kv_group, int causal, const int* len_k);
 /* padt_mask_scatter on fp32 e2 / mask tokens. */
 int padt_mask_scatter_f32(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
                           const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm);

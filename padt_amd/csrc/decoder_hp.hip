@@ -503,6 +503,280 @@ extern "C" int padt_attn_f32(void* stream, const void* q, long ldq, const void* 
     return 0;
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// fp32 attention on the f32-input matrix cores (round 6): softmax(q k^T * scale) v with EXACT fp32 operands through
+// v_mfma_f32_16x16x4_f32 (bit for bit an fmaf chain; 64 FLOP / clk / SIMD = the fp32 vector peak, reached from one wave per SIMD and with
+// the VALU free for the softmax).  The reference-precision mode (padt_amd/reference.py) ran every attention of ViT and LLM on the VALU
+// kernels above — 40 % of its time (profiles/r05_reference_precision_kernel_stats.md): 2116 x 2116 ViT layers 11.6 ms, a causal
+// 577-token prompt layer 1.75 ms.  Same arguments and semantics as padt_attn_f32 (GQA, bottom-right causal mask, per-segment key counts
+// over a strided cache, split (hi | lo) output rows).
+//
+// Everything is computed TRANSPOSED so that a lane owns one query column from the first MFMA to the store (as csrc/attention.hip does
+// for 16-bit operands): S^T = K Q^T — lane (j, g) = (lane & 15, lane >> 4) ends up with S^T[key 4g + r][query j], r = 0..3 — the row
+// max / sum are in-lane plus two shuffles across g, and those four registers ARE the B operand of O^T = V^T P^T under the key permutation
+// "k-slot g of MFMA r = key 4g + r", which the V^T operand applies too.  The contraction index of Q K^T is permuted likewise so that every
+// lane reads CONTIGUOUS floats: k-slot g of MFMA (c, e) = d = g * D/4 + 4c + e → lane (i, g) holds row i's chunk [g D/4, (g + 1) D/4) of K
+// (and of Q) as D/16 float4 loads; the A-row index i of a V^T d-tile n maps to d = i * D/16 + n (D = 128: 8 contiguous floats per lane
+// and key) or, for D = 80, d = 4i + n (n < 4) and 64 + i (n = 4): one float4 + one float.  Operands go global / L2 → registers directly
+// (no LDS): a wave carries QT tiles of 16 queries, so each K / V fragment feeds QT MFMAs.
+// Column modes: token mode — column c of a wave = query token qbase + c of head blockIdx.y; head mode (few queries per segment: the
+// decode steps) — column c = (token qbase + c / G, head hk G + c % G) of kv head hk = blockIdx.y, so the G query heads of a GQA group
+// share every K / V fragment.
+struct AttnMfmaArgs {
+    AttnF32Args a;
+    int head_mode;       // 0 token mode, 1 head mode
+};
+
+template <int D>
+struct VMap {            // lane (i = lane & 15) of V^T d-tile n ↔ d
+    static constexpr int NT = D / 16;
+};
+
+// KS (head mode): the 4 waves of a block take the SAME query columns and every fourth 32-key block each; their (m, l, O) states are merged
+// through LDS by wave 0 — a decode step has one query token per segment, so the key range is the only parallelism a block has.
+template <int D, int QT, bool KS>
+__global__ __launch_bounds__(256, 2) void attn_f32_mfma_kernel(AttnMfmaArgs pa) {
+    static_assert(D == 128 || D == 80, "head widths of LLM (128) and ViT / PaDT decoder (80)");
+    const AttnF32Args& p = pa.a;
+    constexpr int C4 = D / 16;                  // float4 pieces of a lane's K / Q chunk (D/4 floats)
+    constexpr int NT = D / 16;                  // 16-row d-tiles of O^T
+    constexpr int COLS = 16 * QT;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int seg = blockIdx.z;
+    const int qs0 = p.cu_q[seg], nq_seg = p.cu_q[seg + 1] - qs0;
+    const int k0 = p.cu_k[seg], nk = p.len_k ? p.len_k[seg] : p.cu_k[seg + 1] - k0;
+    const int G = p.kv_group;
+    const int tpw = pa.head_mode ? COLS / G : COLS;                     // query tokens per wave
+    const int qbase = (KS ? blockIdx.x : blockIdx.x * 4 + wave) * tpw;  // first token (within the segment) of this wave
+    if (qbase >= nq_seg) return;                                        // (KS: block-uniform, so nobody waits at the merge barrier)
+    const int hk = pa.head_mode ? blockIdx.y : blockIdx.y / G;
+    const int shift = p.causal ? nk - nq_seg : nk;                      // query at segment position i sees keys 0 .. i + shift
+    // ---- per q-tile: this lane's query column
+    int q_pos[QT];            // position within the segment (clamped for loads)
+    bool q_ok[QT];
+    long q_off[QT];           // element offset of the column's head row in q / out coordinates: token * ld + head * D
+    int q_head[QT];
+    f32x4 qf[QT][C4];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        const int c = t * 16 + j;
+        int tok = pa.head_mode ? qbase + c / G : qbase + c;
+        const int hh = pa.head_mode ? hk * G + c % G : blockIdx.y;
+        q_ok[t] = tok < nq_seg && (!pa.head_mode || c / G < tpw);
+        tok = tok < nq_seg ? tok : nq_seg - 1;
+        q_pos[t] = tok;
+        q_head[t] = hh;
+        const float* qr = p.q + (long)(qs0 + tok) * p.ldq + (long)hh * D + g * (D / 4);
+#pragma unroll
+        for (int c4 = 0; c4 < C4; ++c4) {
+            f32x4 v = *reinterpret_cast<const f32x4*>(qr + 4 * c4);
+            qf[t][c4] = v * p.scale;
+        }
+    }
+    // last key any column of this wave may see (causal: the wave's last token)
+    int k_end = nk;
+    if (p.causal) {
+        int last = qbase + tpw - 1;
+        last = last < nq_seg ? last : nq_seg - 1;
+        k_end = last + shift + 1;
+        k_end = k_end < nk ? k_end : nk;
+    }
+    f32x4 o[QT][NT];
+    float m[QT], l[QT];
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        m[t] = -INFINITY; l[t] = 0.f;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[t][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const float* kbase = p.k + (long)k0 * p.ldk + (long)hk * D + g * (D / 4);
+    const float* vbase = p.v + (long)k0 * p.ldv + (long)hk * D;
+    constexpr int KB = 32;                                             // keys per softmax step (two 16-key MFMA tiles)
+    for (int kb = KS ? wave * KB : 0; kb < k_end; kb += KS ? 4 * KB : KB) {
+        f32x4 s[QT][2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            int key = kb + u * 16 + j;                                 // A row i = j: this lane's key row of tile u
+            key = key < nk ? key : nk - 1;
+            const float* kr = kbase + (long)key * p.ldk;
+            f32x4 kf[C4];
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4) kf[c4] = *reinterpret_cast<const f32x4*>(kr + 4 * c4);
+#pragma unroll
+            for (int t = 0; t < QT; ++t) s[t][u] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int c4 = 0; c4 < C4; ++c4)
+#pragma unroll
+                for (int e = 0; e < 4; ++e)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) s[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(kf[c4][e], qf[t][c4][e], s[t][u], 0, 0, 0);
+        }
+        // ---- mask + online softmax (per query column; the 4 lanes g = 0..3 of a column share m)
+        float alpha[QT];
+#pragma unroll
+        for (int t = 0; t < QT; ++t) {
+            const int vis = p.causal ? q_pos[t] + shift : nk - 1;      // last visible key of this column
+            float mx = -INFINITY;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = kb + u * 16 + 4 * g + r;
+                    const bool ok = key < nk && key <= vis;
+                    s[t][u][r] = ok ? s[t][u][r] : -INFINITY;
+                    mx = fmaxf(mx, s[t][u][r]);
+                }
+            mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+            mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+            const float m_new = fmaxf(m[t], mx);
+            // a column that has seen no visible key yet keeps m = -inf: exp(-inf - -inf) must not be NaN
+            const float m_use = m_new == -INFINITY ? 0.f : m_new;
+            alpha[t] = expf(m[t] - m_use);                             // first visible block: exp(-inf) = 0
+            float sum = 0.f;
+#pragma unroll
+            for (int u = 0; u < 2; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const float pj = expf(s[t][u][r] - m_use);
+                    s[t][u][r] = pj;
+                    sum += pj;
+                }
+            l[t] = l[t] * alpha[t] + sum;                              // per-lane partial; reduced across g at the end
+            m[t] = m_new;
+#pragma unroll
+            for (int n = 0; n < NT; ++n) o[t][n] *= alpha[t];
+        }
+        // ---- O^T += V^T P^T: A[i][k-slot g] = V[key u 16 + 4g + r][dmap(i, n)], B = the P registers
+#pragma unroll
+        for (int u = 0; u < 2; ++u)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int key = kb + u * 16 + 4 * g + r;
+                key = key < nk ? key : nk - 1;                         // P is exactly 0 there
+                const float* vr = vbase + (long)key * p.ldv;
+                float vf[NT];
+                if constexpr (D == 128) {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(vr + 8 * j), a1 = *reinterpret_cast<const f32x4*>(vr + 8 * j + 4);
+                    vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a0[2]; vf[3] = a0[3]; vf[4] = a1[0]; vf[5] = a1[1]; vf[6] = a1[2]; vf[7] = a1[3];
+                } else {
+                    const f32x4 a0 = *reinterpret_cast<const f32x4*>(vr + 4 * j);
+                    vf[0] = a0[0]; vf[1] = a0[1]; vf[2] = a0[2]; vf[3] = a0[3]; vf[4] = vr[64 + j];
+                }
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int t = 0; t < QT; ++t) o[t][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(vf[n], s[t][u][r], o[t][n], 0, 0, 0);
+            }
+    }
+    if constexpr (KS) {
+        // ---- merge the 4 waves' partial states (disjoint key sets of the same columns): wave 0 rescales each to the common maximum
+        static_assert(QT == 1, "head mode runs one query tile per wave");
+        __shared__ float mst[3][64][NT * 4 + 2];
+        if (wave > 0) {
+            float* dst = mst[wave - 1][lane];
+            dst[0] = m[0]; dst[1] = l[0];
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) dst[2 + n * 4 + r] = o[0][n][r];
+        }
+        __syncthreads();
+        if (wave > 0) return;
+        float mw[3], mm = m[0];
+#pragma unroll
+        for (int w = 0; w < 3; ++w) { mw[w] = mst[w][lane][0]; mm = fmaxf(mm, mw[w]); }
+        const float m_use = mm == -INFINITY ? 0.f : mm;
+        const float f0 = expf(m[0] - m_use);
+        l[0] *= f0;
+#pragma unroll
+        for (int n = 0; n < NT; ++n) o[0][n] *= f0;
+#pragma unroll
+        for (int w = 0; w < 3; ++w) {
+            const float f = expf(mw[w] - m_use);
+            const float* src = mst[w][lane];
+            l[0] += src[1] * f;
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) o[0][n][r] += src[2 + n * 4 + r] * f;
+        }
+    }
+    // ---- normalise and store split rows: lane (j, g) holds O[query j][d = dmap(4g + r, n)]
+#pragma unroll
+    for (int t = 0; t < QT; ++t) {
+        float ls = l[t];
+        ls += __shfl_xor(ls, 16, 64);
+        ls += __shfl_xor(ls, 32, 64);
+        if (!q_ok[t]) continue;
+        const float inv = ls > 0.f ? 1.f / ls : 0.f;                   // a query without visible keys yields a zero row, not NaN
+        const long row = (long)(qs0 + q_pos[t]) * p.ldo;
+        const int col0 = q_head[t] * D;
+        if constexpr (D == 128) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                float v4[4];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) v4[e] = o[t][half * 4 + e][r] * inv;
+                    split_store4(p.out, row, col0 + 8 * (4 * g + r) + 4 * half, p.chunk, v4);
+                }
+            }
+        } else {
+            float v4[4];
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v4[e] = o[t][e][r] * inv;
+                split_store4(p.out, row, col0 + 4 * (4 * g + r), p.chunk, v4);
+            }
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v4[r] = o[t][4][r] * inv;
+            split_store4(p.out, row, col0 + 64 + 4 * g, p.chunk, v4);
+        }
+    }
+}
+
+template <int D>
+static void launch_attn_f32_mfma(const AttnF32Args& a, int nseg, int max_q, int n_heads, hipStream_t s) {
+    const int G = a.kv_group;
+    // head mode pays when a segment has too few queries to fill 16 columns with tokens of ONE head and the group fits a tile
+    const bool head_mode = G > 1 && G <= 16 && max_q < 16;
+    AttnMfmaArgs pa{a, head_mode ? 1 : 0};
+    if (head_mode) {
+        const int tpw = 16 / G;
+        hipLaunchKernelGGL((attn_f32_mfma_kernel<D, 1, true>), dim3((max_q + tpw - 1) / tpw, n_heads / G, nseg), dim3(256), 0, s, pa);
+    } else if (max_q > 16) {
+        hipLaunchKernelGGL((attn_f32_mfma_kernel<D, 2, false>), dim3((max_q + 127) / 128, n_heads, nseg), dim3(256), 0, s, pa);
+    } else {
+        hipLaunchKernelGGL((attn_f32_mfma_kernel<D, 1, false>), dim3((max_q + 63) / 64, n_heads, nseg), dim3(256), 0, s, pa);
+    }
+}
+
+// padt_attn_f32 on the f32-input MFMA (same arguments, same results up to fp32 summation order); head_dim 80 or 128.
+extern "C" int padt_attn_f32_mfma(void* stream, const void* q, long ldq, const void* k, long ldk, const void* v, long ldv, void* out_split,
+                                  long ldo, long chunk, const int* cu_q, const int* cu_k, int nseg, int max_seqlen_q, int max_seqlen_k,
+                                  int n_heads, int head_dim, float scale, int kv_group, int causal, const int* len_k) {
+    if (nseg <= 0 || max_seqlen_q <= 0) return 0;
+    if (kv_group < 1 || n_heads % kv_group) { padt_set_error("padt_attn_f32_mfma: kv_group must divide n_heads"); return -1; }
+    if ((ldq & 3) || (ldk & 3) || (ldv & 3) || (ldo & 3) || (chunk & 3) || chunk <= 0 || ((uintptr_t)q & 15) || ((uintptr_t)k & 15) ||
+        ((uintptr_t)v & 15) || ((uintptr_t)out_split & 7) || max_seqlen_k <= 0 || nseg > 65535 || n_heads > 65535) {
+        padt_set_error("padt_attn_f32_mfma: strides / chunk multiples of 4, 16-byte aligned q/k/v, nseg and n_heads <= 65535");
+        return -1;
+    }
+    AttnF32Args a{(const float*)q, ldq, (const float*)k, ldk, (const float*)v, ldv, (x16_t*)out_split, ldo, (int)chunk, cu_q, cu_k, scale, kv_group,
+                  causal ? 1 : 0, len_k};
+    hipStream_t s = (hipStream_t)stream;
+    switch (head_dim) {
+        case 80: launch_attn_f32_mfma<80>(a, nseg, max_seqlen_q, n_heads, s); break;
+        case 128: launch_attn_f32_mfma<128>(a, nseg, max_seqlen_q, n_heads, s); break;
+        default: padt_set_error("padt_attn_f32_mfma: head_dim must be 80 or 128"); return -1;
+    }
+    PADT_CHECK_LAUNCH("attn_f32_mfma");
+    return 0;
+}
+
 extern "C" int padt_mask_scatter_f32(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,
                                      const int* obj_w, void* masks_f32, int n_obj, long total_patches, int Hm4, int Wm4, int dm) {
     if (n_obj <= 0 || total_patches <= 0) return 0;

@@ -187,7 +187,6 @@ class DecodeSession:
         self.np_cur = np_max
         self.step_fn = None              # precision="reference": the eager split-precision decode step (reference.ReferencePath.step) instead of step_kernels
         self.hid32 = None                # ... and its fp32 per-step hidden rows [t_max][B][D]
-        self.ref_step = 0
 
     # one decode step, all on the current stream (eager or under capture)
     def step_kernels(self):
@@ -282,24 +281,21 @@ class DecodeSession:
     def run_steps(self, n: int, use_graph: bool = True):
         if n <= 0:
             return
-        if self.step_fn is not None:                         # reference-precision mode: eager by construction
-            for _ in range(n):
-                self.step_fn(self)
-            return
+        one_step = self.step_kernels if self.step_fn is None else (lambda: self.step_fn(self))    # reference precision: reference.ReferencePath.step
         if not use_graph:
             for _ in range(n):
-                self.step_kernels()
+                one_step()
             return
-        gkey = (self.do_sample, self.keep_scores)            # different kernel sequences → one captured graph per mode
+        gkey = (self.do_sample, self.keep_scores, self.step_fn is not None)   # different kernel sequences → one captured graph per mode
         if gkey not in self.graphs:
-            self.step_kernels()                              # real step; also pays every one-time kernel attribute call
+            one_step()                                       # real step; also pays every one-time kernel attribute call
             n -= 1
             g = torch.cuda.CUDAGraph()
             # thread_local: only THIS thread's calls are checked during capture.  With world > 1 the process group's watchdog thread polls
             # the events of an in-flight result gather (pipeline.ResultExchange) while a later lane captures its graph; under the default
             # global mode such a query from another thread invalidates the capture.
             with torch.cuda.graph(g, capture_error_mode="thread_local"):
-                self.step_kernels()
+                one_step()
             self.graphs[gkey] = g
         t = ops.STEP_TIMER
         ev = t.begin() if t is not None else None

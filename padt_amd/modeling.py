@@ -401,7 +401,6 @@ class PaDTForConditionalGeneration:
                 sess.step_fn = self.ref.step
                 if sess.hid32 is None or sess.hid32.shape[0] < T_max:
                     sess.hid32 = torch.zeros((sess.t_max, sess.B, cfg.hidden_size), device=dev, dtype=torch.float32)
-                sess.ref_step = 1                                 # row 0 = the last prompt position (written by each batch's prompt pass)
         else:
             sess = group["sess"]
             if (group["launched"] or k >= group["n_slots"] or B != group["B"] or T_max != group["T_max"]

@@ -818,7 +818,7 @@ def scatter_rows_f32(src, idx, dst, D=None):
     return dst
 
 
-def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, out=None, kv_group=1, causal=False, len_k=None):
+def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, out=None, kv_group=1, causal=False, len_k=None, mfma=False):
     """fp32 varlen attention → split rows (Tq, 2*n_heads*head_dim) bf16.  kv_group: q heads per kv head (GQA); causal: bottom-right aligned
     mask; len_k (int32 device, per segment): key counts for segments that start at cu_k[s] and are not packed back to back (a KV cache)."""
     assert q.dtype == F32 and k.dtype == F32 and v.dtype == F32 and cu_q.dtype == torch.int32 and cu_k.dtype == torch.int32
@@ -826,7 +826,8 @@ def attn_f32(q, k, v, cu_q, cu_k, max_q, max_k, n_heads, head_dim, scale=None, o
     if out is None:
         out = torch.empty((q.shape[0], 2 * Dm), device=q.device, dtype=BF16)
     scale = head_dim ** -0.5 if scale is None else scale
-    _lib.check(_lib.load().padt_attn_f32(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), Dm,
+    fn = _lib.load().padt_attn_f32_mfma if mfma else _lib.load().padt_attn_f32     # mfma: v_mfma_f32_16x16x4_f32 (head_dim 80 / 128)
+    _lib.check(fn(_stream(), _p(q), q.stride(0), _p(k), k.stride(0), _p(v), v.stride(0), _p(out), out.stride(0), Dm,
                                          _p(cu_q), _p(cu_k), cu_q.numel() - 1, int(max_q), int(max_k), n_heads, head_dim, float(scale), int(kv_group),
                                          1 if causal else 0, _p(len_k)),
                "padt_attn_f32")

@@ -91,7 +91,6 @@ class ReferencePath:
         self.cfg, self.m, self.device = cfg, model, model.device
         assert model.dtype == F16, "the reference-precision path runs its LLM attention on the fp16 instantiation"
         self.R = prepare_reference_weights(state_dict, cfg, self.device)
-        self._tables = {}
 
     # ------------------------------------------------------------------ ViT (padt.py:48-106)
     def visual(self, pixel_values, grid_thw, nf=None):
@@ -116,7 +115,7 @@ class ReferencePath:
             n, _ = ops.norm_split(x32, R[d + "norm1"], eps=1e-6)
             qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"])             # (P, 3 vh) fp32
             ops.rope_half_f32_(qkv, plan.cos, plan.sin, 2 * H, hd)             # q and k are adjacent in the fused row
-            a = ops.attn_f32(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:3 * vh], cu, cu, mx, mx, H, hd)
+            a = ops.attn_f32(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:3 * vh], cu, cu, mx, mx, H, hd, mfma=hd in (80, 128))
             ops.gemm_hp(a, R[d + "proj.hp"], R[d + "proj.b"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
             n, _ = ops.norm_split(x32, R[d + "norm2"], eps=1e-6)
             gu = ops.gemm_hp(n, R[d + "gu.hp"], R[d + "gu.b"])
@@ -134,19 +133,14 @@ class ReferencePath:
     # ------------------------------------------------------------------ the fp32 embedding table of a session
     def table(self, sess):
         """[E ‖ prototypes (np_max rows) ‖ image rows (np_max rows: a batch has as many merged image tokens as prototypes)] in fp32, one per
-        decode session: every embedding the LLM consumes is a row of it."""
+        decode session and owned by it (the captured decode graph holds its address): every embedding the LLM consumes is a row of it."""
         cfg = self.cfg
-        key = id(sess)
-        t = self._tables.get(key)
-        need = cfg.vocab_size + 2 * sess.np_max
-        if t is None or t[0] is not sess or t[1].shape[0] < need:
-            buf = torch.empty((need, cfg.hidden_size), device=self.device, dtype=F32)
-            buf[: cfg.vocab_size].copy_(self.R["llm.embed32"])
-            if len(self._tables) >= 8:
-                self._tables.pop(next(iter(self._tables)))
-            t = (sess, buf)
-            self._tables[key] = t
-        return t[1]
+        t = getattr(sess, "ref_table", None)
+        if t is None:
+            t = torch.empty((cfg.vocab_size + 2 * sess.np_max, cfg.hidden_size), device=self.device, dtype=F32)
+            t[: cfg.vocab_size].copy_(self.R["llm.embed32"])
+            sess.ref_table = t
+        return t
 
     def prototypes(self, low32, sess, proto_row0, nf=None):
         """padt.py:187-191 in fp32 / split precision → the session's fp32 table rows AND its fp16 prototype table (head, range checks)."""
@@ -227,7 +221,7 @@ class ReferencePath:
                 kv = qkv[:, Hq * hd:]
                 ops.gather_rows(kv, src, out=kvc[i][first_row * S: (first_row + B) * S], D=2 * Hkv * hd)
                 return ops.attn_f32(qkv[:, : Hq * hd], kv[:, : Hkv * hd], kv[:, Hkv * hd:], plan.cu, plan.cu, mx, mx, Hq, hd,
-                                    kv_group=Hq // Hkv, causal=True)
+                                    kv_group=Hq // Hkv, causal=True, mfma=hd in (80, 128))
             self._layer(i, x32, attention)
         hn, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
         if nf is not None:
@@ -235,7 +229,9 @@ class ReferencePath:
         return hn
 
     def step(self, sess):
-        """One decode step for every row of the session (eager; the default path's step_kernels with split-precision projections and fp32 attention)."""
+        """One decode step for every row of the session: the default path's step_kernels with split-precision projections and fp32 attention on
+        the f32-input MFMA.  No host-side state and no host-dependent argument: DecodeSession.run_steps captures it into a hipGraph like the
+        default step (round 6; round 5 ran it eagerly, 10 launches per layer from Python)."""
         cfg = self.cfg
         Hq, Hkv, hd = cfg.num_attention_heads, cfg.num_key_value_heads, cfg.head_dim
         B = sess.B
@@ -250,13 +246,10 @@ class ReferencePath:
                 ops.rope_half_f32_(qkv, cos, sin, Hq + Hkv, hd)
                 ops.scatter_rows_f32(qkv[:, Hq * hd:], where, kvc[i], D=2 * Hkv * hd)
                 return ops.attn_f32(qkv[:, : Hq * hd], kvc[i][:, : Hkv * hd], kvc[i][:, Hkv * hd:], sess.cu_q1, sess.cu_k32, 1, sess.s_max, Hq, hd,
-                                    kv_group=Hq // Hkv, len_k=sess.lens)
+                                    kv_group=Hq // Hkv, len_k=sess.lens, mfma=hd in (80, 128))
             self._layer(i, x32, attention)
         hn32, _ = ops.norm_split(x32, self.R["llm.norm"], eps=cfg.rms_norm_eps, y0_mode=ops.OUT_F32)
         ops.cast_f32_x16(hn32, out=sess.hn)
         ops.check_finite(hn32, sess.nf, rows_per_flag=1, rows=B)
-        t = sess.ref_step
-        if t < sess.hid32.shape[0]:
-            sess.hid32[t].copy_(hn32)
-        sess.ref_step = t + 1
+        ops.stash_step_f32(hn32, sess.step, sess.hid32)                        # hid32[*step] = this step's rows (device counter: the step is graph-replayable)
         sess.head_and_select(sess.hn, advance=True)

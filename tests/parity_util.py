@@ -86,8 +86,13 @@ class operand_floor:
     dtype: torch.bfloat16 (8 mantissa bits) or torch.float16 (11).  The PaDT decoder is left alone (call vl_decode outside the context;
     the HIP decoder runs split-precision operands)."""
 
-    def __init__(self, dtype=torch.bfloat16, classes=OPERAND_CLASSES):
+    def __init__(self, dtype=torch.bfloat16, classes=OPERAND_CLASSES, gemm=None):
+        """gemm (round 6, tests/studies/split_fp8_floor.py): optional callable (x, w, b, cls) → F.linear-like result that REPLACES the plain
+        "round the activation operand, multiply" of the projection sites (classes *.rows / *.ao / *.hid / vit.misc) — a model of a GEMM with a
+        different operand scheme (e.g. an fp16 hi term plus an fp8 lo term against an fp8 weight image); the attention-internal classes
+        (*.qkv, *.p) and the head keep the rounding of `dtype`."""
         self.dtype = dtype
+        self.gemm = gemm
         self.classes = frozenset(classes)
         unknown = self.classes - set(OPERAND_CLASSES)
         if unknown:
@@ -100,14 +105,20 @@ class operand_floor:
 
         def rd(t, cls):
             return t.to(dt).to(torch.float32) if cls in on else t
+        gemm = self.gemm
+
+        def mm(x, w, b, cls):                                        # one projection site
+            if gemm is not None and cls in on:
+                return gemm(x, w, b, cls)
+            return F.linear(rd(x, cls), w, b)
 
         def linear(x, w, b=None):                                    # the sites outside the blocks: patch embed, merger, prototypes
-            return F.linear(rd(x, "vit.misc"), w, b)
+            return mm(x, w, b, "vit.misc")
 
         def vit_block(w, pfx, cfg, x, cu, cos, sin):
             H, T = cfg.vit_heads, x.shape[0]
-            n = rd(O.rms_norm(x, w[pfx + "norm1.weight"], 1e-6), "vit.rows")
-            qkv = F.linear(n, w[pfx + "attn.qkv.weight"], w[pfx + "attn.qkv.bias"]).reshape(T, 3, H, -1)
+            n = O.rms_norm(x, w[pfx + "norm1.weight"], 1e-6)
+            qkv = mm(n, w[pfx + "attn.qkv.weight"], w[pfx + "attn.qkv.bias"], "vit.rows").reshape(T, 3, H, -1)
             q, k, v = qkv.permute(1, 0, 2, 3).unbind(0)
             c, s = cos.unsqueeze(-2).float(), sin.unsqueeze(-2).float()
             q, k, v = rd(q * c + O.rotate_half(q) * s, "vit.qkv"), rd(k * c + O.rotate_half(k) * s, "vit.qkv"), rd(v, "vit.qkv")
@@ -118,18 +129,18 @@ class operand_floor:
                 sc = torch.matmul(qs, ks.transpose(1, 2)) * (q.shape[-1] ** -0.5)
                 e = torch.exp(sc - sc.max(-1, keepdim=True).values)
                 a[a0:a1] = (torch.matmul(rd(e, "vit.p"), vs) / e.sum(-1, keepdim=True)).transpose(0, 1)
-            x = x + F.linear(rd(a.reshape(T, -1), "vit.ao"), w[pfx + "attn.proj.weight"], w[pfx + "attn.proj.bias"])
-            n = rd(O.rms_norm(x, w[pfx + "norm2.weight"], 1e-6), "vit.rows")
-            g = F.linear(n, w[pfx + "mlp.gate_proj.weight"], w[pfx + "mlp.gate_proj.bias"])
-            u = F.linear(n, w[pfx + "mlp.up_proj.weight"], w[pfx + "mlp.up_proj.bias"])
-            return x + F.linear(rd(F.silu(g) * u, "vit.hid"), w[pfx + "mlp.down_proj.weight"], w[pfx + "mlp.down_proj.bias"])
+            x = x + mm(a.reshape(T, -1), w[pfx + "attn.proj.weight"], w[pfx + "attn.proj.bias"], "vit.ao")
+            n = O.rms_norm(x, w[pfx + "norm2.weight"], 1e-6)
+            g = mm(n, w[pfx + "mlp.gate_proj.weight"], w[pfx + "mlp.gate_proj.bias"], "vit.rows")
+            u = mm(n, w[pfx + "mlp.up_proj.weight"], w[pfx + "mlp.up_proj.bias"], "vit.rows")
+            return x + mm(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"], w[pfx + "mlp.down_proj.bias"], "vit.hid")
 
         def llm_layer(w, pfx, cfg, h, cos, sin, attn_bias, cache, li):
             B, Lq, _ = h.shape
-            n = rd(O.rms_norm(h, w[pfx + "input_layernorm.weight"], cfg.rms_eps), "llm.rows")
-            q = F.linear(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"]).view(B, Lq, cfg.num_heads, cfg.head_dim)
-            k = F.linear(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
-            v = F.linear(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"]).view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            n = O.rms_norm(h, w[pfx + "input_layernorm.weight"], cfg.rms_eps)
+            q = mm(n, w[pfx + "self_attn.q_proj.weight"], w[pfx + "self_attn.q_proj.bias"], "llm.rows").view(B, Lq, cfg.num_heads, cfg.head_dim)
+            k = mm(n, w[pfx + "self_attn.k_proj.weight"], w[pfx + "self_attn.k_proj.bias"], "llm.rows").view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
+            v = mm(n, w[pfx + "self_attn.v_proj.weight"], w[pfx + "self_attn.v_proj.bias"], "llm.rows").view(B, Lq, cfg.num_kv_heads, cfg.head_dim)
             c, s = cos.unsqueeze(2), sin.unsqueeze(2)
             q, k, v = rd(q * c + O.rotate_half(q) * s, "llm.qkv"), rd(k * c + O.rotate_half(k) * s, "llm.qkv"), rd(v, "llm.qkv")
             if cache is not None:
@@ -141,11 +152,11 @@ class operand_floor:
             sc = torch.matmul(qh, kh.transpose(2, 3)) * (cfg.head_dim ** -0.5) + attn_bias
             e = torch.exp(sc - sc.max(-1, keepdim=True).values)
             a = (torch.matmul(rd(e, "llm.p"), vh) / e.sum(-1, keepdim=True)).transpose(1, 2).reshape(B, Lq, -1)
-            h = h + F.linear(rd(a, "llm.ao"), w[pfx + "self_attn.o_proj.weight"])
-            n = rd(O.rms_norm(h, w[pfx + "post_attention_layernorm.weight"], cfg.rms_eps), "llm.rows")
-            g = F.linear(n, w[pfx + "mlp.gate_proj.weight"])
-            u = F.linear(n, w[pfx + "mlp.up_proj.weight"])
-            return h + F.linear(rd(F.silu(g) * u, "llm.hid"), w[pfx + "mlp.down_proj.weight"])
+            h = h + mm(a, w[pfx + "self_attn.o_proj.weight"], None, "llm.ao")
+            n = O.rms_norm(h, w[pfx + "post_attention_layernorm.weight"], cfg.rms_eps)
+            g = mm(n, w[pfx + "mlp.gate_proj.weight"], None, "llm.rows")
+            u = mm(n, w[pfx + "mlp.up_proj.weight"], None, "llm.rows")
+            return h + mm(F.silu(g) * u, w[pfx + "mlp.down_proj.weight"], None, "llm.hid")
 
         def vrt_logits(w, cfg, hidden, proto, lmask):
             return self._saved["vrt_logits"](w, cfg, rd(hidden, "head"), rd(proto, "head"), lmask)

@@ -175,8 +175,8 @@ def test_range_guard_is_per_batch_inside_a_merged_decode_group():
 def test_range_guard_with_a_vit_stream_flags_a_vit_overflow_in_the_second_batch_of_a_group():
     """with PipelinedRunner(vit_stream=True) the ViT / prototype checks of batch k > 0 run on the ViT stream, which does not wait for
     the prefill stream — the batch's flag must be zeroed on the stream that ORs into it first.  Batch B (k = 1 of a 2-batch decode group) carries
-    a pixel column that the edited patch embedding drives past 65504 (fp16 inf in the ViT stream rows); batch A does not: B is re-run on the
-    bf16 twin, A keeps its fp16 result bit for bit."""
+    a pixel column that the edited patch embedding turns into a massive stream channel, which block 0's SwiGLU hidden cannot hold in fp16;
+    batch A does not: B is re-run on the bf16 twin, A keeps its fp16 result bit for bit."""
     if not torch.cuda.is_available():
         pytest.skip("no GPU")
     import padt_amd
@@ -186,8 +186,13 @@ def test_range_guard_with_a_vit_stream_flags_a_vit_overflow_in_the_second_batch_
     cfg = padt_amd.small_test_config()
     w = U.bf16_weights(cfg, seed=23, std=0.05)
     COL = 11
-    w["visual.patch_embed.proj.weight"] = w["visual.patch_embed.proj.weight"].clone()
+    for k in ("visual.patch_embed.proj.weight", "visual.blocks.0.mlp.gate_proj.weight", "visual.blocks.0.mlp.up_proj.weight"):
+        w[k] = w[k].clone()
+    # batch B's pixel column drives channel 7 of the (fp32) ViT stream to 1.3e5 from the first row on; block 0's norm2 then hands ~sqrt(D) in
+    # that channel to gate / up rows 3: silu(g) * u ≈ (64 * 11)^2 = 5e5 > 65504 → the fp16 SwiGLU hidden overflows (batch A: ≈ 64^2, finite)
     w["visual.patch_embed.proj.weight"].view(cfg.vision_config.hidden_size, -1)[7, COL] = 8192.0
+    w["visual.blocks.0.mlp.gate_proj.weight"][3, 7] = 64.0
+    w["visual.blocks.0.mlp.up_proj.weight"][3, 7] = 64.0
     T = 8
     sched = U.rec_schedule(T, vrt_at=range(2, 5))
     proc = padt_amd.VisonTextProcessingClass(U.FakeProcessor(cfg, 40), 2)

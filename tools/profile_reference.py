@@ -1,4 +1,4 @@
-"""One batch of the bench workload (8 images, T_new = 28) through precision="reference" for a kernel trace:
+"""The bench workload (batches of 8 images, T_new = 28) through precision="reference" on the bench leg's runner (32 batches) for a kernel trace:
     cd /tmp && rocprofv3 --kernel-trace -d out -o trace -- python $REPO/tools/profile_reference.py   (then tools/rocpd_stats.py)"""
 import os
 import sys
@@ -21,13 +21,22 @@ def main():
     model = PaDTForConditionalGeneration.from_synthetic(cfg, seed=0, device="cuda:0", operands="fp16", precision="reference")
     args.operands, args.policy = "fp16", "fp16"
     inp = bench.make_inputs(cfg, args, (46, 46), "cuda:0", seed=1234, dtype=torch.float16)
-    for k in range(3):
-        ids, am, pix = bench.next_batch(inp)
-        torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        pipeline.rec_batch(model, inp["proc"], ids, am, pix, inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
-        torch.cuda.synchronize()
-        print(f"batch {k}: {(time.perf_counter() - t0) * 1e3:.1f} ms", file=sys.stderr)
+    # the bench leg's runner: two decode groups of `merge` batches in flight, captured decode steps
+    r = pipeline.PipelinedRunner(model, inp["proc"], depth=args.depth, merge=args.merge)
+
+    def go(n):
+        for _ in range(n):
+            ids, am, pix = bench.next_batch(inp)
+            r.submit(ids, am, pix, inp["grid"], max_new_tokens=args.tnew, schedule=inp["sched"])
+        r.flush()
+    go(args.depth * args.merge)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    n = 2 * args.merge
+    go(n)
+    torch.cuda.synchronize()
+    e = time.perf_counter() - t0
+    print(f"{n} batches: {e / n * 1e3:.1f} ms per batch = {args.batch * n / e:.1f} images/s", file=sys.stderr)
 
 
 if __name__ == "__main__":
