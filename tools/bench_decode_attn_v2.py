@@ -22,6 +22,18 @@ LIB.decode_attn_rope_v2.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _vp, 
 LIB.decode_attn_rope_v2.restype = _i
 
 
+LIB.decode_attn_rope_v3.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _i, _i, _i]
+LIB.decode_attn_rope_v3.restype = _i
+
+
+def v3(qkv, cs, slot, kc, vt, out, Hq, Hkv, D, S_max, packed=False, nw=8, out_packed=False):
+    """round 6: ONE launch, nw waves per (kv head, sample), online merge in registers + LDS, 16-bit output rows written directly."""
+    st = LIB.decode_attn_rope_v3(torch.cuda.current_stream().cuda_stream, qkv.data_ptr(), qkv.stride(0), cs.data_ptr(), slot.data_ptr(),
+                                 kc.data_ptr(), vt.data_ptr(), out.data_ptr(), qkv.shape[0], Hq, Hkv, D, S_max, float(D ** -0.5),
+                                 1 if packed else 0, int(nw), 1 if out_packed else 0)
+    assert st == 0, st
+
+
 def v2(qkv, cs, slot, kc, vt, out, ws, Hq, Hkv, D, S_max, max_len, packed=False):
     st = LIB.decode_attn_rope_v2(torch.cuda.current_stream().cuda_stream, qkv.data_ptr(), qkv.stride(0), cs.data_ptr(), slot.data_ptr(),
                                  kc.data_ptr(), vt.data_ptr(), out.data_ptr(), ws.data_ptr(), qkv.shape[0], Hq, Hkv, D, S_max, int(max_len),
@@ -87,6 +99,18 @@ def parity(Hq, Hkv, slots, S_max=640, D=128, sec=(16, 24, 24), seed=1):
         vv = v3[b, :, :, :L].float().transpose(1, 2).repeat_interleave(rep, 0)
         sc = torch.einsum("hd,hld->hl", qb[b].float().view(Hq, D), kk) * D ** -0.5
         ref[b] = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vv).reshape(-1)
+    for nw in (4, 8):                                              # v3: appends bit-identical, outputs at the same distance to fp32
+        o4 = torch.zeros_like(o2)
+        k4, v4 = kc.clone(), vt.clone()
+        v3(qkv, csx, slot_t, k4, v4, o4, Hq, Hkv, D, S_max, nw=nw)
+        o5 = torch.zeros_like(o2)
+        kp4, vp4 = pack_k(kc), pack_vt(vt)
+        v3(qkv, csx, slot_t, kp4, vp4, o5, Hq, Hkv, D, S_max, packed=True, nw=nw)
+        torch.cuda.synchronize()
+        print(f"[v3 nw={nw}] K append equal {torch.equal(k4, k1)}, V append equal {torch.equal(v4, v1)}; |v3 - fp32| max {(o4.float() - ref).abs().max().item():.3e} "
+              f"(library {(o1.float() - ref).abs().max().item():.3e}); |v3 - library| max {(o4.float() - o1.float()).abs().max().item():.3e} "
+              f"({(o4 != o1).sum().item()} of {o1.numel()} differ); packed == row-major: {torch.equal(o5, o4)}, packed appends equal "
+              f"{torch.equal(unpack_k(kp4, S_max, D), k1) and torch.equal(unpack_vt(vp4, D, S_max), v1)}; finite {bool(torch.isfinite(o4.float()).all())}", flush=True)
     e1 = (o1.float() - ref).abs().max().item()
     e2 = (o2.float() - ref).abs().max().item()
     d12 = (o1.float() - o2.float()).abs().max().item()
@@ -140,8 +164,16 @@ def timing(B, S_max, slot, Hq=16, Hkv=2, D=128):
         j[0] += 1
         v2(qkv, cs, slot_t, kcs[j[0] % nset], vts[j[0] % nset], out, ws, Hq, Hkv, D, S_max, max_len, packed=True)
 
+    def mk3(nw, packed):
+        def f():
+            j[0] += 1
+            v3(qkv, cs, slot_t, kcs[j[0] % nset], vts[j[0] % nset], out, Hq, Hkv, D, S_max, packed=packed, nw=nw)
+        return f
+    t34, t38, t34p, t38p = graph_time(mk3(4, False)), graph_time(mk3(8, False)), graph_time(mk3(4, True)), graph_time(mk3(8, True))
     t1, t2, t3 = graph_time(lib), graph_time(new), graph_time(newp)
     kv_mb = B * Hkv * (slot + 1) * D * 2 * 2 / 1e6
+    print(f"[timing B {B:3d} heads {Hq}:{Hkv} keys {slot + 1:4d}] v3 ONE launch, us per call: 4 waves {t34:6.2f} ({t1 / t34:.2f}x of the library), 8 waves {t38:6.2f} "
+          f"({t1 / t38:.2f}x); on packed caches 4 waves {t34p:6.2f} ({t1 / t34p:.2f}x), 8 waves {t38p:6.2f} ({t1 / t38p:.2f}x) = {kv_mb / min(t34p, t38p):.2f} TB/s of KV", flush=True)
     print(f"[timing B {B:3d} heads {Hq}:{Hkv} keys {slot + 1:4d}] attention + merge, us per call: library {t1:6.2f}, v2 {t2:6.2f} ({t1 / t2:.2f}x), "
           f"v2 on packed caches {t3:6.2f} ({t1 / t3:.2f}x); {kv_mb:.1f} MB of KV: {kv_mb / t1:.2f} → {kv_mb / t2:.2f} → {kv_mb / t3:.2f} TB/s", flush=True)
 

@@ -29,6 +29,7 @@ struct Args {
     x16_t* out;                      // [B][Hq * D] (merge)
     int B, Hq, Hkv, S_max, nsplit;
     float scale_log2;
+    int out_packed = 0;               // v3: out in the 16-row fragment-packed activation layout (row length Hq * D)
 };
 
 // rotate one chunk pair (8 rotate-half pairs): x1 = chunk c (d = 8c ..), x2 = chunk c + D/16 (d + D/2 ..), cs = (cos, sin) of d = 8c .. 8c+7
@@ -258,6 +259,228 @@ __global__ __launch_bounds__(64) void decode_attn_rope_v2_kernel(Args p) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// v3 (round 6): ONE launch.  A block = NW waves owns one (kv head, sample): wave w streams the 64-key splits w, w + NW, ... with v2's
+// register-only body and folds them into a running (m, l, O^T) — flash attention's online rescale, so no per-split partial ever leaves
+// the wave —, the NW states meet in LDS and every wave finishes its share of the O^T d-tiles and stores 16-bit output rows.  No partial
+// traffic (10.5 MB written + 5 MB re-read per layer at 64 rows), no second launch (the two-launch floor is 8.9 us at 8 samples).
+template <int D, int NW, bool PACKED>
+__global__ __launch_bounds__(NW * 64) void decode_attn_rope_v3_kernel(Args p) {
+#pragma clang fp contract(off)
+    static_assert(D == 128, "fragment map below is written for 16 chunks per head");
+    constexpr int KQ = D / 32, NB = D / 16, HALF = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float v3_lds[];
+    float* sm_ml = v3_lds;                                        // [NW][64][2]
+    f32x4* sm_o = reinterpret_cast<f32x4*>(v3_lds + NW * 64 * 2); // [NW][NB][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fq = lane >> 4;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int group = p.Hq / p.Hkv;
+    const int slot = p.slot[b];
+    const int len = slot + 1;
+    const x16_t* row = p.qkv + (long)b * p.ld_qkv;
+    x16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    x16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+    const bool liveq = frow < group;
+    float M = -INFINITY, L = 0.f;
+    f32x4 o[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave * 64 < len) {
+        // ---- q (this lane's head) and the fresh k, rotated in registers straight into fragments (v2)
+        const x16_t* qrow = row + (long)(g * group + (liveq ? frow : 0)) * D;
+        const x16_t* krow = row + (long)(p.Hq + g) * D;
+        const x16_t* vrow = row + (long)(p.Hq + p.Hkv + g) * D;
+        u32x4 qraw[4], knraw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qraw[j] = *reinterpret_cast<const u32x4*>(qrow + (fq + 4 * j) * 8);
+            knraw[j] = *reinterpret_cast<const u32x4*>(krow + (fq + 4 * j) * 8);
+        }
+        float2 cs[2][8];
+        {
+            const float* csb = p.rope_cs + (long)b * HALF * 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(csb + 2 * ((fq + 4 * h) * 8 + e));
+                    cs[h][e] = float2{v.x, v.y};
+                    cs[h][e + 1] = float2{v.z, v.w};
+                }
+        }
+        u32x4 qf[KQ], kn[KQ];
+        rope_chunk_pair(qraw[0], qraw[2], cs[0], qf[0], qf[2]);
+        rope_chunk_pair(qraw[1], qraw[3], cs[1], qf[1], qf[3]);
+        rope_chunk_pair(knraw[0], knraw[2], cs[0], kn[0], kn[2]);
+        rope_chunk_pair(knraw[1], knraw[3], cs[1], kn[1], kn[3]);
+        if (!liveq) {
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) qf[kk] = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int k0 = wave * 64; k0 < len; k0 += NW * 64) {
+            const bool owner = (slot >= k0) && (slot < k0 + 64);
+            u32x4 kraw[4][KQ];
+            u32x4 vfr[2][NB];
+            if constexpr (PACKED) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk)
+                        kraw[kb][kk] = *reinterpret_cast<const u32x4*>(kbase + ((long)((k0 >> 4) + kb) * KQ + kk) * 512 + lane * 8);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+                        vfr[ks][i] = *reinterpret_cast<const u32x4*>(vbase + ((long)i * (p.S_max >> 5) + (k0 >> 5) + ks) * 512 + lane * 8);
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int key = k0 + kb * 16 + frow;
+                    const int kcl = key < p.S_max ? key : p.S_max - 1;
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk) kraw[kb][kk] = *reinterpret_cast<const u32x4*>(kbase + (long)kcl * D + kk * 32 + fq * 8);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const x16_t* vr = vbase + (long)(i * 16 + frow) * p.S_max + k0 + ks * 32 + fq * 4;
+                        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
+                        vfr[ks][i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                    }
+            }
+            unsigned vnew[NB];
+            if (owner) {
+                unsigned vapp[2];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) vnew[i] = vrow[i * 16 + frow];
+                vapp[0] = vrow[lane];
+                vapp[1] = vrow[lane + 64];
+                if constexpr (PACKED) {
+                    if (frow == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < KQ; ++kk)
+                            *reinterpret_cast<u32x4*>(kbase + ((((long)(slot >> 4) * KQ + kk) * 64) + fq * 16 + (slot & 15)) * 8) = kn[kk];
+                    }
+                    const int r32 = slot & 31;
+                    const long vcol = ((long)(slot >> 5) * 64 + ((r32 & 15) >> 2) * 16) * 8 + (r32 >> 4) * 4 + (r32 & 3);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = lane + 64 * h;
+                        vbase[(long)(d >> 4) * (p.S_max >> 5) * 512 + vcol + (d & 15) * 8] = (x16_t)vapp[h];
+                    }
+                } else {
+                    if (frow == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < KQ; ++kk) *reinterpret_cast<u32x4*>(kbase + (long)slot * D + kk * 32 + fq * 8) = kn[kk];
+                    }
+                    vbase[(long)lane * p.S_max + slot] = (x16_t)vapp[0];
+                    vbase[(long)(lane + 64) * p.S_max + slot] = (x16_t)vapp[1];
+                }
+            }
+            const int rel = slot - k0;
+            f32x4 s[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                u32x4 kf[KQ];
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) kf[kk] = kraw[kb][kk];
+                if (owner && (rel >> 4) == kb) {
+                    const bool fresh = frow == (rel & 15);
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk) kf[kk] = fresh ? kn[kk] : kf[kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) s[kb] = mfma16(__builtin_bit_cast(x16x8, kf[kk]), __builtin_bit_cast(x16x8, qf[kk]), s[kb]);
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kb * 16 + fq * 4 + r;
+                    const float x = (key < len) ? s[kb][r] * p.scale_log2 : -INFINITY;
+                    s[kb][r] = x;
+                    m = fmaxf(m, x);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));                  // finite: key k0 < len exists
+            const float Mn = fmaxf(M, m);
+            const float al = exp2f(M - Mn);                       // first split: exp2(-inf) = 0
+            M = Mn;
+            L *= al;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) o[i] *= al;
+            u32x4 pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float pv[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(s[2 * ks + h][r] - Mn);
+                        pv[h * 4 + r] = e;
+                        L += e;                                   // lane-partial over its own keys; reduced across fq after the loop
+                    }
+                pf[ks] = pack8(pv);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (owner && (rel >> 5) == ks) {
+                    const bool mine = fq == ((rel >> 2) & 3);
+                    const int run = (rel >> 4) & 1, w = (rel >> 1) & 1, half = rel & 1;
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const unsigned nv = vnew[i] & 0xffffu;
+                        const int wi = run * 2 + w;
+                        const unsigned cur = wi == 0 ? vfr[ks][i][0] : (wi == 1 ? vfr[ks][i][1] : (wi == 2 ? vfr[ks][i][2] : vfr[ks][i][3]));
+                        const unsigned pat = half ? ((cur & 0x0000ffffu) | (nv << 16)) : ((cur & 0xffff0000u) | nv);
+                        const unsigned val = mine ? pat : cur;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) vfr[ks][i][q] = (wi == q) ? val : vfr[ks][i][q];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) o[i] = mfma16(__builtin_bit_cast(x16x8, vfr[ks][i]), __builtin_bit_cast(x16x8, pf[ks]), o[i]);
+            }
+        }
+        L += __shfl_xor(L, 16, 64);
+        L += __shfl_xor(L, 32, 64);
+    }
+    // ---- the NW running states meet in LDS; wave w finishes the d-tiles w, w + NW, ... of every head
+    sm_ml[(wave * 64 + lane) * 2] = M;
+    sm_ml[(wave * 64 + lane) * 2 + 1] = L;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) sm_o[(wave * NB + i) * 64 + lane] = o[i];
+    __syncthreads();
+    float Mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) Mx = fmaxf(Mx, sm_ml[(w * 64 + lane) * 2]);
+    float wgt[NW], Ls = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float mw = sm_ml[(w * 64 + lane) * 2];
+        wgt[w] = mw == -INFINITY ? 0.f : exp2f(mw - Mx);
+        Ls += wgt[w] * sm_ml[(w * 64 + lane) * 2 + 1];
+    }
+    const float inv = Ls > 0.f ? 1.f / Ls : 0.f;
+    if (liveq) {
+        const long ld = (long)p.Hq * D;
+#pragma unroll
+        for (int i = wave; i < NB; i += NW) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc += sm_o[(w * NB + i) * 64 + lane] * wgt[w];
+            const int n = (g * group + frow) * D + i * 16 + fq * 4;   // 4 consecutive columns of output row b
+            const long off = p.out_packed ? (long)(b >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (b & 15)) * 8 + (n & 7) : (long)b * ld + n;
+            *reinterpret_cast<u32x2*>(p.out + off) = u32x2{pack2x(acc[0] * inv, acc[1] * inv), pack2x(acc[2] * inv, acc[3] * inv)};
+        }
+    }
+}
+
 // the library's merge (csrc/attention.hip decode_combine_kernel), row-major output
 template <int D>
 __global__ void combine_kernel(Args p) {
@@ -312,5 +535,31 @@ extern "C" int decode_attn_rope_v2(void* stream, const void* qkv, long ld_qkv, c
     if (packed) hipLaunchKernelGGL((decode_attn_rope_v2_kernel<128, true>), dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
     else hipLaunchKernelGGL((decode_attn_rope_v2_kernel<128, false>), dim3(nsplit, n_kv_heads, batch), dim3(64), 0, s, a);
     hipLaunchKernelGGL(combine_kernel<128>, dim3(n_heads, batch), dim3(128), 0, s, a);
+    return hipGetLastError() == hipSuccess ? 0 : -2;
+}
+
+// v3: one launch, NW waves per (kv head, sample); nw = 4 or 8
+extern "C" int decode_attn_rope_v3(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,
+                                   void* vt_cache, void* out, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, float scale,
+                                   int packed, int nw, int out_packed) {
+    if (head_dim != 128 || n_heads % n_kv_heads || n_heads / n_kv_heads > 16 || (s_max & 63) || (ld_qkv & 7) || (nw != 4 && nw != 8)) return -1;
+    Args a{(const x16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (x16_t*)k_cache, (x16_t*)vt_cache, nullptr, nullptr,
+           (x16_t*)out, batch, n_heads, n_kv_heads, s_max, 0, scale * 1.4426950408889634f, out_packed};
+    hipStream_t s = (hipStream_t)stream;
+    const size_t lds = (size_t)nw * 64 * 2 * 4 + (size_t)nw * 8 * 64 * 16;
+    static bool attr = false;
+    if (!attr) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_v3_kernel<128, 8, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_v3_kernel<128, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024);
+        attr = true;
+    }
+    const dim3 grid(n_kv_heads, batch);
+    if (nw == 8) {
+        if (packed) hipLaunchKernelGGL((decode_attn_rope_v3_kernel<128, 8, true>), grid, dim3(512), lds, s, a);
+        else hipLaunchKernelGGL((decode_attn_rope_v3_kernel<128, 8, false>), grid, dim3(512), lds, s, a);
+    } else {
+        if (packed) hipLaunchKernelGGL((decode_attn_rope_v3_kernel<128, 4, true>), grid, dim3(256), lds, s, a);
+        else hipLaunchKernelGGL((decode_attn_rope_v3_kernel<128, 4, false>), grid, dim3(256), lds, s, a);
+    }
     return hipGetLastError() == hipSuccess ? 0 : -2;
 }
