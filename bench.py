@@ -254,8 +254,9 @@ def insitu_leg(model, inp, args, cfg, run_steps, steps):
     step_bytes = wbytes + head.numel() * head.element_size() + n_proto * cfg.hidden_size * 2 + kv_bytes
     us = dms * 1e3 / max(n_steps, 1)
     gbs = step_bytes / (us * 1e-6) / 1e9 if us > 0 else 0.0
-    dec = {"bound": "hbm", "kernel": "one decode step = one hipGraph replay: %d x [norm+qkv, rope+append+split attention, merge, o+resid, norm+gate/up+SwiGLU, down+resid] "
-                                     "(gemm_skinny_kernel, decode_attn_rope_kernel) + vrt_head_kernel + greedy_step_kernel" % cfg.num_hidden_layers,
+    dec = {"bound": "hbm", "kernel": "one decode step = one hipGraph replay: %d x [norm+qkv, rope+append+attention over fragment-packed KV caches (ONE launch: block per "
+                                     "(kv head, sample), on-chip merge), o+resid, norm+gate/up+SwiGLU, down+resid] (gemm_skinny_kernel, decode_attn_rope_packed_kernel) "
+                                     "+ vrt_head_kernel + greedy_step_kernel" % cfg.num_hidden_layers,
            "rows_per_step": rows, "bytes_per_step": int(step_bytes), "weight_bytes_per_step": int(wbytes), "kv_bytes_per_step": int(kv_bytes),
            "us_per_step": round(us, 1), "achieved": round(gbs, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(gbs / HBM_PEAK_GBS, 4),
            "steps_timed": n_steps,

@@ -152,13 +152,21 @@ int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const vo
                       void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim, int s_max, int max_len,
                       float scale);
 
-/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1): split attention over 64-key chunks + combine.
+/* Decode-step attention with mRoPE + KV-cache append fused in (T = 1).
  * rope_cs = this step's fp32 (cos, sin) table [B][head_dim/2][2] from padt_rope_table; slot[b] = append index (keys
- * visible afterwards = slot[b]+1); workspace as padt_decode_attn_workspace; out_packed: write `out` in the fragment-packed
- * activation layout (see padt_gemm_packed_bf16).  HF:557-599, 641-689, 665-666. */
+ * visible afterwards = slot[b]+1); out_packed: write `out` in the fragment-packed activation layout (see padt_gemm_packed_bf16).
+ * cache_packed = 0: row-major K / transposed V caches (above), split attention over 64-key chunks + a combine launch, workspace as
+ *   padt_decode_attn_workspace.
+ * cache_packed = 1 (round 6; head_dim 128): FRAGMENT-PACKED caches — K [B][Hkv][S_max/16][D/32][64 lanes][8] (lane (frow, fq) of tile
+ *   (s16, kk): K[16 s16 + frow][32 kk + 8 fq ..+8)), V^T [B][Hkv][D/16][S_max/32][64 lanes][8] (lane (frow, fq) of tile (i, ks):
+ *   V[32 ks + 4 fq + e][16 i + frow], e < 4, then the same keys + 16) — every wave-wide load is 1 KiB contiguous — and ONE launch: a block
+ *   of 8 waves per (kv head, sample) streams the sample's keys, merges on chip and writes the output rows; no workspace (may be null).
+ *   11.2 us per layer at 64 rows against 18.7 (profiles/r06_decode_attn_v3.log).  Same results up to one 16-bit rounding (different
+ *   merge order).  padt_llm_qkv_post writes the same images when given cache_packed = 1.
+ * HF:557-599, 641-689, 665-666. */
 int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,
                           void* vt_cache, void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,
-                          int s_max, int max_len, float scale, int out_packed);
+                          int s_max, int max_len, float scale, int out_packed, int cache_packed);
 /* rope_cs[b][d] = (cos, sin)(pos3[axis(d)][b] * inv_freq[d]) with mRoPE sections (sec0, sec1, rest).  HF:525-538,589-595. */
 int padt_rope_table(void* stream, const int* pos3, const void* inv_freq, void* rope_cs, int batch, int head_dim, int sec0,
                     int sec1);
@@ -208,7 +216,7 @@ int padt_embed_tokens(void* stream, const long* ids, const int* img_index, const
 int padt_llm_qkv_post(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample, const int* slot,
                       const int* lens, const void* inv_freq, void* q_out, long ld_q, void* k_pack, long ld_kp,
                       void* k_cache, void* vt_cache, long T, int n_heads, int n_kv_heads, int head_dim, int s_max,
-                      int sec0, int sec1);
+                      int sec0, int sec1, int cache_packed);
 /* PaDT mask head tail: per-patch 4x4 dot with the object's mask token, scattered to (n_obj, 4H, 4W) fp32.
  * padt_decoder.py:241-274. */
 int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask_tok, long ld_tok, const int* cu_patch,

@@ -708,6 +708,264 @@ __global__ __launch_bounds__(64) void decode_attn_rope_kernel(DecodeRopeArgs p) 
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Decode-step attention over FRAGMENT-PACKED caches, ONE launch (round 6).  The two-launch form above spends 18.7 us per layer at 64 rows
+// (8.9 us of it the latency floor of two dependent launches; 10.5 MB of fp32 partials written and 5 MB re-read); packing the caches
+// alone bought 1.13-1.23x (round 4, tools/ubench/decode_attn_v2.hip), a single launch on the row-major caches nothing (one CU cannot
+// issue a sample's 307 KB of KV as 64-byte row pieces fast enough: 19.0 us) — together: 11.2 us at 64 rows (1.68x), 18.5 at 128 (1.73x),
+// 26.3 at 128 rows x 951 keys (1.57x), 18.9 for PaDT_Pro_7B's 28:4 heads at 64 rows (1.70x); profiles/r06_decode_attn_v3.log.
+// Cache images (every wave-wide load instruction reads 1 KiB of contiguous memory, as the packed weight image of csrc/gemm.hip):
+//   K   [B][Hkv][S_max/16][D/32][64 lanes][8]: lane (frow, fq) of tile (s16, kk) holds K[16 s16 + frow][32 kk + 8 fq .. + 8)
+//   V^T [B][Hkv][D/16][S_max/32][64 lanes][8]: lane (frow, fq) of tile (i, ks) holds V[32 ks + 4 fq + e][16 i + frow], e < 4, then the
+//       same four keys + 16 — the key permutation under which the transposed scores' registers ARE the second MFMA's B operand.
+// padt_llm_qkv_post writes the same images (cache_packed = 1).  A block = NW waves owns one (kv head, sample): wave w streams the 64-key
+// splits w, w + NW, ... with a register-only body (q and the fresh k rotated in registers straight into fragments, S^T = K Q^T so a lane
+// owns one head's scores: in-lane soft-max + two shuffles, probabilities fed to O^T = V^T P^T from registers) into a running (m, l, O^T)
+// — no per-split partial leaves the wave —, the NW states meet in LDS and every wave finishes its share of the d-tiles and stores 16-bit
+// rows.  Per-sample results do not depend on the batch (a block sees one sample) nor on S_max (splits sit at absolute key positions).
+// The merge arithmetic differs from decode_combine's, so outputs are equal to the two-launch form's or one 16-bit rounding apart.
+struct DecodePackedArgs {
+    const x16_t* qkv; long ld_qkv;   // [B][(Hq + 2 Hkv) * D], bias already added
+    const float* rope_cs;             // [B][D/2][2] cos, sin of this step's position
+    const int* slot;                  // [B] append index; valid keys afterwards = slot + 1
+    x16_t* kc; x16_t* vtc;           // packed images (above)
+    x16_t* out;                      // [B][Hq * D] rows (or the 16-row fragment-packed activation layout)
+    int B, Hq, Hkv, S_max;
+    float scale_log2;
+    int out_packed;
+};
+
+// rotate one chunk pair (8 rotate-half pairs): x1 = chunk c (d = 8c ..), x2 = chunk c + D/16 (d + D/2 ..), cs = (cos, sin) of d = 8c .. 8c+7
+PADT_DEV void rope_chunk_pair(const u32x4& r1, const u32x4& r2, const float2* cs, u32x4& lo, u32x4& hi) {
+    float x1[8], x2[8], o1[8], o2[8];
+    unpack8(r1, x1);
+    unpack8(r2, x2);
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+        o1[e] = rope_lo(x1[e], x2[e], cs[e].x, cs[e].y);
+        o2[e] = rope_hi(x1[e], x2[e], cs[e].x, cs[e].y);
+    }
+    lo = pack8(o1);
+    hi = pack8(o2);
+}
+
+template <int D, int NW, bool PACKED>
+__global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(DecodePackedArgs p) {
+#pragma clang fp contract(off)
+    static_assert(D == 128, "fragment map below is written for 16 chunks per head");
+    constexpr int KQ = D / 32, NB = D / 16, HALF = D / 2;
+    extern __shared__ __attribute__((aligned(16))) float v3_lds[];
+    float* sm_ml = v3_lds;                                        // [NW][64][2]
+    f32x4* sm_o = reinterpret_cast<f32x4*>(v3_lds + NW * 64 * 2); // [NW][NB][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, frow = lane & 15, fq = lane >> 4;
+    const int g = blockIdx.x, b = blockIdx.y;
+    const int group = p.Hq / p.Hkv;
+    const int slot = p.slot[b];
+    const int len = slot + 1;
+    const x16_t* row = p.qkv + (long)b * p.ld_qkv;
+    x16_t* kbase = p.kc + ((long)b * p.Hkv + g) * p.S_max * D;
+    x16_t* vbase = p.vtc + ((long)b * p.Hkv + g) * D * (long)p.S_max;
+    const bool liveq = frow < group;
+    float M = -INFINITY, L = 0.f;
+    f32x4 o[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wave * 64 < len) {
+        // ---- q (this lane's head) and the fresh k, rotated in registers straight into fragments (v2)
+        const x16_t* qrow = row + (long)(g * group + (liveq ? frow : 0)) * D;
+        const x16_t* krow = row + (long)(p.Hq + g) * D;
+        const x16_t* vrow = row + (long)(p.Hq + p.Hkv + g) * D;
+        u32x4 qraw[4], knraw[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            qraw[j] = *reinterpret_cast<const u32x4*>(qrow + (fq + 4 * j) * 8);
+            knraw[j] = *reinterpret_cast<const u32x4*>(krow + (fq + 4 * j) * 8);
+        }
+        float2 cs[2][8];
+        {
+            const float* csb = p.rope_cs + (long)b * HALF * 2;
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+#pragma unroll
+                for (int e = 0; e < 8; e += 2) {
+                    const float4 v = *reinterpret_cast<const float4*>(csb + 2 * ((fq + 4 * h) * 8 + e));
+                    cs[h][e] = float2{v.x, v.y};
+                    cs[h][e + 1] = float2{v.z, v.w};
+                }
+        }
+        u32x4 qf[KQ], kn[KQ];
+        rope_chunk_pair(qraw[0], qraw[2], cs[0], qf[0], qf[2]);
+        rope_chunk_pair(qraw[1], qraw[3], cs[1], qf[1], qf[3]);
+        rope_chunk_pair(knraw[0], knraw[2], cs[0], kn[0], kn[2]);
+        rope_chunk_pair(knraw[1], knraw[3], cs[1], kn[1], kn[3]);
+        if (!liveq) {
+#pragma unroll
+            for (int kk = 0; kk < KQ; ++kk) qf[kk] = u32x4{0u, 0u, 0u, 0u};
+        }
+        for (int k0 = wave * 64; k0 < len; k0 += NW * 64) {
+            const bool owner = (slot >= k0) && (slot < k0 + 64);
+            u32x4 kraw[4][KQ];
+            u32x4 vfr[2][NB];
+            if constexpr (PACKED) {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk)
+                        kraw[kb][kk] = *reinterpret_cast<const u32x4*>(kbase + ((long)((k0 >> 4) + kb) * KQ + kk) * 512 + lane * 8);
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i)
+                        vfr[ks][i] = *reinterpret_cast<const u32x4*>(vbase + ((long)i * (p.S_max >> 5) + (k0 >> 5) + ks) * 512 + lane * 8);
+            } else {
+#pragma unroll
+                for (int kb = 0; kb < 4; ++kb) {
+                    const int key = k0 + kb * 16 + frow;
+                    const int kcl = key < p.S_max ? key : p.S_max - 1;
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk) kraw[kb][kk] = *reinterpret_cast<const u32x4*>(kbase + (long)kcl * D + kk * 32 + fq * 8);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const x16_t* vr = vbase + (long)(i * 16 + frow) * p.S_max + k0 + ks * 32 + fq * 4;
+                        const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
+                        vfr[ks][i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
+                    }
+            }
+            unsigned vnew[NB];
+            if (owner) {
+                unsigned vapp[2];
+#pragma unroll
+                for (int i = 0; i < NB; ++i) vnew[i] = vrow[i * 16 + frow];
+                vapp[0] = vrow[lane];
+                vapp[1] = vrow[lane + 64];
+                if constexpr (PACKED) {
+                    if (frow == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < KQ; ++kk)
+                            *reinterpret_cast<u32x4*>(kbase + ((((long)(slot >> 4) * KQ + kk) * 64) + fq * 16 + (slot & 15)) * 8) = kn[kk];
+                    }
+                    const int r32 = slot & 31;
+                    const long vcol = ((long)(slot >> 5) * 64 + ((r32 & 15) >> 2) * 16) * 8 + (r32 >> 4) * 4 + (r32 & 3);
+#pragma unroll
+                    for (int h = 0; h < 2; ++h) {
+                        const int d = lane + 64 * h;
+                        vbase[(long)(d >> 4) * (p.S_max >> 5) * 512 + vcol + (d & 15) * 8] = (x16_t)vapp[h];
+                    }
+                } else {
+                    if (frow == 0) {
+#pragma unroll
+                        for (int kk = 0; kk < KQ; ++kk) *reinterpret_cast<u32x4*>(kbase + (long)slot * D + kk * 32 + fq * 8) = kn[kk];
+                    }
+                    vbase[(long)lane * p.S_max + slot] = (x16_t)vapp[0];
+                    vbase[(long)(lane + 64) * p.S_max + slot] = (x16_t)vapp[1];
+                }
+            }
+            const int rel = slot - k0;
+            f32x4 s[4];
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb) {
+                s[kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+                u32x4 kf[KQ];
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) kf[kk] = kraw[kb][kk];
+                if (owner && (rel >> 4) == kb) {
+                    const bool fresh = frow == (rel & 15);
+#pragma unroll
+                    for (int kk = 0; kk < KQ; ++kk) kf[kk] = fresh ? kn[kk] : kf[kk];
+                }
+#pragma unroll
+                for (int kk = 0; kk < KQ; ++kk) s[kb] = mfma16(__builtin_bit_cast(x16x8, kf[kk]), __builtin_bit_cast(x16x8, qf[kk]), s[kb]);
+            }
+            float m = -INFINITY;
+#pragma unroll
+            for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    const int key = k0 + kb * 16 + fq * 4 + r;
+                    const float x = (key < len) ? s[kb][r] * p.scale_log2 : -INFINITY;
+                    s[kb][r] = x;
+                    m = fmaxf(m, x);
+                }
+            m = fmaxf(m, __shfl_xor(m, 16, 64));
+            m = fmaxf(m, __shfl_xor(m, 32, 64));                  // finite: key k0 < len exists
+            const float Mn = fmaxf(M, m);
+            const float al = exp2f(M - Mn);                       // first split: exp2(-inf) = 0
+            M = Mn;
+            L *= al;
+#pragma unroll
+            for (int i = 0; i < NB; ++i) o[i] *= al;
+            u32x4 pf[2];
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                float pv[8];
+#pragma unroll
+                for (int h = 0; h < 2; ++h)
+#pragma unroll
+                    for (int r = 0; r < 4; ++r) {
+                        const float e = exp2f(s[2 * ks + h][r] - Mn);
+                        pv[h * 4 + r] = e;
+                        L += e;                                   // lane-partial over its own keys; reduced across fq after the loop
+                    }
+                pf[ks] = pack8(pv);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                if (owner && (rel >> 5) == ks) {
+                    const bool mine = fq == ((rel >> 2) & 3);
+                    const int run = (rel >> 4) & 1, w = (rel >> 1) & 1, half = rel & 1;
+#pragma unroll
+                    for (int i = 0; i < NB; ++i) {
+                        const unsigned nv = vnew[i] & 0xffffu;
+                        const int wi = run * 2 + w;
+                        const unsigned cur = wi == 0 ? vfr[ks][i][0] : (wi == 1 ? vfr[ks][i][1] : (wi == 2 ? vfr[ks][i][2] : vfr[ks][i][3]));
+                        const unsigned pat = half ? ((cur & 0x0000ffffu) | (nv << 16)) : ((cur & 0xffff0000u) | nv);
+                        const unsigned val = mine ? pat : cur;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) vfr[ks][i][q] = (wi == q) ? val : vfr[ks][i][q];
+                    }
+                }
+#pragma unroll
+                for (int i = 0; i < NB; ++i) o[i] = mfma16(__builtin_bit_cast(x16x8, vfr[ks][i]), __builtin_bit_cast(x16x8, pf[ks]), o[i]);
+            }
+        }
+        L += __shfl_xor(L, 16, 64);
+        L += __shfl_xor(L, 32, 64);
+    }
+    // ---- the NW running states meet in LDS; wave w finishes the d-tiles w, w + NW, ... of every head
+    sm_ml[(wave * 64 + lane) * 2] = M;
+    sm_ml[(wave * 64 + lane) * 2 + 1] = L;
+#pragma unroll
+    for (int i = 0; i < NB; ++i) sm_o[(wave * NB + i) * 64 + lane] = o[i];
+    __syncthreads();
+    float Mx = -INFINITY;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) Mx = fmaxf(Mx, sm_ml[(w * 64 + lane) * 2]);
+    float wgt[NW], Ls = 0.f;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const float mw = sm_ml[(w * 64 + lane) * 2];
+        wgt[w] = mw == -INFINITY ? 0.f : exp2f(mw - Mx);
+        Ls += wgt[w] * sm_ml[(w * 64 + lane) * 2 + 1];
+    }
+    const float inv = Ls > 0.f ? 1.f / Ls : 0.f;
+    if (liveq) {
+        const long ld = (long)p.Hq * D;
+#pragma unroll
+        for (int i = wave; i < NB; i += NW) {
+            f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int w = 0; w < NW; ++w) acc += sm_o[(w * NB + i) * 64 + lane] * wgt[w];
+            const int n = (g * group + frow) * D + i * 16 + fq * 4;   // 4 consecutive columns of output row b
+            const long off = p.out_packed ? (long)(b >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (b & 15)) * 8 + (n & 7) : (long)b * ld + n;
+            *reinterpret_cast<u32x2*>(p.out + off) = u32x2{pack2x(acc[0] * inv, acc[1] * inv), pack2x(acc[2] * inv, acc[3] * inv)};
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 template <int D, bool CAUSAL, int QR, bool ROPE, bool GQA>
 static void launch_attn_k(const AttnArgs& a, dim3 grid, hipStream_t s) {
     constexpr int lds = ROPE ? AttnCfg<D>::LDS : AttnCfg<D>::LDS2;             // the LDS-DMA path double-buffers the K / V tiles
@@ -822,11 +1080,25 @@ extern "C" int PADT_TWIN(padt_decode_attn)(void* stream, const void* q, const vo
 
 extern "C" int PADT_TWIN(padt_decode_attn_rope)(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot,
                                      void* k_cache, void* vt_cache, void* out, void* workspace, int batch, int n_heads,
-                                     int n_kv_heads, int head_dim, int s_max, int max_len, float scale, int out_packed) {
+                                     int n_kv_heads, int head_dim, int s_max, int max_len, float scale, int out_packed, int cache_packed) {
     if (batch <= 0) return 0;
     if (n_heads % n_kv_heads || n_heads / n_kv_heads > 16 || (s_max & 63) || (ld_qkv & 7) || max_len > s_max || max_len <= 0) {
         padt_set_error("padt_decode_attn_rope: need heads/kv_heads <= 16, s_max % 64 == 0, ld_qkv % 8 == 0, 0 < max_len <= s_max");
         return -1;
+    }
+    if (cache_packed) {                                        // fragment-packed caches: ONE launch, no workspace (decode_attn_rope_packed_kernel)
+        if (head_dim != 128 || batch > 65535) { padt_set_error("padt_decode_attn_rope: packed caches need head_dim 128 and batch <= 65535"); return -1; }
+        constexpr int NW = 8;
+        constexpr int lds = NW * 64 * 2 * 4 + NW * 8 * 64 * 16;
+        static PerDeviceOnce once;
+        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_packed_kernel<128, NW, true>),
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+        DecodePackedArgs pa{(const x16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (x16_t*)k_cache, (x16_t*)vt_cache, (x16_t*)out,
+                            batch, n_heads, n_kv_heads, s_max, scale * 1.4426950408889634f, out_packed};
+        hipLaunchKernelGGL((decode_attn_rope_packed_kernel<128, NW, true>), dim3(n_kv_heads, batch), dim3(NW * 64), lds, (hipStream_t)stream, pa);
+        hipError_t e = hipGetLastError();
+        if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+        return 0;
     }
     const int nsplit = (max_len + 63) / 64;
     DecodeRopeArgs a{(const x16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (x16_t*)k_cache, (x16_t*)vt_cache,

@@ -137,6 +137,16 @@ PADT_DEV f32x4 mfma16(x16x8 a, x16x8 b, f32x4 c) { return __builtin_amdgcn_mfma_
 // and in the block that drew the last ticket: ld_agent(...)*.
 PADT_DEV void st_agent(float* p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 PADT_DEV float ld_agent(const float* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// The same hand-off 16 bytes at a time (round 6): a scalar sc1 store is one fabric write each — a dword costs ≈6x a dwordx4 per byte
+// (MI355X_MICROARCH.md, "stores of each flavour") — and the split-K partials are whole f32x4 fragments.  sc1 = write-through / L1-bypassing at
+// agent scope on both sides (the guide's valid form "{sc1 stores and loads both sides}" + the drained ticket of handoff_arrive / the
+// s_waitcnt vmcnt(0) in front of the ticket); the load waits for its own data before returning.
+PADT_DEV void st_agent4(float* p, f32x4 v) { asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(p), "v"(v) : "memory"); }
+PADT_DEV f32x4 ld_agent4(const float* p) {
+    f32x4 v;
+    asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=v"(v) : "v"(p) : "memory");
+    return v;
+}
 // one-wave blocks (or wave 0 only): returns true in the block that arrives last; the ticket is left at zero
 PADT_DEV bool handoff_arrive(int* ticket, int total, int lane) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");              // this wave's partial stores are acknowledged

@@ -559,7 +559,17 @@ struct QkvPostArgs {
     x16_t* k_pack; long ld_kp; // may be null
     x16_t* kc; x16_t* vtc;   // caches
     int T, Hq, Hkv, D, S_max, sec0, sec1;
+    int cache_packed;          // 1: fragment-packed cache images (csrc/attention.hip decode_attn_rope_packed_kernel), 0: row-major K / V^T
 };
+
+// element offsets inside one (sample, kv head) cache image; D % 32 == 0, S_max % 32 == 0 for the packed forms
+PADT_DEV long kc_offset(int slot, int d, int D, int packed) {           // K: row-major [S][D] or [S/16][D/32][64 lanes][8]
+    return packed ? ((((long)(slot >> 4) * (D >> 5) + (d >> 5)) * 64) + ((d >> 3) & 3) * 16 + (slot & 15)) * 8 + (d & 7) : (long)slot * D + d;
+}
+PADT_DEV long vtc_offset(int slot, int d, int S_max, int packed) {      // V^T: row-major [D][S] or [D/16][S/32][64 lanes][8]
+    return packed ? (((long)(d >> 4) * (S_max >> 5) + (slot >> 5)) * 64 + ((slot & 15) >> 2) * 16 + (d & 15)) * 8 + ((slot >> 4) & 1) * 4 + (slot & 3)
+                  : (long)d * S_max + slot;
+}
 
 __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
     __shared__ float cs[2][128];                                  // cos / sin of this token's D/2 angles (D <= 256)
@@ -599,9 +609,9 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
                 *reinterpret_cast<u32x4*>(q + half) = r2;
             } else {
                 const int g = h - p.Hq;
-                x16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D + d;
-                *reinterpret_cast<u32x4*>(kc) = r1;
-                *reinterpret_cast<u32x4*>(kc + half) = r2;
+                x16_t* kc = p.kc + ((long)b * p.Hkv + g) * p.S_max * p.D;         // an 8-wide chunk (d % 8 == 0) is contiguous in both images
+                *reinterpret_cast<u32x4*>(kc + kc_offset(slot, d, p.D, p.cache_packed)) = r1;
+                *reinterpret_cast<u32x4*>(kc + kc_offset(slot, d + half, p.D, p.cache_packed)) = r2;
                 if (p.k_pack) {
                     x16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D + d;
                     *reinterpret_cast<u32x4*>(kp) = r1;
@@ -622,8 +632,8 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
                 q[d] = o1; q[d + half] = o2;
             } else {
                 const int g = h - p.Hq;
-                x16_t* kc = p.kc + (((long)b * p.Hkv + g) * p.S_max + slot) * p.D;
-                kc[d] = o1; kc[d + half] = o2;
+                x16_t* kc = p.kc + ((long)b * p.Hkv + g) * p.S_max * p.D;
+                kc[kc_offset(slot, d, p.D, p.cache_packed)] = o1; kc[kc_offset(slot, d + half, p.D, p.cache_packed)] = o2;
                 if (p.k_pack) {
                     x16_t* kp = p.k_pack + (long)t * p.ld_kp + (long)g * p.D;
                     kp[d] = o1; kp[d + half] = o2;
@@ -634,20 +644,21 @@ __global__ __launch_bounds__(256) void llm_qkv_post_kernel(QkvPostArgs p) {
     const x16_t* v = row + (long)(p.Hq + p.Hkv) * p.D;
     for (int i = threadIdx.x; i < p.Hkv * p.D; i += blockDim.x) {
         const int g = i / p.D, d = i % p.D;
-        p.vtc[(((long)b * p.Hkv + g) * p.D + d) * p.S_max + slot] = v[i];
+        p.vtc[((long)b * p.Hkv + g) * p.D * p.S_max + vtc_offset(slot, d, p.S_max, p.cache_packed)] = v[i];
     }
 }
 
 extern "C" int PADT_TWIN(padt_llm_qkv_post)(void* stream, const void* qkv, long ld_qkv, const int* pos3, const int* sample,
                                  const int* slot, const int* lens, const void* inv_freq, void* q_out, long ld_q,
                                  void* k_pack, long ld_kp, void* k_cache, void* vt_cache, long T, int n_heads,
-                                 int n_kv_heads, int head_dim, int s_max, int sec0, int sec1) {
+                                 int n_kv_heads, int head_dim, int s_max, int sec0, int sec1, int cache_packed) {
     if (T <= 0) return 0;
     if (!slot && !lens) { padt_set_error("padt_llm_qkv_post: need slot[] or lens[]"); return -1; }
     if (head_dim > 256 || (head_dim & 1)) { padt_set_error("padt_llm_qkv_post: head_dim must be even and <= 256"); return -1; }
+    if (cache_packed && ((head_dim & 31) || (s_max & 31))) { padt_set_error("padt_llm_qkv_post: packed caches need head_dim % 32 == 0 and s_max % 32 == 0"); return -1; }
     QkvPostArgs a{(const x16_t*)qkv, ld_qkv, pos3, sample, slot, lens, (const float*)inv_freq, (x16_t*)q_out, ld_q,
                   (x16_t*)k_pack, ld_kp, (x16_t*)k_cache, (x16_t*)vt_cache, (int)T, n_heads, n_kv_heads, head_dim,
-                  s_max, sec0, sec1};
+                  s_max, sec0, sec1, cache_packed ? 1 : 0};
     hipLaunchKernelGGL(llm_qkv_post_kernel, dim3((unsigned)T), dim3(256), 0, (hipStream_t)stream, a);
     PADT_CHECK_LAUNCH("llm_qkv_post");
     return 0;

@@ -486,9 +486,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             if (jw < MT) {
                 float* mine = p.ws + (((long)(blockIdx.x * S + blockIdx.y) * (NT * MT)) * 64 + lane) * 4;
 #pragma unroll
-                for (int i = 0; i < NT; ++i)
-#pragma unroll
-                    for (int r = 0; r < 4; ++r) st_agent(mine + (i * MT + jw) * 256 + r, sum[q][i][r]);
+                for (int i = 0; i < NT; ++i) st_agent4(mine + (i * MT + jw) * 256, sum[q][i]);    // one 16-byte write-through store per fragment
             }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this wave's partial stores are acknowledged
@@ -513,10 +511,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 #pragma unroll
                     for (int i = 0; i < NT; ++i) {
                         f32x4 v = sum[q][i];
-                        if (y != (int)blockIdx.y) {
-#pragma unroll
-                            for (int r = 0; r < 4; ++r) v[r] = ld_agent(part + (i * MT + jw) * 256 + r);
-                        }
+                        if (y != (int)blockIdx.y) v = ld_agent4(part + (i * MT + jw) * 256);
                         tot[i] = (y == 0) ? v : tot[i] + v;
                     }
                 }

@@ -129,6 +129,12 @@ class DecodeSession:
         D, hd, Hkv, nl = cfg.hidden_size, cfg.head_dim, cfg.num_key_value_heads, cfg.num_hidden_layers
         bf = W.op16                                         # 16-bit operand type of the model (fp16 by default, bf16: weights.prepare_weights)
         z = lambda *s, dt=bf: torch.zeros(*s, device=device, dtype=dt)
+        # KV caches, one pair per layer.  head_dim 128 (PaDT_Pro_3B / 7B): the FRAGMENT-PACKED images of padt_decode_attn_rope (K
+        # [S/16][D/32][64 lanes][8], V^T [D/16][S/32][64 lanes][8]: 1 KiB contiguous per wave-wide load) read by the one-launch decode
+        # attention and written in place by the prompt pass (llm_qkv_post) and the decode step's append; otherwise row-major K / transposed V
+        # with the two-launch split attention.  PADT_KV_PACKED=0 keeps the row-major form for A/B runs.
+        import os
+        self.cache_packed = hd == 128 and cfg.num_attention_heads // Hkv <= 16 and os.environ.get("PADT_KV_PACKED", "1") != "0"
         self.kc = [z(B, Hkv, s_max, hd) for _ in range(nl)]
         self.vtc = [z(B, Hkv, hd, s_max) for _ in range(nl)]
         self.proto = z(np_max, D)
@@ -210,7 +216,7 @@ class DecodeSession:
                 ops.gemm_packed_fp8(self.x, W[p + "qkv.wq"], W[p + "qkv.ws"], self.n_qkv, W[p + "qkv.b"], out=self.qkv,
                                     norm_eps=eps_n, a_packed=True, rows=B)
                 ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
-                                     hd, self.s_max, self.s_max, out_packed=True)
+                                     hd, self.s_max, self.s_max, out_packed=True, cache_packed=self.cache_packed)
                 if f32:
                     ops.gemm_packed_resid32(self.att, W[p + "o.wq"], D, self.x32, self.x, scales=W[p + "o.ws"], split_k=self.o_split,
                                             workspace=self.splitk_ws, rows=B)
@@ -229,7 +235,7 @@ class DecodeSession:
             ops.gemm_packed(self.x, W[p + "qkv.wp"], self.n_qkv, W[p + "qkv.b"], out=self.qkv, norm_eps=eps_n,
                             a_packed=True, rows=B)
             ops.decode_attn_rope(self.qkv, self.rope_cs, self.slot, self.kc[i], self.vtc[i], self.att, self.attn_ws, Hq, Hkv,
-                                 hd, self.s_max, self.s_max, out_packed=True)
+                                 hd, self.s_max, self.s_max, out_packed=True, cache_packed=self.cache_packed)
             if f32:
                 ops.gemm_packed_resid32(self.att, W[p + "o.wp"], D, self.x32, self.x, split_k=self.o_split, workspace=self.splitk_ws, rows=B)
             else:
@@ -378,7 +384,7 @@ class LanguageModel:
                 ops.row_rstd(x, eps=eps_n, out=rstd)                       # norm weight is folded into qkv.w
                 ops.gemm(x, W[p + "qkv.w"], W[p + "qkv.b"], out=qkv, row_scale=rstd)
             ops.llm_qkv_post(qkv, plan.pos3, sess.inv_freq, q, sess.kc[i], sess.vtc[i], Hq, Hkv, hd, sess.s_max,
-                             cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp)
+                             cfg.mrope_section, sample=plan.sample, slot=plan.slot, k_pack=kp, cache_packed=sess.cache_packed)
             ops.attn_varlen(q, kp, qkv[:, (Hq + Hkv) * hd:], att, plan.cu, plan.cu, mx, Hq, Hkv, hd, causal=True)
             if f8 and (p + "o.w8") in W:
                 ops.quant_rows_fp8(att, out=a8, rs=rs8)

@@ -405,13 +405,37 @@ def rope_table(pos3, inv_freq, out, head_dim, sections):
 
 
 def decode_attn_rope(qkv, rope_cs, slot, k_cache, vt_cache, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len,
-                     scale=None, out_packed=False):
+                     scale=None, out_packed=False, cache_packed=False):
+    """cache_packed: k_cache / vt_cache hold the fragment-packed images (pack_k_cache / pack_vt_cache, written by llm_qkv_post(cache_packed=True))
+    → the one-launch kernel (no workspace needed)."""
     dt = _x16(qkv, k_cache, vt_cache, out)
     scale = head_dim ** -0.5 if scale is None else scale
     _lib.check(_fn("padt_decode_attn_rope", dt)(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
                                          _p(out), _p(workspace), qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max,
-                                         int(max_len), float(scale), 1 if out_packed else 0), "padt_decode_attn_rope")
+                                         int(max_len), float(scale), 1 if out_packed else 0, 1 if cache_packed else 0), "padt_decode_attn_rope")
     return out
+
+
+def pack_k_cache(kc):
+    """Row-major K cache (B, Hkv, S, D) → the fragment-packed image [S/16][D/32][fq 4][frow 16][8] (same shape, padt_decode_attn_rope)."""
+    B, G, S, D = kc.shape
+    return kc.view(B, G, S // 16, 16, D // 32, 4, 8).permute(0, 1, 2, 4, 5, 3, 6).contiguous().view(B, G, S, D)
+
+
+def unpack_k_cache(kp):
+    B, G, S, D = kp.shape
+    return kp.view(B, G, S // 16, D // 32, 4, 16, 8).permute(0, 1, 2, 5, 3, 4, 6).reshape(B, G, S, D)
+
+
+def pack_vt_cache(vt):
+    """Transposed V cache (B, Hkv, D, S) → the fragment-packed image [D/16][S/32][fq 4][frow 16][run 2][4] (same shape)."""
+    B, G, D, S = vt.shape
+    return vt.view(B, G, D // 16, 16, S // 32, 2, 4, 4).permute(0, 1, 2, 4, 6, 3, 5, 7).contiguous().view(B, G, D, S)
+
+
+def unpack_vt_cache(vp):
+    B, G, D, S = vp.shape
+    return vp.view(B, G, D // 16, S // 32, 4, 16, 2, 4).permute(0, 1, 2, 5, 3, 6, 4, 7).reshape(B, G, D, S)
 
 
 def rmsnorm(x, w, out=None, eps=1e-6, add=None, add_div=1, D=None, gelu=False):
@@ -545,13 +569,13 @@ def embed_tokens(ids, img_index, table, proto, image_embeds, out=None, err_flag=
 
 
 def llm_qkv_post(qkv, pos3, inv_freq, q_out, k_cache, vt_cache, n_heads, n_kv_heads, head_dim, s_max, sections,
-                 sample=None, slot=None, lens=None, k_pack=None):
+                 sample=None, slot=None, lens=None, k_pack=None, cache_packed=False):
     dt = _x16(qkv, q_out, k_cache, vt_cache, k_pack)
     assert pos3.dtype == torch.int32 and pos3.is_contiguous() and inv_freq.dtype == torch.float32
     _lib.check(_fn("padt_llm_qkv_post", dt)(_stream(), _p(qkv), qkv.stride(0), _p(pos3), _p(sample), _p(slot), _p(lens),
                                      _p(inv_freq), _p(q_out), q_out.stride(0), _p(k_pack),
                                      k_pack.stride(0) if k_pack is not None else 0, _p(k_cache), _p(vt_cache),
-                                     qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max, sections[0], sections[1]),
+                                     qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max, sections[0], sections[1], 1 if cache_packed else 0),
                "padt_llm_qkv_post")
 
 

@@ -34,9 +34,9 @@ def rel(a, b):
     return ((a - b).abs().max() / (b.abs().max() + 1e-12)).item(), ((a - b).pow(2).mean().sqrt() / (b.pow(2).mean().sqrt() + 1e-12)).item()
 
 
-def q_e4m3(t, block):
-    """e4m3 codes of t under power-of-two scales 2^ceil(log2(amax / 448)) per row (block=None) or per `block` consecutive elements of the last
-    axis (the MX layout: one E8M0 scale per 32 K elements) — returned de-quantised, fp32."""
+def q_codes(t, block):
+    """→ (e4m3 codes, power-of-two scales 2^ceil(log2(amax / 448)), original shape): scales per row (block=None) or per `block` consecutive
+    elements of the last axis (the MX layout: one E8M0 scale per 32 K elements)."""
     shp = t.shape
     if block is not None:
         K = shp[-1]
@@ -46,10 +46,17 @@ def q_e4m3(t, block):
         t = t.reshape(*t.shape[:-1], -1, block)
     amax = t.abs().amax(dim=-1, keepdim=True)
     scale = torch.where(amax > 0, torch.exp2(torch.ceil(torch.log2(amax.clamp_min(1e-38) / 448.0))), torch.ones_like(amax))
-    d = (t / scale).to(E4).to(torch.float32) * scale
-    if block is not None:
-        d = d.reshape(*shp[:-1], -1)[..., : shp[-1]]
-    return d
+    return (t / scale).to(E4), scale, shp
+
+
+def deq(codes, scale, shp):
+    d = codes.to(torch.float32) * scale
+    return d.reshape(*shp[:-1], -1)[..., : shp[-1]] if d.dim() != len(shp) else d
+
+
+def q_e4m3(t, block):
+    """t rounded to e4m3 under the scales of q_codes — de-quantised, fp32."""
+    return deq(*q_codes(t, block))
 
 
 class SplitGemm:
@@ -64,9 +71,18 @@ class SplitGemm:
         if self.lo:
             key = w.data_ptr()
             if key not in self.w8:
-                self.w8[key] = q_e4m3(w, self.block)
-            y = y + F.linear(q_e4m3(x - hi, self.block), self.w8[key])
+                self.w8[key] = q_codes(w, self.block)              # 1 byte per weight (the fp32 image would double a 33 GB 7B oracle)
+            y = y + F.linear(q_e4m3(x - hi, self.block), deq(*self.w8[key]))
         return y
+
+
+def _run_all(run, allc):
+    run("fp16 operands everywhere, weights unfolded (1.0x MFMA)", allc, SplitGemm(None, lo=False))
+    run("GEMMs fp16 hi + fp8 lo x fp8 W [row scales], fp16 attention (1.5x)", allc, SplitGemm(None))
+    run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32 scales], fp16 attention (1.5x)", allc, SplitGemm(32))
+    run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32], exact attention (f32 MFMA)", GEMM_CLASSES + ("head",), SplitGemm(32))
+    run("GEMMs fp16 only (unfolded), exact attention", GEMM_CLASSES + ("head",), SplitGemm(None, lo=False))
+    run("exact GEMMs, fp16 attention only", ATTN_CLASSES, None)
 
 
 def main():
@@ -108,12 +124,12 @@ def main():
             print("%-58s vit %.2e hid %.2e box %.2e score %.2e mask max %.2e rms %.2e  (%.0f s)" % (*row, time.perf_counter() - t0), flush=True)
 
         allc = GEMM_CLASSES + ATTN_CLASSES + ("head",)
-        run("fp16 operands everywhere, weights unfolded (1.0x MFMA)", allc, SplitGemm(None, lo=False))
-        run("GEMMs fp16 hi + fp8 lo x fp8 W [row scales], fp16 attention (1.5x)", allc, SplitGemm(None))
-        run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32 scales], fp16 attention (1.5x)", allc, SplitGemm(32))
-        run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32], exact attention (f32 MFMA)", GEMM_CLASSES + ("head",), SplitGemm(32))
-        run("GEMMs fp16 only (unfolded), exact attention", GEMM_CLASSES + ("head",), SplitGemm(None, lo=False))
-        run("exact GEMMs, fp16 attention only", ATTN_CLASSES, None)
+        if which != "3b":                                          # the 33 GB oracle: only the two rows that decide
+            run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32 scales], fp16 attention (1.5x)", allc, SplitGemm(32))
+            run("GEMMs fp16 hi + fp8 lo x fp8 W [mx32], exact attention (f32 MFMA)", GEMM_CLASSES + ("head",), SplitGemm(32))
+            allc = None
+        if allc is not None:
+            _run_all(run, allc)
 
     md = ["| run (%s, one 46 x 46 image, 8 steps) | ViT high_res rel rms | hidden rows rel rms (worst step) | boxes abs max | score abs | mask logits max / range | mask rel rms |" % which,
           "|---|---|---|---|---|---|---|"]

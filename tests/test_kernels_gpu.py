@@ -536,6 +536,73 @@ def test_decode_attn_rope_matches_unfused_pipeline(ops, D, Hq, Hkv, sec):
     assert torch.equal(un, out1)
 
 
+@pytest.mark.parametrize("Hq,Hkv", [(16, 2), (28, 4)])
+@pytest.mark.parametrize("dt", [BF, torch.float16], ids=["bf16", "fp16"])
+def test_decode_attn_rope_on_fragment_packed_caches(ops, Hq, Hkv, dt):
+    """Round 6: the one-launch decode attention over FRAGMENT-PACKED caches (padt_decode_attn_rope, cache_packed = 1) against the two-launch
+    form on row-major caches, in both operand types:
+      * the caches it appends to, un-packed, are the row-major call's bit for bit — and the prompt pass (llm_qkv_post, cache_packed = 1) writes
+        the same images, at every position draw (same rotation roundings at all three sites);
+      * outputs are the row-major call's up to one 16-bit rounding (different merge order) and sit at the same distance from the fp32 statement;
+      * a sample's output does not depend on what else is in the batch (a block sees one sample) nor on the capacity S_max of the cache
+        (splits sit at absolute key positions): merged decode groups == batch-at-a-time;
+      * the fragment-packed output layout (out_packed) holds the same rows."""
+    D, sec = 128, (16, 24, 24)
+    B, S_max = 5, 1344
+    slots = [577, 63, 1290, 0, 64]
+    g = torch.Generator().manual_seed(91)
+    mk = lambda *shape: torch.randn(*shape, generator=g).cuda().to(dt)
+    qkv, kc, vt = mk(B, (Hq + 2 * Hkv) * D), mk(B, Hkv, S_max, D), mk(B, Hkv, D, S_max)
+    slot_t = torch.tensor(slots, dtype=torch.int32, device="cuda")
+    inv = (1.0 / (1e6 ** (torch.arange(0, D, 2, dtype=torch.float) / D))).cuda()
+    assert torch.equal(ops.unpack_k_cache(ops.pack_k_cache(kc)), kc) and torch.equal(ops.unpack_vt_cache(ops.pack_vt_cache(vt)), vt)
+    for seed in range(1, 8):
+        gpos = torch.randint(0, 4000, (3, B), dtype=torch.int32, generator=torch.Generator().manual_seed(seed)).cuda()
+        cs = torch.zeros(B, D // 2, 2, device="cuda")
+        ops.rope_table(gpos, inv, cs, D, sec)
+        k1, v1 = kc.clone(), vt.clone()
+        o1 = torch.zeros(B, Hq * D, device="cuda", dtype=dt)
+        ops.decode_attn_rope(qkv, cs, slot_t, k1, v1, o1, ops.new_decode_workspace(B, Hkv, D, S_max, "cuda"), Hq, Hkv, D, S_max, S_max)
+        kp, vp = ops.pack_k_cache(kc), ops.pack_vt_cache(vt)
+        o2 = torch.zeros_like(o1)
+        ops.decode_attn_rope(qkv, cs, slot_t, kp, vp, o2, None, Hq, Hkv, D, S_max, S_max, cache_packed=True)
+        assert torch.equal(ops.unpack_k_cache(kp), k1) and torch.equal(ops.unpack_vt_cache(vp), v1), f"packed append differs (positions seed {seed})"
+        kq, vq = ops.pack_k_cache(kc), ops.pack_vt_cache(vt)
+        qd = torch.zeros_like(o1)
+        ops.llm_qkv_post(qkv, gpos, inv, qd, kq, vq, Hq, Hkv, D, S_max, sec, slot=slot_t, cache_packed=True)
+        assert torch.equal(kq, kp) and torch.equal(vq, vp), f"prompt-pass append into the packed images differs (positions seed {seed})"
+        assert torch.isfinite(o2.float()).all()
+        # one 16-bit rounding: |a - b| <= one ulp of the larger magnitude (8 / 11 mantissa bits)
+        ulp = torch.maximum(o1.float().abs(), o2.float().abs()) * (2.0 ** -7 if dt == BF else 2.0 ** -10) + 1e-6
+        assert bool(((o1.float() - o2.float()).abs() <= ulp).all()), f"more than one rounding apart (positions seed {seed})"
+    # fp32 statement from the rotated q (prompt kernel) and the appended caches
+    rep = Hq // Hkv
+    ref = torch.zeros(B, Hq * D, device="cuda")
+    for b in range(B):
+        L = slots[b] + 1
+        kk = k1[b, :, :L].float().repeat_interleave(rep, 0)
+        vv = v1[b, :, :, :L].float().transpose(1, 2).repeat_interleave(rep, 0)
+        sc = torch.einsum("hd,hld->hl", qd[b].float().view(Hq, D), kk) * D ** -0.5
+        ref[b] = torch.einsum("hl,hld->hd", torch.softmax(sc, -1), vv).reshape(-1)
+    e1, e2 = (o1.float() - ref).abs().max().item(), (o2.float() - ref).abs().max().item()
+    print(f"\n[decode attention, packed caches, {Hq}:{Hkv} {dt}] |two launches - fp32| {e1:.3e}, |one launch - fp32| {e2:.3e}, differing outputs {(o1 != o2).sum().item()} of {o1.numel()}")
+    assert e2 <= 1.25 * e1 + 1e-4
+    # batch- and capacity-invariance: sample 2 alone, in a smaller cache
+    S2 = 1344 - 64 * 0
+    for rows, S_small in (([2], S_max), ([2, 0], S_max), ([1, 4], 128)):
+        kk = ops.pack_k_cache(kc[rows, :, :S_small].contiguous())
+        vv = ops.pack_vt_cache(vt[rows, :, :, :S_small].contiguous())
+        oo = torch.zeros(len(rows), Hq * D, device="cuda", dtype=dt)
+        ops.decode_attn_rope(qkv[rows].contiguous(), cs[rows].contiguous(), slot_t[rows].contiguous(), kk, vv, oo, None, Hq, Hkv, D, S_small, S_small,
+                             cache_packed=True)
+        assert torch.equal(oo, o2[rows]), f"rows {rows} at capacity {S_small}: the output depends on the batch or on S_max"
+    outp = torch.zeros(16, Hq * D, device="cuda", dtype=dt)
+    ops.decode_attn_rope(qkv, cs, slot_t, ops.pack_k_cache(kc), ops.pack_vt_cache(vt), outp, None, Hq, Hkv, D, S_max, S_max, out_packed=True, cache_packed=True)
+    un = torch.zeros_like(o2)
+    ops.pack_rows(outp, un, B, to_packed=False)
+    assert torch.equal(un, o2)
+
+
 # ------------------------------------------------------------------------------------------------------------ row kernels
 def test_rmsnorm_layernorm(ops):
     g = ops.rmsnorm(rnd(5, 1280, seed=47), (1 + 0.1 * rnd(1280, seed=41).float()).to(BF), gelu=True)

@@ -26,7 +26,7 @@ LIB.decode_attn_rope_v3.argtypes = [_vp, _vp, _l, _vp, _vp, _vp, _vp, _vp, _i, _
 LIB.decode_attn_rope_v3.restype = _i
 
 
-def v3(qkv, cs, slot, kc, vt, out, Hq, Hkv, D, S_max, packed=False, nw=8, out_packed=False):
+def attn_v3(qkv, cs, slot, kc, vt, out, Hq, Hkv, D, S_max, packed=False, nw=8, out_packed=False):
     """round 6: ONE launch, nw waves per (kv head, sample), online merge in registers + LDS, 16-bit output rows written directly."""
     st = LIB.decode_attn_rope_v3(torch.cuda.current_stream().cuda_stream, qkv.data_ptr(), qkv.stride(0), cs.data_ptr(), slot.data_ptr(),
                                  kc.data_ptr(), vt.data_ptr(), out.data_ptr(), qkv.shape[0], Hq, Hkv, D, S_max, float(D ** -0.5),
@@ -102,10 +102,10 @@ def parity(Hq, Hkv, slots, S_max=640, D=128, sec=(16, 24, 24), seed=1):
     for nw in (4, 8):                                              # v3: appends bit-identical, outputs at the same distance to fp32
         o4 = torch.zeros_like(o2)
         k4, v4 = kc.clone(), vt.clone()
-        v3(qkv, csx, slot_t, k4, v4, o4, Hq, Hkv, D, S_max, nw=nw)
+        attn_v3(qkv, csx, slot_t, k4, v4, o4, Hq, Hkv, D, S_max, nw=nw)
         o5 = torch.zeros_like(o2)
         kp4, vp4 = pack_k(kc), pack_vt(vt)
-        v3(qkv, csx, slot_t, kp4, vp4, o5, Hq, Hkv, D, S_max, packed=True, nw=nw)
+        attn_v3(qkv, csx, slot_t, kp4, vp4, o5, Hq, Hkv, D, S_max, packed=True, nw=nw)
         torch.cuda.synchronize()
         print(f"[v3 nw={nw}] K append equal {torch.equal(k4, k1)}, V append equal {torch.equal(v4, v1)}; |v3 - fp32| max {(o4.float() - ref).abs().max().item():.3e} "
               f"(library {(o1.float() - ref).abs().max().item():.3e}); |v3 - library| max {(o4.float() - o1.float()).abs().max().item():.3e} "
@@ -167,7 +167,7 @@ def timing(B, S_max, slot, Hq=16, Hkv=2, D=128):
     def mk3(nw, packed):
         def f():
             j[0] += 1
-            v3(qkv, cs, slot_t, kcs[j[0] % nset], vts[j[0] % nset], out, Hq, Hkv, D, S_max, packed=packed, nw=nw)
+            attn_v3(qkv, cs, slot_t, kcs[j[0] % nset], vts[j[0] % nset], out, Hq, Hkv, D, S_max, packed=packed, nw=nw)
         return f
     t34, t38, t34p, t38p = graph_time(mk3(4, False)), graph_time(mk3(8, False)), graph_time(mk3(4, True)), graph_time(mk3(8, True))
     t1, t2, t3 = graph_time(lib), graph_time(new), graph_time(newp)
