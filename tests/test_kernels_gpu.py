@@ -543,7 +543,7 @@ def test_decode_attn_rope_on_fragment_packed_caches(ops, Hq, Hkv, dt):
     form on row-major caches, in both operand types:
       * the caches it appends to, un-packed, are the row-major call's bit for bit — and the prompt pass (llm_qkv_post, cache_packed = 1) writes
         the same images, at every position draw (same rotation roundings at all three sites);
-      * outputs are the row-major call's up to one 16-bit rounding (different merge order) and sit at the same distance from the fp32 statement;
+      * outputs are the row-major call's up to two 16-bit roundings (different merge order) and sit at the same distance from the fp32 statement;
       * a sample's output does not depend on what else is in the batch (a block sees one sample) nor on the capacity S_max of the cache
         (splits sit at absolute key positions): merged decode groups == batch-at-a-time;
       * the fragment-packed output layout (out_packed) holds the same rows."""
@@ -572,9 +572,12 @@ def test_decode_attn_rope_on_fragment_packed_caches(ops, Hq, Hkv, dt):
         ops.llm_qkv_post(qkv, gpos, inv, qd, kq, vq, Hq, Hkv, D, S_max, sec, slot=slot_t, cache_packed=True)
         assert torch.equal(kq, kp) and torch.equal(vq, vp), f"prompt-pass append into the packed images differs (positions seed {seed})"
         assert torch.isfinite(o2.float()).all()
-        # one 16-bit rounding: |a - b| <= one ulp of the larger magnitude (8 / 11 mantissa bits)
-        ulp = torch.maximum(o1.float().abs(), o2.float().abs()) * (2.0 ** -7 if dt == BF else 2.0 ** -10) + 1e-6
-        assert bool(((o1.float() - o2.float()).abs() <= ulp).all()), f"more than one rounding apart (positions seed {seed})"
+        # at most two 16-bit roundings apart (8 / 11 mantissa bits) + fp32 noise on outputs that cancel to ~0: the probabilities are rounded to
+        # 16 bits relative to the RUNNING maximum here and to each split's own maximum in the two-launch form, then merged in a different order
+        # (an output that cancels to a small value carries the P-rounding noise of the whole row: an absolute term of one 16-bit step of the row scale)
+        eps16 = 2.0 ** -8 if dt == BF else 2.0 ** -11
+        lim = torch.maximum(o1.float().abs(), o2.float().abs()) * 4 * eps16 + 2 * eps16 * o1.float().pow(2).mean().sqrt()
+        assert bool(((o1.float() - o2.float()).abs() <= lim).all()), f"one-launch and two-launch outputs further apart than the operand type's P rounding allows (positions seed {seed})"
     # fp32 statement from the rotated q (prompt kernel) and the appended caches
     rep = Hq // Hkv
     ref = torch.zeros(B, Hq * D, device="cuda")
