@@ -229,10 +229,20 @@ int padt_mask_scatter(void* stream, const void* e2, long ld_e2, const void* mask
  * [hi(K) | lo(K)] per row against a weight image [W | W]: padt_gemm_bf16_ex below IS padt_gemm_bf16 at K' = 2K (fp32
  * accumulation of hi*W + lo*W), with two extra epilogue options:
  *   resid_f32: epilogue 2 adds an fp32 residual R[M][ldr] (out_f32 must be 1) — the fp32 residual stream, in place allowed;
- *   lo_off:    bf16 output stored as a pair, hi at C[m][n], lo at C[m][lo_off + n] (lo_off >= N, ldc >= lo_off + N). */
+ *   lo_off:    bf16 output stored as a pair, hi at C[m][n], lo at C[m][lo_off + n] (lo_off >= N, ldc >= lo_off + N); with epilogue 3 (round 6:
+ *              the split SwiGLU of precision="reference" — exact expf / division as padt_swiglu_split, no fp32 gate / up rows in between) the
+ *              pair is silu(gate) * up, n < N / 2, lo_off >= N / 2. */
 int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long ldw, const void* bias, void* C, long ldc,
                       const void* R, long ldr, long M, long N, long K, int epilogue, int out_f32, const void* row_scale,
                       int resid_f32, long lo_off);
+/* The same split-precision projection for FEW rows (M <= 64: the decode steps of precision="reference"), bound by the weight stream:
+ * A rows = [hi(K) | lo(K)] pairs with the lo half a_lo_off elements into the row, W [N][ldw] with its first K columns used and read ONCE
+ * (every weight fragment multiplies the hi and the lo fragment of a row block) — pass padt_gemm_bf16_ex's doubled image with ldw = 2K.
+ * epilogue 0 / 2: C fp32 = A_hi W^T + A_lo W^T + bias (+ R_f32, in place allowed), c_lo_off = 0; epilogue 3: SwiGLU over [gate16 | up16]-interleaved
+ * weight rows (N % 32 == 0), C = bf16 split rows — silu(gate) * up as (hi, lo) pairs, hi at C[m][n], lo at C[m][c_lo_off + n], n < N / 2 (exact expf and
+ * division, as padt_swiglu_split).  HF:641-757 at one token per row. */
+int padt_gemm_split_rows(void* stream, const void* A_split, long lda, long a_lo_off, const void* W, long ldw, const void* bias, void* C,
+                         long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue);
 /* Row kernel: y0 = f(x), y1 = f(x) + pos[r % pos_rows], f(x) = act(RMSNorm_w(x[idx[r]] + add[r / add_div])), every stage
  * optional (null pointer); x bf16 or fp32 (x_f32); each output off (mode 0), fp32 rows (1) or bf16 split rows (2) laid out
  * [hi(chunk) lo(chunk)] x D/chunk.  padt_decoder.py:71-74 (RMSNorm), :30-31 (+ positional query), :220 (repeat4(low) + high),

@@ -68,6 +68,7 @@ struct GemmArgs {
     unsigned long long* prof = nullptr;   // tile kernels: optional in-kernel launch timing slot (padt_gemm_profile)
     x16_t* C2 = nullptr;        // fp32 output: optional bf16 mirror of C (fp32 residual stream → the next projection's A operand), row-major
     long ldc2 = 0;               //   or, with c_pack, in the fragment-packed activation layout (decode steps)
+    long a_lo_off = 0;           // skinny kernel, WQ = 2: A rows are (hi | lo) pairs, the lo half starts a_lo_off elements into the row (padt_gemm_split_rows)
 };
 
 // bf16 split pair of 4 fp32 values: hi = bf16(x), lo = bf16(x - hi)  (hi + lo carries 16 mantissa bits)
@@ -173,6 +174,20 @@ PADT_DEV void store_swiglu(const GemmArgs& p, int m, int n_gate, f32x4 g, f32x4 
     const float sc = p.rs ? p.rs[m] : 1.0f;
     f32x4 gs = f32x4{1.f, 1.f, 1.f, 1.f}, us = gs;
     if (p.cs) { gs = *reinterpret_cast<const f32x4*>(p.cs + n_gate); us = *reinterpret_cast<const f32x4*>(p.cs + n_gate + 16); }
+    if (p.lo_off) {
+        // split SwiGLU (precision="reference", round 6): exact expf + IEEE division (what padt_swiglu_split computes), (hi, lo) pair with lo at lo_off
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const float gv = g[r] * sc * gs[r] + gb[r];
+            o[r] = gv / (1.0f + expf(-gv)) * (u[r] * sc * us[r] + ub[r]);
+        }
+        u32x2 hi, lo;
+        split4(o, hi, lo);
+        x16_t* c = reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no;
+        *reinterpret_cast<u32x2*>(c) = hi;
+        *reinterpret_cast<u32x2*>(c + p.lo_off) = lo;
+        return;
+    }
 #pragma unroll
     for (int r = 0; r < 4; ++r) o[r] = silu(g[r] * sc * gs[r] + gb[r]) * (u[r] * sc * us[r] + ub[r]);
     x16_t* c = reinterpret_cast<x16_t*>(p.C) + act_index(m, no, p.ldc, p.c_pack);
@@ -343,6 +358,9 @@ __global__ __launch_bounds__(256) void gemm_tile_kernel(GemmArgs p) {
 //   y = (x * rsqrt(mean(x^2)+eps) * g) @ W^T  ==  rstd[m] * (x @ (W·diag(g))^T)[m]  — the norm weight g is folded into the
 //   weight matrix once at load time (weights.py), the per-row sum of squares is accumulated from the x fragments the
 //   MFMA consumes anyway, and rstd scales the fp32 accumulator.
+// WQ = 2 (round 6, padt_gemm_split_rows): split-precision A rows [hi(K) | lo(K)] against the PLAIN weight matrix — every weight fragment is
+//   loaded ONCE and multiplied with the row block's hi and lo fragments (acc += W·hi + W·lo per K-step).  The decode steps of
+//   precision="reference" streamed the doubled image [W | W] through the K' = 2K loop: twice the HBM bytes of a launch that is bound by them.
 // WQ = 1: fp8 weights (OCP e4m3, per-output-row scale in p.cs) in the fp8 fragment-packed image [N/16][Kp/64][64 lanes][16 B]: a lane's
 //   16 bytes hold its 8 elements of K-step 2t and its 8 elements of K-step 2t + 1 — one 1-KiB wave load feeds two MFMA K-steps, the
 //   weight stream is half the bf16 bytes; bytes are converted to bf16 fragments in registers (exact), accumulation stays fp32.
@@ -404,6 +422,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
     const int g_stride = NW * gridDim.y;
     for (int gi = blockIdx.y * NW + wave; gi * KG < nks; gi += g_stride * GPI) {
         x16x8 wf[U][NT], xf[U][MT];
+        x16x8 xl[WQ == 2 ? U : 1][WQ == 2 ? MT : 1];             // WQ = 2: the lo halves of the same rows
 #pragma unroll
         for (int u = 0; u < U; ++u) {
             const int ks = (gi + (u / KG) * g_stride) * KG + (u % KG);
@@ -411,7 +430,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             const bool kok = (ks < nks) && (k < p.K);
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                if (WQ) {
+                if (WQ == 1) {
                     if ((u & 1) == 0) {                           // U is even and groups start at even K-steps: one load = K-steps (ks, ks + 1)
                         const unsigned char* wq = reinterpret_cast<const unsigned char*>(p.W) +
                                                   (((long)(n0 / 16 + i) * (p.ldw / 64) + (ks >> 1)) * 64 + lane) * 16;
@@ -428,6 +447,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
             }
 #pragma unroll
             for (int j = 0; j < MT; ++j) xf[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + (long)ks * xstep) : zero_frag();
+            if constexpr (WQ == 2) {
+#pragma unroll
+                for (int j = 0; j < MT; ++j) xl[u][j] = (kok && xok[j]) ? ld_frag(xrow[j] + p.a_lo_off + (long)ks * xstep) : zero_frag();
+            }
             if (NORM) {
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
@@ -443,7 +466,10 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_kernel(GemmArgs p, float 
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) acc[i][j] = mfma16(wf[u][i], xf[u][j], acc[i][j]);
+                for (int j = 0; j < MT; ++j) {
+                    acc[i][j] = mfma16(wf[u][i], xf[u][j], acc[i][j]);
+                    if constexpr (WQ == 2) acc[i][j] = mfma16(wf[u][i], xl[u][j], acc[i][j]);
+                }
     }
 
     if (NORM) {
@@ -654,16 +680,17 @@ static int gemm_bf16_impl(void* stream, const void* A, long lda, const void* W, 
         padt_set_error("padt_gemm_bf16_ex: an fp32 residual needs epilogue 2, fp32 output and a 16-byte aligned R");
         return -1;
     }
-    if (lo_off && (out_f32 || epilogue == EPI_SWIGLU || (lo_off & 3) || lo_off < N || ldc < lo_off + N)) {
-        padt_set_error("padt_gemm_bf16_ex: a split (hi|lo) output needs bf16 output, lo_off % 4 == 0, lo_off >= N and ldc >= lo_off + N");
+    if (lo_off && (out_f32 || (lo_off & 3) || lo_off < out_n || ldc < lo_off + out_n)) {
+        padt_set_error("padt_gemm_bf16_ex: a split (hi|lo) output needs bf16 output, lo_off % 4 == 0, lo_off >= the output width (N; N / 2 with SwiGLU) and ldc >= lo_off + that width");
         return -1;
     }
+    const int tag256 = (epilogue == EPI_SWIGLU && lo_off) ? 1 : out_f32;      // gemm_tile256_kernel<EPI_SWIGLU, true> = the split SwiGLU (16-bit pairs)
     if (C2 && (!out_f32 || (ldc2 & 7) || ((uintptr_t)C2 & 15) || ldc2 < N)) {
         padt_set_error("padt_gemm_resid32: the bf16 mirror needs fp32 output, ldxb % 8 == 0, ldxb >= N and a 16-byte aligned pointer");
         return -1;
     }
     unsigned long long* prof = (M > 64) ? next_prof_slot() : nullptr;
-    if (M > 64 && PADT_TWIN(padt_gemm256_try)(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
+    if (M > 64 && PADT_TWIN(padt_gemm256_try)(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, tag256, rs, &rp, &done, resid_f32, lo_off, C2, ldc2, prof) == 0) {
         if (done >= M) {
             hipError_t e = hipGetLastError();
             if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
@@ -719,6 +746,48 @@ extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const vo
                                  const void* row_scale, int resid_f32, long lo_off) {
     return gemm_bf16_impl(stream, A, lda, W, ldw, bias, C, ldc, R, ldr, M, N, K, epilogue, out_f32, row_scale,
                           RopeEpi{nullptr, nullptr, 0, 0, 0}, resid_f32, lo_off);
+}
+#endif
+
+#if !PADT_OP16_F16
+// Split-precision projection for FEW rows (the decode steps of precision="reference"; padt_decoder / HF Linear at one token per row):
+// C_f32[m][n] = epi(sum_k (hi[m][k] + lo[m][k]) * W[n][k] + bias[n] (+ R_f32[m][n])), A rows = [hi(K) | lo(K)] bf16 pairs (lo at a_lo_off),
+// W [N][ldw] bf16 with the first K columns used — pass the doubled image [W | W] of padt_gemm_bf16_ex with ldw = 2K and it is read ONCE.
+// M <= 64; epilogue 0 or 2 (fp32 residual, in place allowed) → fp32 C; epilogue 3 (SwiGLU over [gate16 | up16]-interleaved weight rows, N % 32 == 0)
+// → C = bf16 split rows: silu(gate) * up as (hi, lo) pairs, hi at C[m][n], lo at C[m][c_lo_off + n], n < N / 2.
+extern "C" int padt_gemm_split_rows(void* stream, const void* A_split, long lda, long a_lo_off, const void* W, long ldw, const void* bias, void* C,
+                                    long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue) {
+    if (M <= 0 || N <= 0) return 0;
+    const bool glu = epilogue == EPI_SWIGLU;
+    if (M > 64 || K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || (a_lo_off & 7) || a_lo_off < K || ((uintptr_t)A_split & 15) || ((uintptr_t)W & 15) ||
+        (ldc & 3) || ((uintptr_t)C & 15) || ((uintptr_t)bias & 7) || (epilogue != EPI_NONE && epilogue != EPI_RESID && !glu) ||
+        (epilogue == EPI_RESID && (R_f32 == nullptr || (ldr & 3) || ((uintptr_t)R_f32 & 15))) ||
+        (glu && ((N & 31) || (c_lo_off & 3) || c_lo_off < N / 2 || ldc < c_lo_off + N / 2)) || (!glu && c_lo_off != 0)) {
+        padt_set_error("padt_gemm_split_rows: M <= 64, K / lda / ldw / a_lo_off multiples of 8, a_lo_off >= K, 16-byte aligned A / W / C / R, epilogue 0, 2 "
+                       "(fp32 C, c_lo_off 0) or 3 (N % 32 == 0, bf16 pairs: c_lo_off % 4 == 0, c_lo_off >= N / 2, ldc >= c_lo_off + N / 2)");
+        return -1;
+    }
+    GemmArgs a{(const x16_t*)A_split, lda, (const x16_t*)W, ldw, (const x16_t*)bias, C, ldc, (const x16_t*)R_f32, ldr, (int)M, (int)N, (int)K};
+    a.a_lo_off = a_lo_off;
+    a.lo_off = c_lo_off;
+    a.r_f32 = epilogue == EPI_RESID ? 1 : 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (glu) {
+        if (M <= 16) launch_skinny<1, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
+    } else if (epilogue == EPI_RESID) {
+        if (M <= 16) launch_skinny<1, EPI_RESID, true, false, false, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_RESID, true, false, false, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_RESID, true, false, false, 2>(a, 0.f, s);
+    } else {
+        if (M <= 16) launch_skinny<1, EPI_NONE, true, false, false, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_NONE, true, false, false, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_NONE, true, false, false, 2>(a, 0.f, s);
+    }
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
 }
 #endif
 

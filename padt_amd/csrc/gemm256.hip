@@ -109,6 +109,16 @@ PADT_DEV f32x4 mfma_f8(x16x8 a_lo, x16x8 a_hi, x16x8 b_lo, x16x8 b_hi, f32x4 c) 
 }
 
 PADT_DEV void unpack4b(u32x2 v, float* f) { unpack4x(v, f); }
+// x * sigmoid(x) with the exact expf and an IEEE division: the split-output SwiGLU of precision="reference" (what padt_swiglu_split computes)
+PADT_DEV float silu_exact(float x) { return x / (1.0f + expf(-x)); }
+// (hi, lo) pair of four fp32 values at cp / cp + lo_off: hi = X(x), lo = X(x - hi)
+PADT_DEV void store_split4(x16_t* cp, long lo_off, const float* o) {
+    const u32x2 hi = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
+    float hv[4];
+    unpack4x(hi, hv);
+    *reinterpret_cast<u32x2*>(cp) = hi;
+    *reinterpret_cast<u32x2*>(cp + lo_off) = u32x2{pack2x(o[0] - hv[0], o[1] - hv[1]), pack2x(o[2] - hv[2], o[3] - hv[3])};
+}
 }  // namespace
 
 // MF = 16-row MFMA blocks per wave per m-half: tile height 64*MF (256, 192 or 128 rows) x 256 columns.  The shorter tiles
@@ -116,9 +126,12 @@ PADT_DEV void unpack4b(u32x2 v, float* f) { unpack4x(v, f); }
 // FP8: A and W are OCP e4m3 bytes (K-tile = 128 elements = the same 128 bytes per row: staging, LDS image and swizzle are unchanged); a
 // lane's MFMA operand is the 32 consecutive K bytes [32 fq, 32 fq + 32) = LDS chunks 2 fq and 2 fq + 1, one 16x16x128 MFMA per fragment
 // pair and K-tile instead of two 16x16x32; the accumulator is scaled by rs[m] * cs[n] (activation row scale x weight row scale).
+// EPI_SWIGLU with OUT_F32 set (round 6) = the SPLIT SwiGLU of precision="reference": silu(gate) * up evaluated with the exact expf / division and
+// stored as a (hi, lo) 16-bit pair, lo at p.lo_off — the [hi | lo] A operand of the down projection, without the fp32 gate / up rows in between.
 template <int EPI, bool OUT_F32, int MF, bool FP8 = false>
 __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
     constexpr int TMV = 64 * MF;
+    constexpr bool SPLIT_GLU = (EPI == EPI_SWIGLU) && OUT_F32;
     constexpr int ES = FP8 ? 1 : 2;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -334,9 +347,12 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
 #pragma unroll
                         for (int r = 0; r < 4; ++r)
                             o[r] = FP8 ? silu(acc[mi][ni][r] * (rsc[mi] * csc[ni][r]) + bv[ni][r]) * (acc[mi][ni + 1][r] * (rsc[mi] * csc[ni + 1][r]) + bv[ni + 1][r])
-                                       : silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
+                                 : SPLIT_GLU ? silu_exact(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r])
+                                             : silu(acc[mi][ni][r] * rsc[mi] + bv[ni][r]) * (acc[mi][ni + 1][r] * rsc[mi] + bv[ni + 1][r]);
                         const int no = (n0 >> 1) + wc * 32 + (ni >> 1) * 16 + fq * 4;
-                        if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
+                        if (SPLIT_GLU) {
+                            if (live) store_split4(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no, p.lo_off, o);
+                        } else if (live) *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) = u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
                     }
                 } else {
 #pragma unroll
@@ -423,9 +439,12 @@ __global__ __launch_bounds__(512) void gemm_tile256_kernel(Gemm256Args p) {
                 unpack4b(*reinterpret_cast<const u32x2*>(bp), gb);
                 unpack4b(*reinterpret_cast<const u32x2*>(bp + (p.bias ? 16 : 0)), ub);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) o[r] = silu(acc[mi][ni][r] * rsc + gb[r]) * (acc[mi][ni + 1][r] * rsc + ub[r]);
+                for (int r = 0; r < 4; ++r)
+                    o[r] = SPLIT_GLU ? silu_exact(acc[mi][ni][r] * rsc + gb[r]) * (acc[mi][ni + 1][r] * rsc + ub[r])
+                                     : silu(acc[mi][ni][r] * rsc + gb[r]) * (acc[mi][ni + 1][r] * rsc + ub[r]);
                 const int no = (n >> 5) * 16 + (n & 15);
-                *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) =
+                if (SPLIT_GLU) store_split4(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no, p.lo_off, o);
+                else *reinterpret_cast<u32x2*>(reinterpret_cast<x16_t*>(p.C) + (long)m * p.ldc + no) =
                     u32x2{pack2x(o[0], o[1]), pack2x(o[2], o[3])};
             }
         } else {
@@ -569,7 +588,7 @@ static long launch256(Gemm256Args a, hipStream_t s) {
     a2.N = a.N - (int)n1;
     a2.W = a.W + n1 * a.ldw;
     if (a.bias) a2.bias = a.bias + n1;
-    a2.C = F32 ? (void*)((float*)a.C + c1) : (void*)((x16_t*)a.C + c1);
+    a2.C = (F32 && EPI != EPI_SWIGLU) ? (void*)((float*)a.C + c1) : (void*)((x16_t*)a.C + c1);    // the split SwiGLU (F32 tag) writes 16-bit pairs
     if (a.R) a2.R = a.r_f32 ? (const x16_t*)((const float*)a.R + c1) : a.R + c1;
     if (a.C2) a2.C2 = a.C2 + c1;
     run256<EPI, F32>(a1, pm.mf, s);
@@ -605,6 +624,7 @@ extern "C" int PADT_TWIN(padt_gemm256_try)(void* stream, const void* A, long lda
         case 4: *rows_done = launch256<EPI_RESID, false>(a, s); break;
         case 5: *rows_done = launch256<EPI_RESID, true>(a, s); break;
         case 6: *rows_done = launch256<EPI_SWIGLU, false>(a, s); break;
+        case 7: *rows_done = launch256<EPI_SWIGLU, true>(a, s); break;      // split SwiGLU: (hi, lo) 16-bit pairs, lo at lo_off (not an fp32 tile)
         default: return 1;
     }
     return 0;

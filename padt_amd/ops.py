@@ -750,13 +750,16 @@ OUT_NONE, OUT_F32, OUT_SPLIT = 0, 1, 2
 
 def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_mode=OUT_F32, M=None):
     """Split-precision GEMM (include/padt_hip.h "hp decoder"): a_split (M, 2K) bf16 rows [hi | lo], w2 (N, 2K) = [W | W].
-    out_mode OUT_F32 → fp32 (M, N) [+ fp32 residual, in place allowed]; OUT_SPLIT → bf16 (M, 2N) rows [hi | lo]."""
+    out_mode OUT_F32 → fp32 (M, N) [+ fp32 residual, in place allowed]; OUT_SPLIT → bf16 (M, 2N) rows [hi | lo]; epilogue EPI_SWIGLU (OUT_SPLIT only,
+    weight rows [gate16 | up16]-interleaved) → bf16 (M, 2 * N/2) split rows of silu(gate) * up."""
     lib = _lib.load()
     _chk_bf16(a_split, w2, bias)
     M = a_split.shape[0] if M is None else M
     N, K2 = w2.shape
     assert a_split.shape[1] == K2, (a_split.shape, w2.shape)
+    n_out = N // 2 if epilogue == EPI_SWIGLU else N
     if out_mode == OUT_F32:
+        assert epilogue != EPI_SWIGLU
         if out is None:
             out = torch.empty((M, (N + 3) // 4 * 4), device=a_split.device, dtype=F32)
         assert out.dtype == F32 and out.stride(-1) == 1
@@ -764,11 +767,17 @@ def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, 
             assert residual.dtype == F32 and epilogue == EPI_RESID
         lo_off = 0
     else:
-        assert residual is None and N % 4 == 0
+        assert residual is None and n_out % 4 == 0
         if out is None:
-            out = torch.empty((M, 2 * N), device=a_split.device, dtype=BF16)
-        assert out.dtype == BF16 and out.shape[1] >= 2 * N
-        lo_off = N
+            out = torch.empty((M, 2 * n_out), device=a_split.device, dtype=BF16)
+        assert out.dtype == BF16 and out.shape[1] >= 2 * n_out
+        lo_off = n_out
+    if M <= 64 and K2 % 16 == 0 and ((out_mode == OUT_F32 and epilogue in (EPI_NONE, EPI_RESID)) or epilogue == EPI_SWIGLU):
+        # few rows (a decode step): bound by the weight stream — read W once and multiply it with the hi and the lo fragments (padt_gemm_split_rows)
+        K = K2 // 2
+        _lib.check(lib.padt_gemm_split_rows(_stream(), _p(a_split), a_split.stride(0), K, _p(w2), w2.stride(0), _p(bias), _p(out), out.stride(0), lo_off,
+                                            _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue), "padt_gemm_split_rows")
+        return out
     if GEMM_LOG is not None:
         GEMM_LOG.append(("hp", a_split, w2, bias, out, epilogue, residual, out_mode, M))
     _tg_note("hp", M, N, K2 // 2)                                    # algorithmic K: the MFMA pipe executes 2K (hi and lo operands)

@@ -6,8 +6,9 @@ This mode meets it on every float output, at 2x the MFMA work:
 
   * every GEMM A operand of ViT, merger, prototype projection and LLM is a bf16 (hi, lo) pair — hi = bf16(x), lo = bf16(x − hi): 16 mantissa
     bits — against the weight image [W | W] (``padt_gemm_bf16_ex`` at K' = 2K; checkpoints are bf16, so W itself is exact; NO norm folding:
-    the normalised rows are produced explicitly by ``padt_norm_split``), fp32 accumulation, fp32 residual streams, fp32 SwiGLU
-    (``padt_swiglu_split``), fp32 LayerNorm of the prototypes (``padt_layernorm_f32``);
+    the normalised rows are produced explicitly by ``padt_norm_split``), fp32 accumulation, fp32 residual streams, fp32 SwiGLU (round 6: the
+    gate/up GEMM's own epilogue — exact expf / division on the fp32 accumulators, (hi, lo) pair out — instead of fp32 gate / up rows + a
+    ``padt_swiglu_split`` pass), fp32 LayerNorm of the prototypes (``padt_layernorm_f32``);
   * ALL attention in fp32 (``padt_attn_f32``, the decoder's varlen kernel): the ViT's 64-token windows and 2116 x 2116 full layers, the LLM's
     causal GQA prompt pass (kv_group / causal arguments, round 5) and its decode steps over an fp32 [K | V] cache per layer (one row per cached
     token, samples at a fixed stride; ``len_k`` = the valid keys; the step's new rows land by ``padt_scatter_rows_f32``); rotary in fp32
@@ -18,8 +19,10 @@ This mode meets it on every float output, at 2x the MFMA work:
   * token / image / prototype embeddings are gathered from ONE fp32 table [E ‖ prototypes ‖ image rows] (no 16-bit rounding on the way in),
     the per-step hidden rows are kept in fp32 for ``parseVRTintoCompletion`` → ``vl_decode``.
 
-Decode steps run eagerly (10 launches per layer); this is a precision mode, not the throughput path: bench.py prints its rate next to the
-headline (``reference_precision``).  Everything below is kernel sequencing — no arithmetic in PyTorch.
+Round 6: attention runs on the f32-input MFMA (``padt_attn_f32_mfma``), decode steps are captured hipGraphs over static session buffers, and
+their projections read every weight ONCE (``padt_gemm_split_rows``: a weight fragment multiplies the hi and the lo fragment of a row block; the
+K' = 2K form streamed the doubled image).  bench.py prints this mode's rate next to the headline (``reference_precision``).  Everything below is
+kernel sequencing — no arithmetic in PyTorch.
 """
 from typing import Dict
 
@@ -27,7 +30,7 @@ import torch
 
 from . import ops
 from .config import PaDTConfig
-from .weights import _pad_cols, _pad_rows, _pad_to
+from .weights import _pad_cols, _pad_rows, _pad_to, interleave16
 
 BF16, F16, F32 = torch.bfloat16, torch.float16, torch.float32
 
@@ -38,8 +41,9 @@ def _dbl(t: torch.Tensor) -> torch.Tensor:
 
 
 def prepare_reference_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, device) -> dict:
-    """Checkpoint → bf16 weight images of the reference-precision path: plain nn.Linear matrices doubled along K, nothing folded, gate / up
-    stacked [gate(I_pad) ; up(I_pad)] (un-interleaved: the SwiGLU is its own fp32 kernel), MLP intermediates zero-padded to a multiple of 64."""
+    """Checkpoint → bf16 weight images of the reference-precision path: plain nn.Linear matrices doubled along K, nothing folded, gate / up rows
+    interleaved in 16-row blocks [gate16 | up16 | ...] (round 6: the SwiGLU is the gate/up GEMM's epilogue — exact expf / division on the fp32
+    accumulators, (hi, lo) pair out; the fp32 gate / up rows of round 5 are never written), MLP intermediates zero-padded to a multiple of 64."""
     dev = torch.device(device)
     R = {}
 
@@ -56,8 +60,8 @@ def prepare_reference_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, devi
         R[d + "norm1"], R[d + "norm2"] = g(s + "norm1.weight").contiguous(), g(s + "norm2.weight").contiguous()
         R[d + "qkv.hp"], R[d + "qkv.b"] = _dbl(g(s + "attn.qkv.weight")), g(s + "attn.qkv.bias").contiguous()
         R[d + "proj.hp"], R[d + "proj.b"] = _dbl(g(s + "attn.proj.weight")), g(s + "attn.proj.bias").contiguous()
-        R[d + "gu.hp"] = _dbl(torch.cat([_pad_rows(g(s + "mlp.gate_proj.weight"), vi_pad), _pad_rows(g(s + "mlp.up_proj.weight"), vi_pad)], 0))
-        R[d + "gu.b"] = torch.cat([_pad_rows(g(s + "mlp.gate_proj.bias"), vi_pad), _pad_rows(g(s + "mlp.up_proj.bias"), vi_pad)], 0).contiguous()
+        R[d + "gu.hp"] = _dbl(interleave16(_pad_rows(g(s + "mlp.gate_proj.weight"), vi_pad), _pad_rows(g(s + "mlp.up_proj.weight"), vi_pad)))
+        R[d + "gu.b"] = interleave16(_pad_rows(g(s + "mlp.gate_proj.bias"), vi_pad), _pad_rows(g(s + "mlp.up_proj.bias"), vi_pad)).contiguous()
         R[d + "down.hp"], R[d + "down.b"] = _dbl(_pad_cols(g(s + "mlp.down_proj.weight"), vi_pad)), g(s + "mlp.down_proj.bias").contiguous()
     R["vit.ln_q"] = g("visual.merger.ln_q.weight").contiguous()
     mu, vh = cfg.merge_unit, v.hidden_size
@@ -73,7 +77,7 @@ def prepare_reference_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, devi
         R[d + "qkv.hp"] = _dbl(torch.cat([g(s + "self_attn.q_proj.weight"), g(s + "self_attn.k_proj.weight"), g(s + "self_attn.v_proj.weight")], 0))
         R[d + "qkv.b"] = torch.cat([g(s + "self_attn.q_proj.bias"), g(s + "self_attn.k_proj.bias"), g(s + "self_attn.v_proj.bias")], 0).contiguous()
         R[d + "o.hp"] = _dbl(g(s + "self_attn.o_proj.weight"))
-        R[d + "gu.hp"] = _dbl(torch.cat([_pad_rows(g(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(g(s + "mlp.up_proj.weight"), li_pad)], 0))
+        R[d + "gu.hp"] = _dbl(interleave16(_pad_rows(g(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(g(s + "mlp.up_proj.weight"), li_pad)))
         R[d + "down.hp"] = _dbl(_pad_cols(g(s + "mlp.down_proj.weight"), li_pad))
     R["llm.norm"] = g("model.norm.weight").contiguous()
     R["llm.embed32"] = sd["model.embed_tokens.weight"].to(device=dev, dtype=F32).contiguous()
@@ -118,8 +122,7 @@ class ReferencePath:
             a = ops.attn_f32(qkv[:, :vh], qkv[:, vh:2 * vh], qkv[:, 2 * vh:3 * vh], cu, cu, mx, mx, H, hd, mfma=hd in (80, 128))
             ops.gemm_hp(a, R[d + "proj.hp"], R[d + "proj.b"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
             n, _ = ops.norm_split(x32, R[d + "norm2"], eps=1e-6)
-            gu = ops.gemm_hp(n, R[d + "gu.hp"], R[d + "gu.b"])
-            h = ops.swiglu_split(gu, R["vi_pad"])
+            h = ops.gemm_hp(n, R[d + "gu.hp"], R[d + "gu.b"], epilogue=ops.EPI_SWIGLU, out_mode=S)      # silu(gate) * up as (hi, lo) rows
             ops.gemm_hp(h, R[d + "down.hp"], R[d + "down.b"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
         if nf is not None:
             ops.check_finite(x32, nf)
@@ -188,8 +191,7 @@ class ReferencePath:
         a = attention(qkv)                                                     # fp32 rotary + fp32 attention → (hi, lo) rows
         ops.gemm_hp(a, R[d + "o.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
         n, _ = ops.norm_split(x32, R[d + "post_norm"], eps=cfg.rms_norm_eps)
-        gu = ops.gemm_hp(n, R[d + "gu.hp"])
-        h = ops.swiglu_split(gu, R["li_pad"])
+        h = ops.gemm_hp(n, R[d + "gu.hp"], epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)             # silu(gate) * up as (hi, lo) rows
         ops.gemm_hp(h, R[d + "down.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
 
     def prefill(self, plan, low32, sess, nf=None):
