@@ -309,6 +309,10 @@ int  padt_greedy_step(void* stream, const void* part_val, const void* part_idx, 
  * (value, index) pair per row in padt_greedy_step's partial layout (nblk = 1). */
 int  padt_sample_token(void* stream, const void* logits_f32, long ld_logits, long n_rows_table, const void* gen_cfg, const int* step,
                        void* part_val, void* part_idx, long batch);
+/* Arg-max of fp32 score rows → one (value, index) pair per row in padt_greedy_step's partial layout (nblk = 1), ties → lowest index
+ * (torch.argmax, padt.py:745): the selection of the HOOKED decode loop, where caller-supplied logits processors (padt.py:717) have rewritten
+ * the rows padt_vrt_head wrote. */
+int  padt_argmax_rows_f32(void* stream, const void* scores_f32, long ld, long n_cols, void* part_val, void* part_idx, long batch);
 /* The synchronising half of generate() (padt.py:745-757 stop rule, :203 table assert, the range guard's flags) in ONE launch + one small
  * D2H copy: out[0] = *err, out[1] = any(unfinished[0..n_rows)), out[2..] = nf_rows[n_rows], nf_batch[n_batch], first_eos[n_rows] — the first
  * step t < done at which a row's token is an EOS id (eos or gen_cfg's list), -1 if none.  out holds 2 + 2 n_rows + n_batch int32. */
@@ -341,7 +345,7 @@ int padt_mask_upsample_binarize(void* stream, const void* masks_f32, long ld_obj
  * (scratch AND result, capacity cap_counts >= h*w + 1 in the worst case; n_counts < 0 when exceeded) and the counts string str[o][0 .. str_len[o])
  * (capacity cap_str; str_len = -1 when exceeded).  With packed_u8 != null the strings are also written back to back into packed_u8 behind
  * offsets[0 .. n_obj] (offsets[n_obj] = total bytes, -1 on a capacity error), so that one small device-to-host copy carries a batch's RLEs
- * instead of its masks.  max_h <= 7680. */
+ * instead of its masks.  max_h <= 7680; an object with dst_h > max_h or dst_w > ld_row is reported like a capacity error (n_counts = str_len = -1). */
 int padt_mask_rle(void* stream, const void* mask_u8, long ld_obj, long ld_row, const int* dst_h, const int* dst_w, int n_obj, int max_h,
                   int* counts, long cap_counts, void* str_u8, long cap_str, int* n_counts, int* str_len, void* packed_u8, long cap_packed,
                   int* offsets);

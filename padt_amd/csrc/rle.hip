@@ -10,8 +10,7 @@
 //   2. rleToString: count j (from the fourth on: minus count j - 2) as little-endian 5-bit groups, bit 5 = "more follows", + 48; the byte
 //      offset of a count is a prefix sum of its group number.
 // Integer work: results are byte-identical to the host statement (tests/test_kernels_gpu.py, tests/golden/postprocess.npz).
-#include <hip/hip_runtime.h>
-#include <stdint.h>
+#include "common.h"
 
 extern "C" void padt_set_error(const char* msg);
 
@@ -25,6 +24,7 @@ struct RleArgs {
     unsigned char* str; long cap_str;
     int* n_counts; int* str_len;
     int sw;                        // strip width (columns staged per pass); LDS pitch = sw + 4
+    int max_h; long max_w;         // the LDS strip holds max_h rows, a mask row ld_row bytes: an object beyond either is reported, not clamped
 };
 
 __device__ __forceinline__ int wave_incl_sum(int v, int lane) {
@@ -88,6 +88,10 @@ __global__ __launch_bounds__(NT) void mask_rle_kernel(RleArgs p) {
     unsigned char* str = p.str + (long)o * p.cap_str;
     if (n <= 0) {                                                 // rleEncode of an empty mask: no counts, empty string
         if (tid == 0) { p.n_counts[o] = 0; p.str_len[o] = 0; }
+        return;
+    }
+    if (h > p.max_h || w > p.max_w) {                             // taller than the LDS strip / wider than a mask row: failed object, never an overrun
+        if (tid == 0) { p.n_counts[o] = -1; p.str_len[o] = -1; }
         return;
     }
     const unsigned char* img = p.mask + (long)o * p.ld_obj;
@@ -188,7 +192,6 @@ __global__ __launch_bounds__(NT) void mask_rle_kernel(RleArgs p) {
 // strings of all objects back to back behind an offset table: ONE device-to-host copy of offsets[n_obj] bytes after the table was read
 __global__ __launch_bounds__(NT) void rle_pack_kernel(const unsigned char* __restrict__ str, long cap_str, const int* __restrict__ str_len, int n_obj,
                                                       unsigned char* __restrict__ packed, long cap_packed, int* __restrict__ offsets) {
-    __shared__ long s_off;
     long off = 0;
     bool bad = false;
     for (int o = 0; o < n_obj; ++o) {
@@ -198,11 +201,7 @@ __global__ __launch_bounds__(NT) void rle_pack_kernel(const unsigned char* __res
         if (threadIdx.x == 0) offsets[o] = (int)off;
         off += len;
     }
-    if (threadIdx.x == 0) {
-        s_off = off;
-        offsets[n_obj] = bad ? -1 : (int)off;
-    }
-    (void)s_off;
+    if (threadIdx.x == 0) offsets[n_obj] = bad ? -1 : (int)off;
 }
 }  // namespace
 
@@ -225,14 +224,9 @@ extern "C" int padt_mask_rle(void* stream, const void* mask_u8, long ld_obj, lon
         padt_set_error("padt_mask_rle: max_h <= 7680, counts / string buffers with their capacities and (with packed) the offset table required");
         return -1;
     }
-    static bool attr_set[64] = {false};
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    if (!attr_set[dev & 63]) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 61 * 1024);
-        attr_set[dev & 63] = true;
-    }
-    RleArgs a{(const unsigned char*)mask_u8, ld_obj, ld_row, dst_h, dst_w, counts, cap_counts, (unsigned char*)str_u8, cap_str, n_counts, str_len, sw};
+    static PerDeviceOnce once;                                    // per device, safe against two threads making the first call (common.h)
+    once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&mask_rle_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 61 * 1024); });
+    RleArgs a{(const unsigned char*)mask_u8, ld_obj, ld_row, dst_h, dst_w, counts, cap_counts, (unsigned char*)str_u8, cap_str, n_counts, str_len, sw, max_h, ld_row};
     hipLaunchKernelGGL(mask_rle_kernel, dim3(n_obj), dim3(NT), (size_t)lds, (hipStream_t)stream, a);
     if (packed_u8 != nullptr)
         hipLaunchKernelGGL(rle_pack_kernel, dim3(1), dim3(NT), 0, (hipStream_t)stream, (const unsigned char*)str_u8, cap_str, str_len, n_obj,

@@ -467,6 +467,49 @@ extern "C" int padt_sample_token(void* stream, const void* logits_f32, long ld_l
     return 0;
 }
 
+// Arg-max of fp32 score rows (round 6: the selection of the HOOKED decode loop — caller-supplied `logits_processor`s of padt.py:717 have rewritten
+// the step's score rows between the head kernel and the selection, so the head's fused arg-max partials no longer describe them): one block per
+// row, ties → lowest index (torch.argmax, padt.py:745), one (value, index) partial per row in the layout padt_greedy_step reads with nblk = 1.
+__global__ __launch_bounds__(1024) void argmax_rows_f32_kernel(const float* __restrict__ x, long ld, int n, float* __restrict__ out_val, int* __restrict__ out_idx) {
+    __shared__ float red_v[1024];
+    __shared__ int red_i[1024];
+    const int b = blockIdx.x, tid = threadIdx.x;
+    const float* row = x + (long)b * ld;
+    float best = -INFINITY;
+    int bidx = 0x7fffffff;
+    for (int i = tid; i < n; i += 1024) {
+        const float v = row[i];
+        if (v > best || (v == best && i < bidx) || (v != v && best == best)) { best = v; bidx = i; }    // a NaN wins once (torch.argmax: NaN is the maximum)
+    }
+    red_v[tid] = best;
+    red_i[tid] = bidx;
+    __syncthreads();
+    for (int s2 = 512; s2 > 0; s2 >>= 1) {
+        if (tid < s2) {
+            const float ov = red_v[tid + s2], cv = red_v[tid];
+            const int oi = red_i[tid + s2], ci = red_i[tid];
+            const bool o_nan = ov != ov, c_nan = cv != cv;
+            const bool take = (o_nan && !c_nan) || (o_nan == c_nan && (ov > cv || ((ov == cv || o_nan) && oi < ci)));
+            if (take) { red_v[tid] = ov; red_i[tid] = oi; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) { out_val[b] = red_v[0]; out_idx[b] = red_i[0] == 0x7fffffff ? 0 : red_i[0]; }
+}
+
+extern "C" int padt_argmax_rows_f32(void* stream, const void* scores_f32, long ld, long n_cols, void* part_val, void* part_idx, long batch) {
+    if (batch <= 0) return 0;
+    if (scores_f32 == nullptr || n_cols <= 0 || n_cols > 0x7fffffffL || part_val == nullptr || part_idx == nullptr) {
+        padt_set_error("padt_argmax_rows_f32: score rows, a column count and the partial buffers are required");
+        return -1;
+    }
+    hipLaunchKernelGGL(argmax_rows_f32_kernel, dim3((unsigned)batch), dim3(1024), 0, (hipStream_t)stream, (const float*)scores_f32, ld, (int)n_cols,
+                       (float*)part_val, (int*)part_idx);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
+    return 0;
+}
+
 // ---------------------------------------------------------------------------------------------------------------------
 // What generate()'s synchronising half needs from the device, in ONE launch and ONE small D2H copy (round 6: replaces a torch.cat of flag
 // tensors, `unfinished.any()` per chunk and isin / argmax / max over the token ring — seven ATen reduce launches and three host syncs per

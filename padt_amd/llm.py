@@ -119,6 +119,21 @@ def plan_prompt(cfg: PaDTConfig, input_ids: torch.Tensor, attention_mask: Option
 MODE = {"f": 0, None: 0, "t": 1, "v": 2, "e": 3}
 
 
+def _call_hooks(hooks, input_ids, scores, chain: bool):
+    """HF's LogitsProcessorList / StoppingCriteriaList are callables over (input_ids, scores); a plain list / tuple of callables is walked here:
+    processors chain (each sees its predecessor's scores), criteria are OR-ed."""
+    if callable(hooks):
+        return hooks(input_ids, scores)
+    out = scores if chain else None
+    for h in hooks:
+        if chain:
+            out = h(input_ids, out)
+        else:
+            r = h(input_ids, scores)
+            out = r if out is None else (out | r)
+    return out
+
+
 class DecodeSession:
     """Persistent device state for one (batch, S_max, max prototypes, T_max) shape: KV caches, per-step state, the
     prototype table and the captured decode-step hipGraph.  Pointers are stable across generate() calls so the graph
@@ -192,6 +207,7 @@ class DecodeSession:
         self.logits = None               # fp32 [B][V + np_max] rows for the sampling kernel, allocated on first use
         self.np_cur = np_max
         self.step_fn = None              # precision="reference": the eager split-precision decode step (reference.ReferencePath.step) instead of step_kernels
+        self.hooks = None                # caller-supplied logits_processor / stopping_criteria of this generate (modeling.generate): the HOOKED, eager loop
         self.hid32 = None                # ... and its fp32 per-step hidden rows [t_max][B][D]
 
     # one decode step, all on the current stream (eager or under capture)
@@ -272,6 +288,14 @@ class DecodeSession:
         else:
             ops.vrt_head(hn, W["llm.head"], self.proto, self.vrt_off, self.part_val, self.part_idx, cfg.eos_token_id,
                          mode_table=self.mode_table, step=self.step, gen_cfg=self.gen_cfg, seen=self.seen, logits=lg)
+        hk = self.hooks
+        if hk is not None and hk["processors"]:
+            # padt.py:717 `next_token_scores = logits_processor(input_ids, next_token_logits)` with the CALLER's processors: they see the rows the head
+            # wrote (logit mask + the built-in processors applied) and the sequences so far, and what they return is what is scored / selected / kept
+            view = lg[: hk["B"], : hk["table_rows"]]
+            new = _call_hooks(hk["processors"], hk["sequences"](), view, chain=True)
+            if new is not view:
+                view.copy_(new.to(torch.float32))
         if self.keep_scores:                                 # padt.py:719-720: scores += (next_token_scores,) — filed under the device step counter
             if self.scores is None:
                 self.scores = torch.zeros((self.t_max,) + tuple(self.logits.shape), device=hn.device, dtype=torch.float32)
@@ -280,9 +304,22 @@ class DecodeSession:
         if self.do_sample:                                   # padt.py:740-743: multinomial over softmax of the warped scores
             ops.sample_token(lg, cfg.vocab_size + self.np_max, self.gen_cfg, self.step, self.part_val, self.part_idx, self.B)
             nblk = 1
+        elif hk is not None and hk["processors"]:            # the head's fused arg-max partials describe the rows BEFORE the caller's processors
+            ops.argmax_rows(lg, cfg.vocab_size + self.np_max, self.part_val, self.part_idx, self.B)
+            nblk = 1
         ops.greedy_step(self.part_val, self.part_idx, nblk, hn, self.hidden_buf, self.unfinished, self.tokens,
                         self.cur_tok, self.step, self.slot, self.lens, self.pos3, cfg.eos_token_id, cfg.pad_token_id,
                         advance=advance, gen_cfg=self.gen_cfg, seen=self.seen)
+        if hk is not None:
+            hk["t"] += 1
+            if hk["criteria"]:
+                # padt.py:752 `unfinished_sequences = unfinished_sequences & ~stopping_criteria(input_ids, scores)` for the caller's criteria (EOS and
+                # the length limit are the loop's own: padt_greedy_step / max_new_tokens)
+                kept = tuple(self.scores[i, : hk["B"], : hk["table_rows"]] for i in range(hk["t"])) if hk["pass_scores"] else None
+                stop = _call_hooks(hk["criteria"], hk["sequences"](), kept, chain=False)
+                if not isinstance(stop, torch.Tensor):       # criteria of the old API answer one bool for the whole batch
+                    stop = torch.full((hk["B"],), bool(stop), device=hn.device)
+                self.unfinished[: hk["B"]].mul_((~stop.to(device=hn.device, dtype=torch.bool)).to(self.unfinished.dtype))
 
     def run_steps(self, n: int, use_graph: bool = True):
         if n <= 0:

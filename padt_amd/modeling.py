@@ -99,7 +99,7 @@ _GENERATE_IGNORED = {
     "eta_cutoff": (0.0, None), "encoder_repetition_penalty": (1.0, None), "guidance_scale": (None, 1.0), "renormalize_logits": (False, None),
 }
 # arguments the reference honours (padt.py:418-424,445,511-533,570-580,719-737) and this path does not implement
-_GENERATE_REJECTED = ("inputs", "logits_processor", "stopping_criteria", "prefix_allowed_tokens_fn", "assistant_model", "streamer",
+_GENERATE_REJECTED = ("inputs", "prefix_allowed_tokens_fn", "assistant_model", "streamer",
                       "negative_prompt_ids", "negative_prompt_attention_mask", "pixel_values_videos", "video_grid_thw", "second_per_grid_ts",
                       "inputs_embeds", "past_key_values", "position_ids", "cache_position", "rope_deltas", "stop_strings", "max_time",
                       "sequence_bias", "suppress_tokens", "begin_suppress_tokens", "forced_bos_token_id", "forced_eos_token_id",
@@ -112,8 +112,8 @@ def check_generate_kwargs(kwargs: dict, max_new_tokens, max_length, prompt_len) 
     for k in list(kwargs):
         v = kwargs[k]
         if k in _GENERATE_REJECTED:
-            if v is None or (k in ("logits_processor", "stopping_criteria") and hasattr(v, "__len__") and len(v) == 0):
-                continue                                              # the reference's own defaults (None / empty lists)
+            if v is None:
+                continue                                              # the reference's own default
             raise NotImplementedError(f"generate({k}=...) is not implemented on the MI355X path (the reference honours it, padt.py:414-580): "
                                       "remove the argument or run the reference for this call")
         if k in _GENERATE_IGNORED:
@@ -269,12 +269,19 @@ class PaDTForConditionalGeneration:
                  use_graph: bool = True, lane: int = 0, repetition_penalty: Optional[float] = None, eos_token_id=None,
                  temperature: Optional[float] = None, top_k: Optional[int] = None, top_p: Optional[float] = None,
                  seed: Optional[int] = None, max_length: Optional[int] = None, output_scores: bool = False, output_logits: bool = False,
-                 pad_token_id: Optional[int] = None, **kwargs):
+                 pad_token_id: Optional[int] = None, logits_processor=None, stopping_criteria=None, **kwargs):
         """Greedy generation over the unified text‖VRT vocabulary.
 
+        ``logits_processor`` / ``stopping_criteria`` (padt.py:422-423,570-580,717,752; round 6): HF ``LogitsProcessorList`` / ``StoppingCriteriaList``
+        objects or plain lists of callables ``f(input_ids, scores)``.  They run where the reference runs them — the processors on the step's fp32
+        score rows AFTER the logit mask and the built-in processors (repetition penalty), before the arg-max / the sampler; the criteria on the
+        sequences including the step's token, OR-ed into the stop state next to EOS and the length limit — on the HOOKED loop: decode steps launched
+        kernel by kernel (no captured graph: the callables are host code), one host sync per step, ``.scores`` = the processed rows.  Not available
+        inside ``pipeline.PipelinedRunner``'s merged decode groups.
+
         Arguments of the reference's ``generate`` (padt.py:414-434 + the HF generation kwargs it forwards) that this path does not
-        implement are REJECTED by name (``NotImplementedError``: ``stopping_criteria``, ``logits_processor``, ``streamer``, ``min_length``,
-        ``num_beams`` > 1, video inputs, ``inputs_embeds``, ``output_scores`` / ``output_logits`` …), arguments that cannot change the
+        implement are REJECTED by name (``NotImplementedError``: ``streamer``, ``prefix_allowed_tokens_fn``, ``min_length``,
+        ``num_beams`` > 1, video inputs, ``inputs_embeds`` …), arguments that cannot change the
         result here are accepted and ignored (``use_cache``, ``attn_implementation``, ``synced_gpus=False`` …), anything else raises the
         ``ValueError`` HF's ``_validate_model_kwargs`` raises (padt.py:440) — a caller never gets silently different behaviour.
         ``max_length`` (padt.py:511-520): total length incl. the (padded) prompt; ``max_new_tokens`` wins when both are given, as in HF.
@@ -303,15 +310,21 @@ class PaDTForConditionalGeneration:
         if pad_token_id is not None and int(pad_token_id) != int(self.generation_config.pad_token_id):
             raise NotImplementedError(f"generate(pad_token_id={pad_token_id}): finished rows are padded with the checkpoint's pad token "
                                       f"({self.generation_config.pad_token_id}) on this path")
+        processors = logits_processor if logits_processor is not None and len(logits_processor) > 0 else None
+        criteria = stopping_criteria if stopping_criteria is not None and len(stopping_criteria) > 0 else None
+        hooks = None
+        if processors is not None or criteria is not None:
+            hooks = dict(processors=processors, criteria=criteria, pass_scores=bool(output_scores))
+            use_graph, sync_every = False, 1                          # host callables between the kernels of every step
         if output_logits:
             pen = self.generation_config.repetition_penalty if repetition_penalty is None else repetition_penalty
-            if float(pen) != 1.0 or schedule is not None:
-                raise NotImplementedError("generate(output_logits=True) with a logits processor active (repetition_penalty != 1 or a schedule): only the "
-                                          "processed rows are kept on this path — ask for output_scores=True")
+            if float(pen) != 1.0 or schedule is not None or processors is not None:
+                raise NotImplementedError("generate(output_logits=True) with a logits processor active (repetition_penalty != 1, a schedule or a "
+                                          "logits_processor): only the processed rows are kept on this path — ask for output_scores=True")
         ctx = self.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample,
                                    schedule, sync_every, use_graph, lane, repetition_penalty=repetition_penalty,
                                    eos_token_id=eos_token_id, temperature=temperature, top_k=top_k, top_p=top_p, seed=seed,
-                                   keep_scores=bool(output_scores or output_logits))
+                                   keep_scores=bool(output_scores or output_logits or hooks is not None), hooks=hooks)
         return self.generate_collect(ctx, output_hidden_states, return_dict_in_generate, output_scores=bool(output_scores),
                                      output_logits=bool(output_logits))
 
@@ -319,7 +332,7 @@ class PaDTForConditionalGeneration:
     def generate_launch(self, input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens=1024, do_sample=None,
                         schedule=None, sync_every=16, use_graph=True, lane=0, decode_stream=None, group=None, n_slots=1,
                         repetition_penalty=None, eos_token_id=None, temperature=None, top_k=None, top_p=None, seed=None,
-                        vit_stream=None, inputs_ready=None, keep_scores=False):
+                        vit_stream=None, inputs_ready=None, keep_scores=False, hooks=None):
         """Asynchronous half of generate(): host integer prep + every kernel up to the first host sync point, enqueued on
         the current stream (the decode steps on ``decode_stream`` if given, ordered after the prefill by an event).
         Returns a group context for generate_collect().
@@ -336,7 +349,7 @@ class PaDTForConditionalGeneration:
         if owner is not self:
             return owner.generate_launch(input_ids, attention_mask, pixel_values, image_grid_thw, max_new_tokens, do_sample, schedule, sync_every,
                                          use_graph, lane, decode_stream, group, n_slots, repetition_penalty, eos_token_id, temperature, top_k, top_p,
-                                         seed, vit_stream, inputs_ready, keep_scores)
+                                         seed, vit_stream, inputs_ready, keep_scores, hooks)
         self._batches_seen += 1
         gc = self.generation_config
         do_sample = gc.do_sample if do_sample is None else do_sample
@@ -371,6 +384,8 @@ class PaDTForConditionalGeneration:
         plan = plan_prompt(cfg, input_ids, attention_mask, grid, dev, row0=row0, proto_row0=proto_row0)
         n_proto = plan.vrt_off[-1]
         need_s = max(plan.lens) + T_max
+        if hooks is not None and (group is not None or n_slots != 1):
+            raise NotImplementedError("logits_processor / stopping_criteria run on generate()'s own (un-merged) decode loop, not inside a merged decode group")
         if group is None:
             sess = self.lm.session(B * n_slots, need_s, n_proto * n_slots, T_max, lane=lane)
             group = dict(sess=sess, subs=[], proto_rows=0, B=B, n_slots=n_slots, T_max=T_max, sync_every=sync_every,
@@ -381,6 +396,14 @@ class PaDTForConditionalGeneration:
                                                   top_p=samp[2] if samp else 1.0).to(dev, non_blocking=True))
             sess.do_sample = samp is not None
             sess.keep_scores = bool(keep_scores)
+            sess.hooks = None
+            if hooks is not None:
+                ids_dev = input_ids.detach().to(dev).long().contiguous()
+                hk = dict(hooks, B=B, table_rows=cfg.vocab_size + n_proto, t=0)
+                # `input_ids` as the reference's loop holds them (padt.py:751): the prompt and the tokens selected so far
+                hk["sequences"] = lambda hk=hk, s=sess: ops.assemble_sequences(ids_dev, s.tokens[:B], hk["t"], cfg.vocab_size, 0)
+                sess.hooks = hk
+                group["hooks"] = hooks
             if gen_key[0] != 1.0:
                 sess.seen.zero_()
             # neutral state for every row; the batches overwrite their own rows (unused rows stay finished / empty)
@@ -489,6 +512,8 @@ class PaDTForConditionalGeneration:
         group["launched"] = True
         sess, T_max = group["sess"], group["T_max"]
         n = min(group["sync_every"], T_max - 1)
+        if sess.hooks is not None:
+            n = 0                                                    # hooked loop: the stop state is read after EVERY token, the first included (padt.py:752-757)
 
         def go():
             sess.head_and_select(sess.hn_first, advance=False)
@@ -592,10 +617,13 @@ class PaDTForConditionalGeneration:
         kw = dict(do_sample=False)
         if samp is not None:
             kw = dict(do_sample=True, temperature=samp[0], top_k=samp[1], top_p=samp[2], seed=samp[3])
+        if group.get("hooks") is not None:
+            kw.update(logits_processor=group["hooks"]["processors"], stopping_criteria=group["hooks"]["criteria"])
         return fb.generate(input_ids=sub["input_ids"], attention_mask=am, pixel_values=pix, image_grid_thw=grid, max_new_tokens=group["T_max"],
                            schedule=group["schedule"], sync_every=group["sync_every"], use_graph=group["use_graph"], lane=("fb", group["lane"]),
                            repetition_penalty=pen, eos_token_id=list(eos), output_hidden_states=output_hidden_states,
-                           return_dict_in_generate=return_dict_in_generate, output_scores=bool(group["gen_key"][3]), **kw)
+                           return_dict_in_generate=return_dict_in_generate,
+                           output_scores=bool(group["gen_key"][3]) and (group.get("hooks") is None or group["hooks"]["pass_scores"]), **kw)
 
     # ------------------------------------------------------------------ vl_decode (padt.py:342-412)
     @torch.no_grad()

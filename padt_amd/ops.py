@@ -628,6 +628,13 @@ def sample_token(logits, n_rows_table, gen_cfg, step, part_val, part_idx, batch)
                                              _p(part_idx), int(batch)), "padt_sample_token")
 
 
+def argmax_rows(scores, n_cols, part_val, part_idx, batch):
+    """Arg-max per fp32 score row (ties → lowest index) into the (value, index) partial layout (padt_argmax_rows_f32): the hooked decode loop."""
+    assert scores.dtype == torch.float32 and scores.stride(-1) == 1
+    _lib.check(_lib.load().padt_argmax_rows_f32(_stream(), _p(scores), scores.stride(0), int(n_cols), _p(part_val), _p(part_idx), int(batch)),
+               "padt_argmax_rows_f32")
+
+
 def greedy_step(part_val, part_idx, nblk, hidden, hidden_buf, unfinished, tokens_out, cur_tok, step, slot, lens, pos3,
                 eos, pad, advance=True, gen_cfg=None, seen=None):
     lib = _lib.load()
@@ -689,33 +696,57 @@ def mask_upsample_binarize(masks, src_h, src_w, dst_h, dst_w, max_h, max_w, want
     return (out, up) if want_logits else out
 
 
-def mask_rle_launch(bin_masks, dst_h, dst_w):
+def _rle_caps(mh, mw, worst_case):
+    """(runs, string bytes) capacity per object.  The worst case — every pixel its own run — is 4 + 2 bytes of scratch per PIXEL per object (an OVD batch
+    of 56 objects at 640 x 640: 140 MB per call); a segmentation mask has a handful of runs per COLUMN, so the default bound is 128 runs per column
+    (+ the zero-length first run; the noise-like masks random-init weights produce have ~80), 5 bytes per run (counts below 2^24).  A mask beyond it is reported (n_counts < 0) and the caller falls back to the
+    host statement for that batch."""
+    if worst_case:
+        return mh * mw + 2, 2 * mh * mw + 16
+    runs = min(mh * mw + 2, 128 * mw + 2)
+    return runs, 5 * runs + 16
+
+
+_RLE_SCRATCH = {}                                                     # (device, n, cap_c, cap_s) → buffers, reused by the next call of that shape on the stream
+
+
+def mask_rle_launch(bin_masks, dst_h, dst_w, worst_case=False):
     """Enqueue padt_mask_rle for (n_obj, max_h, max_w) uint8 masks on the current stream; → handle for mask_rle_fetch (no host sync here, so a
-    caller can put its other device work and copies behind the same single wait)."""
+    caller can put its other device work and copies behind the same single wait).  Scratch: bounded capacities (_rle_caps), one cached set per shape
+    (a handle is valid until the next launch of the same shape: fetch first — postprocess does)."""
     lib = _lib.load()
     assert bin_masks.dtype == torch.uint8 and bin_masks.is_cuda and bin_masks.dim() == 3 and bin_masks.stride(2) == 1
     n, mh, mw = bin_masks.shape
     if n == 0:
         return None
     dev = bin_masks.device
-    cap_c = mh * mw + 2                                              # worst case: every pixel its own run (+ the zero-length first run)
-    cap_s = 2 * mh * mw + 16                                         # one byte per count + 4 more for each of the <= n / 16 counts of 16 and up
-    h = dict(n=n, counts=torch.empty((n, cap_c), dtype=torch.int32, device=dev), strs=torch.empty((n, cap_s), dtype=torch.uint8, device=dev),
-             n_counts=torch.empty(n, dtype=torch.int32, device=dev), str_len=torch.empty(n, dtype=torch.int32, device=dev),
-             packed=torch.empty(n * cap_s, dtype=torch.uint8, device=dev), offsets=torch.empty(n + 1, dtype=torch.int32, device=dev), masks=bin_masks)
+    cap_c, cap_s = _rle_caps(mh, mw, worst_case)
+    key = (dev, n, cap_c, cap_s)
+    buf = _RLE_SCRATCH.get(key)
+    if buf is None:
+        if len(_RLE_SCRATCH) >= 8:
+            _RLE_SCRATCH.clear()
+        buf = dict(counts=torch.empty((n, cap_c), dtype=torch.int32, device=dev), strs=torch.empty((n, cap_s), dtype=torch.uint8, device=dev),
+                   n_counts=torch.empty(n, dtype=torch.int32, device=dev), str_len=torch.empty(n, dtype=torch.int32, device=dev),
+                   packed=torch.empty(n * cap_s, dtype=torch.uint8, device=dev), offsets=torch.empty(n + 1, dtype=torch.int32, device=dev))
+        _RLE_SCRATCH[key] = buf
+    h = dict(buf, n=n, masks=bin_masks, worst_case=worst_case)
     _lib.check(lib.padt_mask_rle(_stream(), _p(bin_masks), bin_masks.stride(0), bin_masks.stride(1), _p(dst_h), _p(dst_w), n, mh, _p(h["counts"]), cap_c,
                                  _p(h["strs"]), cap_s, _p(h["n_counts"]), _p(h["str_len"]), _p(h["packed"]), h["packed"].numel(), _p(h["offsets"])),
                "padt_mask_rle")
     return h
 
 
-def mask_rle_fetch(h, want_counts=False):
-    """→ list of n_obj ASCII COCO `counts` strings [, list of count lists]: the offset table, then exactly the string bytes."""
+def mask_rle_fetch(h, want_counts=False, on_overflow="raise"):
+    """→ list of n_obj ASCII COCO `counts` strings [, list of count lists]: the offset table, then exactly the string bytes.  A mask beyond the
+    bounded scratch (or beyond max_h / ld_row): PaDTHipError, or None with on_overflow="none" (the caller computes the batch on the host)."""
     if h is None:
         return ([], []) if want_counts else []
     n = h["n"]
     off = h["offsets"].cpu().tolist()
     if off[-1] < 0:
+        if on_overflow == "none":
+            return None
         raise _lib.PaDTHipError("padt_mask_rle: capacity exceeded (n_counts %s)" % h["n_counts"].cpu().tolist())
     raw = h["packed"][: off[-1]].cpu().numpy().tobytes()
     out = [raw[off[i]: off[i + 1]].decode("ascii") for i in range(n)]
@@ -730,7 +761,10 @@ def mask_rle(bin_masks, dst_h, dst_w, want_counts=False):
     """COCO RLE `counts` strings of binarised masks, computed on the device (padt_mask_rle): bin_masks (n_obj, max_h, max_w) uint8 as
     mask_upsample_binarize returns them, dst_h / dst_w int32 device tensors (n_obj,).  → list of n_obj ASCII strings [, list of count lists].
     Two small device-to-host copies (the offset table, then exactly the string bytes) instead of the masks themselves."""
-    return mask_rle_fetch(mask_rle_launch(bin_masks, dst_h, dst_w), want_counts)
+    r = mask_rle_fetch(mask_rle_launch(bin_masks, dst_h, dst_w), want_counts, on_overflow="none")
+    if r is None:                                                     # noise-like masks beyond the bounded scratch: once more with the worst-case capacities
+        r = mask_rle_fetch(mask_rle_launch(bin_masks, dst_h, dst_w, worst_case=True), want_counts)
+    return r
 
 
 def patchify_normalize(img_u8, lut, out, patch=14, merge=2, temporal=2):

@@ -120,7 +120,7 @@ def postprocess_results(decoded: Dict, labels: List[List[str]], image_sizes: Seq
     res = [{"sample_idx": int(s), "score": scores[i].item(), "category": flat_labels[i],
             "bbox": box_to_pixels(boxes[i].tolist(), sizes[i][0], sizes[i][1])} for i, s in enumerate(sidx)]
     if masks is not None:
-        strs = ops.mask_rle_fetch(rle_h) if rle_h is not None else None
+        strs = ops.mask_rle_fetch(rle_h, on_overflow="none") if rle_h is not None else None     # None: beyond the bounded device scratch → host statement below
         binm = bin_dev.cpu().numpy() if (want_mask or (rle and strs is None)) else None
         for i, r in enumerate(res):
             if binm is not None:

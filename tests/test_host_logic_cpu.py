@@ -286,7 +286,7 @@ def test_processor_and_parser_on_a_real_bpe_tokenizer(golden_dir):
 
 
 # ------------------------------------------------------------------------------------------------ generate() argument policy
-_REJECTED_WITH_VALUES = [("stopping_criteria", [object()]), ("logits_processor", [object()]), ("streamer", object()), ("min_length", 5),
+_REJECTED_WITH_VALUES = [("streamer", object()), ("min_length", 5),
                          ("min_new_tokens", 3), ("num_beams", 4), ("pixel_values_videos", torch.zeros(1)), ("video_grid_thw", torch.zeros(1, 3)),
                          ("inputs_embeds", torch.zeros(1, 2, 4)), ("prefix_allowed_tokens_fn", lambda *a: [0]), ("assistant_model", object()),
                          ("negative_prompt_ids", torch.zeros(1, 2)), ("output_attentions", True),
@@ -303,10 +303,34 @@ def test_generate_rejects_arguments_it_does_not_implement(name, value):
         m.generate(input_ids=torch.zeros((1, 4), dtype=torch.long), max_new_tokens=4, **{name: value})
 
 
+def test_hook_lists_chain_processors_and_or_criteria():
+    """padt.py:717,752: `logits_processor(input_ids, scores)` chains, `stopping_criteria(input_ids, scores)` ORs — for HF's list objects (callables
+    themselves) and for plain lists of callables alike (llm._call_hooks, the host side of the hooked decode loop)."""
+    from transformers import LogitsProcessorList, StoppingCriteriaList, MaxLengthCriteria
+    from transformers.generation.logits_process import LogitsProcessor
+    from padt_amd.llm import _call_hooks
+
+    class Add(LogitsProcessor):
+        def __init__(self, v):
+            self.v = v
+
+        def __call__(self, input_ids, scores):
+            return scores + self.v * input_ids.shape[1]
+    ids = torch.zeros((2, 3), dtype=torch.long)
+    sc = torch.zeros((2, 5))
+    want = sc + 3 * 3
+    assert torch.equal(_call_hooks([Add(1), Add(2)], ids, sc, chain=True), want)
+    assert torch.equal(_call_hooks(LogitsProcessorList([Add(1), Add(2)]), ids, sc, chain=True), want)
+    crit = [lambda i, s: torch.tensor([True, False]), lambda i, s: torch.tensor([False, False])]
+    assert _call_hooks(crit, ids, None, chain=False).tolist() == [True, False]
+    assert _call_hooks(StoppingCriteriaList([MaxLengthCriteria(max_length=3)]), ids, None, chain=False).tolist() == [True, True]
+    assert _call_hooks(StoppingCriteriaList([MaxLengthCriteria(max_length=4)]), ids, None, chain=False).tolist() == [False, False]
+
+
 def test_generate_argument_policy_defaults_unknowns_and_max_length():
     from padt_amd.modeling import PaDTForConditionalGeneration, check_generate_kwargs
     # the callers' own call (eval/test_demo.py:96-103, utils.py:224-232) and the reference's default-valued arguments pass
-    ok = dict(attn_implementation="flash_attention_2", tokenizer=None, stopping_criteria=None, logits_processor=[], streamer=None, num_beams=1,
+    ok = dict(attn_implementation="flash_attention_2", tokenizer=None, streamer=None, num_beams=1,
               min_length=0, generation_config=None, pixel_values_videos=None,
               bos_token_id=151643, decoder_start_token_id=None, return_legacy_cache=True)       # benign GenerationConfig fields (ADVICE r05)
     assert check_generate_kwargs(dict(ok), 16, None, 9) == 16

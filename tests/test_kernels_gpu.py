@@ -1212,3 +1212,35 @@ def test_mask_rle_on_the_device_is_the_host_statement_byte_for_byte(ops):
     for k, s in enumerate(exp_golden):
         assert got_s[k] == s                                          # the reference-side fixture itself
     assert ops.mask_rle(torch.zeros((0, 4, 4), dtype=torch.uint8, device="cuda"), None, None) == []
+
+
+def test_mask_rle_bounded_scratch_overflow_and_oversize_objects_are_reported(ops):
+    """the per-call scratch is bounded (128 runs per column) and cached per shape — blob masks fit; a noise mask beyond it is REPORTED
+    (fetch → None / PaDTHipError) and ops.mask_rle answers it with the worst-case capacities; an object taller than the launch's max_h or wider than a
+    mask row is reported by the kernel instead of overrunning the LDS strip."""
+    import numpy as np
+    from padt_amd import _lib, postprocess as P
+    yy, xx = np.mgrid[0:320, 0:400]
+    blob = (((yy - 150) ** 2 + (xx - 200) ** 2) < 100 ** 2).astype(np.uint8)
+    noise = (np.random.default_rng(3).random((320, 400)) < 0.5).astype(np.uint8)
+    buf = torch.from_numpy(np.stack([blob, blob.T.copy().T])).cuda()
+    dh = torch.tensor([320, 320], dtype=torch.int32, device="cuda")
+    dw = torch.tensor([400, 400], dtype=torch.int32, device="cuda")
+    h1 = ops.mask_rle_launch(buf, dh, dw)
+    assert h1["counts"].shape[1] == 128 * 400 + 2                    # bounded, not 320 * 400 + 2
+    s1 = ops.mask_rle_fetch(h1, on_overflow="none")
+    assert s1 is not None and s1[0] == P.rle_string(P.rle_counts(blob))
+    h2 = ops.mask_rle_launch(buf, dh, dw)
+    assert h2["counts"].data_ptr() == h1["counts"].data_ptr()        # the cached scratch of this shape
+    nb = torch.from_numpy(np.stack([blob, noise])).cuda()
+    h3 = ops.mask_rle_launch(nb, dh, dw)
+    assert ops.mask_rle_fetch(h3, on_overflow="none") is None
+    with pytest.raises(_lib.PaDTHipError):
+        ops.mask_rle_fetch(ops.mask_rle_launch(nb, dh, dw))
+    assert ops.mask_rle(nb, dh, dw)[1] == P.rle_string(P.rle_counts(noise))      # worst-case capacities on the second attempt
+    too_tall = torch.tensor([320, 321], dtype=torch.int32, device="cuda")
+    h4 = ops.mask_rle_launch(buf, too_tall, dw)
+    assert ops.mask_rle_fetch(h4, on_overflow="none") is None and h4["n_counts"].cpu().tolist()[1] == -1
+    too_wide = torch.tensor([400, 401], dtype=torch.int32, device="cuda")
+    h5 = ops.mask_rle_launch(buf, dh, too_wide)
+    assert ops.mask_rle_fetch(h5, on_overflow="none") is None and h5["n_counts"].cpu().tolist()[1] == -1
