@@ -162,7 +162,9 @@ int  padt_decode_attn(void* stream, const void* q, const void* k_cache, const vo
  *   V[32 ks + 4 fq + e][16 i + frow], e < 4, then the same keys + 16) — every wave-wide load is 1 KiB contiguous — and ONE launch: a block
  *   of 8 waves per (kv head, sample) streams the sample's keys, merges on chip and writes the output rows; no workspace (may be null).
  *   11.2 us per layer at 64 rows against 18.7 (profiles/r06_decode_attn_v3.log).  Same results up to one 16-bit rounding (different
- *   merge order).  padt_llm_qkv_post writes the same images when given cache_packed = 1.
+ *   merge order).  padt_llm_qkv_post writes the same images when given cache_packed = 1.  While Hkv x batch <= 128 a (kv head, sample) is
+ *   given to TWO blocks: both score all keys, each multiplies half of the d-tiles with its half of V^T and stores that half of the output columns
+ *   (all 256 CUs stream KV: 13.3 → 12.0 us at 64 rows x 2 kv heads with rotating caches, 8.1 → 6.9 at 8 rows); bit-identical to one block.  cache_packed = 2 / 3 force one / two blocks.
  * HF:557-599, 641-689, 665-666. */
 int padt_decode_attn_rope(void* stream, const void* qkv, long ld_qkv, const void* rope_cs, const int* slot, void* k_cache,
                           void* vt_cache, void* out, void* workspace, int batch, int n_heads, int n_kv_heads, int head_dim,

@@ -748,11 +748,19 @@ PADT_DEV void rope_chunk_pair(const u32x4& r1, const u32x4& r2, const float2* cs
     hi = pack8(o2);
 }
 
-template <int D, int NW, bool PACKED>
+// DS (round 6): with Hkv x B <= 128 blocks only half of the 256 CUs stream KV (64 rows x 2 kv heads: 13.3 us for 38.7 MB, of which ≈7 us are the launch's
+// fixed chain slot → q / k → rope → first split → merge).  DS = 2 gives a (kv head, sample) to TWO blocks (blockIdx.z): both compute the scores and the soft-max
+// over ALL keys (K is read twice — the pair runs concurrently on one XCD, the second read hits its L2), each multiplies HALF of the d-tiles (its half of
+// V^T) and stores that half of the output columns; block 0 appends k, each block the v rows of its half.  No hand-off between the two (the fresh k / v come
+// from registers in both); every output bit is the DS = 1 kernel's.  Measured (8 rotating cache sets, graph replays): 13.3 → 12.0 us at 64 rows, 8.6 → 7.5 at
+// 32, 8.1 → 6.9 at 8; at 128 rows (256 blocks already) 19.6 → 26.7: not taken there.  (Requesting the first split's fragments ahead of the rope prologue
+// was measured too: 256 VGPRs at DS = 1, 16.7 us — dropped.)
+template <int D, int NW, bool PACKED, int DS = 1>
 __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(DecodePackedArgs p) {
 #pragma clang fp contract(off)
     static_assert(D == 128, "fragment map below is written for 16 chunks per head");
-    constexpr int KQ = D / 32, NB = D / 16, HALF = D / 2;
+    constexpr int KQ = D / 32, NB = D / 16 / DS, HALF = D / 2;     // NB: the d-tiles of THIS block
+    const int i0 = (DS > 1 ? (int)blockIdx.z : 0) * NB;           // its first d-tile
     extern __shared__ __attribute__((aligned(16))) float v3_lds[];
     float* sm_ml = v3_lds;                                        // [NW][64][2]
     f32x4* sm_o = reinterpret_cast<f32x4*>(v3_lds + NW * 64 * 2); // [NW][NB][64]
@@ -816,7 +824,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(Decode
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < NB; ++i)
-                        vfr[ks][i] = *reinterpret_cast<const u32x4*>(vbase + ((long)i * (p.S_max >> 5) + (k0 >> 5) + ks) * 512 + lane * 8);
+                        vfr[ks][i] = *reinterpret_cast<const u32x4*>(vbase + ((long)(i0 + i) * (p.S_max >> 5) + (k0 >> 5) + ks) * 512 + lane * 8);
             } else {
 #pragma unroll
                 for (int kb = 0; kb < 4; ++kb) {
@@ -829,7 +837,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(Decode
                 for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
                     for (int i = 0; i < NB; ++i) {
-                        const x16_t* vr = vbase + (long)(i * 16 + frow) * p.S_max + k0 + ks * 32 + fq * 4;
+                        const x16_t* vr = vbase + (long)((i0 + i) * 16 + frow) * p.S_max + k0 + ks * 32 + fq * 4;
                         const u32x2 v0 = *reinterpret_cast<const u32x2*>(vr), v1 = *reinterpret_cast<const u32x2*>(vr + 16);
                         vfr[ks][i] = u32x4{v0[0], v0[1], v1[0], v1[1]};
                     }
@@ -838,11 +846,12 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(Decode
             if (owner) {
                 unsigned vapp[2];
 #pragma unroll
-                for (int i = 0; i < NB; ++i) vnew[i] = vrow[i * 16 + frow];
+                for (int i = 0; i < NB; ++i) vnew[i] = vrow[(i0 + i) * 16 + frow];
                 vapp[0] = vrow[lane];
                 vapp[1] = vrow[lane + 64];
+                const bool app_k = DS == 1 || blockIdx.z == 0;    // DS = 2: block 0 appends k, block z the v rows d in [64 z, 64 z + 64)
                 if constexpr (PACKED) {
-                    if (frow == 0) {
+                    if (frow == 0 && app_k) {
 #pragma unroll
                         for (int kk = 0; kk < KQ; ++kk)
                             *reinterpret_cast<u32x4*>(kbase + ((((long)(slot >> 4) * KQ + kk) * 64) + fq * 16 + (slot & 15)) * 8) = kn[kk];
@@ -852,15 +861,15 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(Decode
 #pragma unroll
                     for (int h = 0; h < 2; ++h) {
                         const int d = lane + 64 * h;
-                        vbase[(long)(d >> 4) * (p.S_max >> 5) * 512 + vcol + (d & 15) * 8] = (x16_t)vapp[h];
+                        if (DS == 1 || (int)blockIdx.z == h) vbase[(long)(d >> 4) * (p.S_max >> 5) * 512 + vcol + (d & 15) * 8] = (x16_t)vapp[h];
                     }
                 } else {
-                    if (frow == 0) {
+                    if (frow == 0 && app_k) {
 #pragma unroll
                         for (int kk = 0; kk < KQ; ++kk) *reinterpret_cast<u32x4*>(kbase + (long)slot * D + kk * 32 + fq * 8) = kn[kk];
                     }
-                    vbase[(long)lane * p.S_max + slot] = (x16_t)vapp[0];
-                    vbase[(long)(lane + 64) * p.S_max + slot] = (x16_t)vapp[1];
+                    if (DS == 1 || blockIdx.z == 0) vbase[(long)lane * p.S_max + slot] = (x16_t)vapp[0];
+                    if (DS == 1 || blockIdx.z == 1) vbase[(long)(lane + 64) * p.S_max + slot] = (x16_t)vapp[1];
                 }
             }
             const int rel = slot - k0;
@@ -958,7 +967,7 @@ __global__ __launch_bounds__(NW * 64) void decode_attn_rope_packed_kernel(Decode
             f32x4 acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int w = 0; w < NW; ++w) acc += sm_o[(w * NB + i) * 64 + lane] * wgt[w];
-            const int n = (g * group + frow) * D + i * 16 + fq * 4;   // 4 consecutive columns of output row b
+            const int n = (g * group + frow) * D + (i0 + i) * 16 + fq * 4;   // 4 consecutive columns of output row b
             const long off = p.out_packed ? (long)(b >> 4) * 16 * ld + ((long)(n >> 3) * 16 + (b & 15)) * 8 + (n & 7) : (long)b * ld + n;
             *reinterpret_cast<u32x2*>(p.out + off) = u32x2{pack2x(acc[0] * inv, acc[1] * inv), pack2x(acc[2] * inv, acc[3] * inv)};
         }
@@ -1091,11 +1100,19 @@ extern "C" int PADT_TWIN(padt_decode_attn_rope)(void* stream, const void* qkv, l
         constexpr int NW = 8;
         constexpr int lds = NW * 64 * 2 * 4 + NW * 8 * 64 * 16;
         static PerDeviceOnce once;
-        once.run([] { (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_packed_kernel<128, NW, true>),
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, lds); });
+        once.run([] {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_packed_kernel<128, NW, true, 1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&decode_attn_rope_packed_kernel<128, NW, true, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        });
         DecodePackedArgs pa{(const x16_t*)qkv, ld_qkv, (const float*)rope_cs, slot, (x16_t*)k_cache, (x16_t*)vt_cache, (x16_t*)out,
                             batch, n_heads, n_kv_heads, s_max, scale * 1.4426950408889634f, out_packed};
-        hipLaunchKernelGGL((decode_attn_rope_packed_kernel<128, NW, true>), dim3(n_kv_heads, batch), dim3(NW * 64), lds, (hipStream_t)stream, pa);
+        // two blocks per (kv head, sample) while one block each would leave half of the chip without a KV stream (decode_attn_rope_packed_kernel, DS);
+        // cache_packed = 2 / 3 or PADT_DECODE_ATTN_DSPLIT = 0 / 1 force the choice (tests, A/B)
+        static const int env = getenv("PADT_DECODE_ATTN_DSPLIT") ? atoi(getenv("PADT_DECODE_ATTN_DSPLIT")) : -1;
+        const int force = cache_packed == 2 ? 0 : (cache_packed == 3 ? 1 : env);
+        const bool dsplit = force >= 0 ? force != 0 : (long)n_kv_heads * batch <= 128;
+        if (dsplit) hipLaunchKernelGGL((decode_attn_rope_packed_kernel<128, NW, true, 2>), dim3(n_kv_heads, batch, 2), dim3(NW * 64), lds, (hipStream_t)stream, pa);
+        else hipLaunchKernelGGL((decode_attn_rope_packed_kernel<128, NW, true, 1>), dim3(n_kv_heads, batch), dim3(NW * 64), lds, (hipStream_t)stream, pa);
         hipError_t e = hipGetLastError();
         if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
         return 0;

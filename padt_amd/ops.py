@@ -407,12 +407,12 @@ def rope_table(pos3, inv_freq, out, head_dim, sections):
 def decode_attn_rope(qkv, rope_cs, slot, k_cache, vt_cache, out, workspace, n_heads, n_kv_heads, head_dim, s_max, max_len,
                      scale=None, out_packed=False, cache_packed=False):
     """cache_packed: k_cache / vt_cache hold the fragment-packed images (pack_k_cache / pack_vt_cache, written by llm_qkv_post(cache_packed=True))
-    → the one-launch kernel (no workspace needed)."""
+    → the one-launch kernel (no workspace needed); 2 / 3 force one / two blocks per (kv head, sample) (True = 1: chosen from Hkv x batch)."""
     dt = _x16(qkv, k_cache, vt_cache, out)
     scale = head_dim ** -0.5 if scale is None else scale
     _lib.check(_fn("padt_decode_attn_rope", dt)(_stream(), _p(qkv), qkv.stride(0), _p(rope_cs), _p(slot), _p(k_cache), _p(vt_cache),
                                          _p(out), _p(workspace), qkv.shape[0], n_heads, n_kv_heads, head_dim, s_max,
-                                         int(max_len), float(scale), 1 if out_packed else 0, 1 if cache_packed else 0), "padt_decode_attn_rope")
+                                         int(max_len), float(scale), 1 if out_packed else 0, int(cache_packed)), "padt_decode_attn_rope")
     return out
 
 

@@ -572,6 +572,12 @@ def test_decode_attn_rope_on_fragment_packed_caches(ops, Hq, Hkv, dt):
         ops.llm_qkv_post(qkv, gpos, inv, qd, kq, vq, Hq, Hkv, D, S_max, sec, slot=slot_t, cache_packed=True)
         assert torch.equal(kq, kp) and torch.equal(vq, vp), f"prompt-pass append into the packed images differs (positions seed {seed})"
         assert torch.isfinite(o2.float()).all()
+        # one block per (kv head, sample) (cache_packed = 2) and two blocks, each with half of the d-tiles (3): the same bits, outputs and appends
+        for force in (2, 3):
+            kf_, vf_ = ops.pack_k_cache(kc), ops.pack_vt_cache(vt)
+            of_ = torch.zeros_like(o1)
+            ops.decode_attn_rope(qkv, cs, slot_t, kf_, vf_, of_, None, Hq, Hkv, D, S_max, S_max, cache_packed=force)
+            assert torch.equal(of_, o2) and torch.equal(kf_, kp) and torch.equal(vf_, vp), f"decode attention with cache_packed = {force} differs (positions seed {seed})"
         # at most two 16-bit roundings apart (8 / 11 mantissa bits) + fp32 noise on outputs that cancel to ~0: the probabilities are rounded to
         # 16 bits relative to the RUNNING maximum here and to each split's own maximum in the two-launch form, then merged in a different order
         # (an output that cancels to a small value carries the P-rounding noise of the whole row: an absolute term of one 16-bit step of the row scale)

@@ -50,7 +50,7 @@ def main():
     x = torch.randn(B, D, device="cuda").to(BF)
     h = torch.randn(B, I, device="cuda").to(BF)
     res = {}
-    for name, N, K, epi, a in (("qkv", QKV, D, 0, x), ("o", D, D, 2, x), ("gu", 2 * I, D, 3, x), ("down", D, I, 2, h)):
+    for name, N, K, epi, a in (() if os.environ.get("GEMMS_SKIP") else (("qkv", QKV, D, 0, x), ("o", D, D, 2, x), ("gu", 2 * I, D, 3, x), ("down", D, I, 2, h))):
         ws = [torch.randn(N, K, device="cuda").to(BF) * 0.02 for _ in range(int(os.environ.get('ROT', 6)))]   # rotate weights: defeat L2/MALL reuse
         if fp8:                                                   # timing only: random bytes stand in for the e4m3 image
             ws = [torch.randint(0, 120, (N, (K + 63) // 64 * 64), device="cuda", dtype=torch.uint8) for _ in ws]
@@ -98,8 +98,12 @@ def main():
     # decode attention (rope + append + split attention + merge), Pro_3B heads, ~600 cached tokens
     Hq, Hkv, D, S_max = 16, 2, 128, 640
     qkv = torch.randn(B, (Hq + 2 * Hkv) * D, device="cuda").to(BF)
-    kcs = [torch.randn(B, Hkv, S_max, D, device="cuda").to(BF) for _ in range(4)]
-    vts = [torch.randn(B, Hkv, D, S_max, device="cuda").to(BF) for _ in range(4)]
+    nkv = int(os.environ.get("ROTKV", 8))                         # rotating cache sets: > the 256 MB Infinity Cache at 64 rows
+    kvp = bool(os.environ.get("KVP"))                              # KVP=1: fragment-packed caches → the one-launch kernel (what the decode step runs)
+    kcs = [torch.randn(B, Hkv, S_max, D, device="cuda").to(BF) for _ in range(nkv)]
+    vts = [torch.randn(B, Hkv, D, S_max, device="cuda").to(BF) for _ in range(nkv)]
+    if kvp:
+        kcs, vts = [ops.pack_k_cache(k) for k in kcs], [ops.pack_vt_cache(v) for v in vts]
     cs = torch.randn(B, D // 2, 2, device="cuda")
     slot = torch.full((B,), 600, dtype=torch.int32, device="cuda")
     att = torch.zeros(B, Hq * D, device="cuda", dtype=BF)
@@ -108,8 +112,10 @@ def main():
 
     def fa():
         j[0] += 1
-        ops.decode_attn_rope(qkv, cs, slot, kcs[j[0] % 4], vts[j[0] % 4], att, wsd, Hq, Hkv, D, S_max, S_max)
-    print(f"decode_attn_rope B={B}: {timeit(fa):7.2f} us")
+        ops.decode_attn_rope(qkv, cs, slot, kcs[j[0] % nkv], vts[j[0] % nkv], att, wsd, Hq, Hkv, D, S_max, S_max, cache_packed=kvp)
+    print(f"decode_attn_rope B={B}{' packed caches' if kvp else ''}: {timeit(fa):7.2f} us")
+    if os.environ.get("ATTN_ONLY"):
+        return
     hid = torch.randn(B, 2048, device="cuda").to(BF)
     table = (torch.randn(151936, 2048, device="cuda") * 0.02).to(BF)
     proto = (torch.randn(4232 * max(1, B // 8), 2048, device="cuda") * 0.02).to(BF)
