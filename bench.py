@@ -535,7 +535,8 @@ def bf16_twin_leg(cfg, args, grid_hw, device):
 
 def reference_precision_leg(cfg, args, grid_hw, device):
     """The SAME workload with precision="reference" (padt_amd/reference.py: ViT / LLM on (hi, lo) bf16 GEMM operands at twice the MFMA work,
-    exact-fp32 attention on the f32-input MFMA incl. an fp32 KV cache, captured decode steps): the mode that meets the north star's 1e-3 on EVERY
+    exact-fp32 attention on the f32-input MFMA incl. an fp32 KV cache, captured decode steps whose projections read each weight once, the SwiGLU as the
+    gate/up GEMM's epilogue): the mode that meets the north star's 1e-3 on EVERY
     float output, mask logits included (tests/test_reference_mode_gpu.py: full-depth 3B boxes 1.8e-6 / mask logits 2.7e-5, tokens equal) — its
     price next to the headline, same runner shape (depth x merge) as the headline."""
     import copy
@@ -566,7 +567,8 @@ def reference_precision_leg(cfg, args, grid_hw, device):
     return {"value": round(a.batch * steps / e, 3), "unit": "images/s", "steps": steps, "ms_per_step": round(e / steps * 1e3, 3),
             "note": "precision='reference': split-precision (hi, lo) bf16 GEMM operands through ViT / merger / prototypes / LLM (2x the MFMA work), exact-fp32 "
                     "attention on the f32-input MFMA (v_mfma_f32_16x16x4_f32: ViT windows / full layers, causal GQA prompt pass, decode steps over an fp32 KV "
-                    "cache), hipGraph-captured decode steps in groups of %d batches (round 5: VALU attention, eager steps, groups of 2: 24.3 images/s); parity of "
+                    "cache), hipGraph-captured decode steps in groups of %d batches whose projections read every weight once (padt_gemm_split_rows), SwiGLU fused into the "
+                    "gate/up GEMM epilogue (round 5: VALU attention, eager steps, groups of 2: 24.3 images/s); parity of "
                     "THIS run's first batch against the oracle: cpu_baseline.parity.reference_precision; full-depth suites: tests/test_reference_mode_gpu.py" % a.merge}
 
 
