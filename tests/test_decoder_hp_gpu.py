@@ -131,6 +131,21 @@ def test_gemm_hp_split_swiglu_against_fp64(ops, M, I, K, bias):
     d = (join(h, I).double() - join(h0, I).double()).abs()
     lim = join(h0, I).double().abs() * 2.0 ** -15 + 4e-6 * ref.pow(2).mean().sqrt()
     assert bool((d <= lim).all()), f"fused vs unfused SwiGLU: worst ratio {(d / lim).max().item():.2f}"
+    if M > 64:
+        # every dispatch variant of the tile kernel writes the same pairs: forced tile heights, a peeled ragged tail (its rows go through the few-row
+        # kernel at K' = 2K), the column split (second launch at a column offset of the SAME hi / lo halves), the 128^2 kernel
+        try:
+            for kn in (dict(mf=2), dict(mf=3), dict(mf=4), dict(peel=2), dict(colsplit=2), dict(mode256=0)):
+                ops.gemm_knobs(**kn)
+                hv = ops.gemm_hp(a_s, w2, b, epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)
+                if "peel" in kn:                                  # the peeled rows are summed in the few-row kernel's wave order: fp32 noise apart
+                    dd = (join(hv, I).double() - join(h, I).double()).abs()
+                    assert bool((dd <= lim).all()), f"split SwiGLU with a peeled tail: worst ratio {(dd / lim).max().item():.2f}"
+                else:
+                    assert torch.equal(hv, h), f"split SwiGLU differs under dispatch knob {kn}"
+                ops.gemm_knobs(mode256=1, mf=0, peel=1, colsplit=1, group_m=8)
+        finally:
+            ops.gemm_knobs(mode256=1, mf=0, peel=1, colsplit=1, group_m=8)
 
 
 def ref_attn64(q, k, v, cq, ck, H, D):
