@@ -138,9 +138,9 @@ def test_gemm_hp_split_swiglu_against_fp64(ops, M, I, K, bias):
             for kn in (dict(mf=2), dict(mf=3), dict(mf=4), dict(peel=2), dict(colsplit=2), dict(mode256=0)):
                 ops.gemm_knobs(**kn)
                 hv = ops.gemm_hp(a_s, w2, b, epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)
-                if "peel" in kn:                                  # the peeled rows are summed in the few-row kernel's wave order: fp32 noise apart
+                if "peel" in kn or "mode256" in kn:               # peeled rows are summed in the few-row kernel's wave order, the 128^2 kernel walks K in its own phase order: fp32 noise apart
                     dd = (join(hv, I).double() - join(h, I).double()).abs()
-                    assert bool((dd <= lim).all()), f"split SwiGLU with a peeled tail: worst ratio {(dd / lim).max().item():.2f}"
+                    assert bool((dd <= lim).all()), f"split SwiGLU under {kn}: worst ratio {(dd / lim).max().item():.2f}"
                 else:
                     assert torch.equal(hv, h), f"split SwiGLU differs under dispatch knob {kn}"
                 ops.gemm_knobs(mode256=1, mf=0, peel=1, colsplit=1, group_m=8)
