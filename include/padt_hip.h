@@ -242,9 +242,11 @@ int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const void* W, long
  * (every weight fragment multiplies the hi and the lo fragment of a row block) — pass padt_gemm_bf16_ex's doubled image with ldw = 2K.
  * epilogue 0 / 2: C fp32 = A_hi W^T + A_lo W^T + bias (+ R_f32, in place allowed), c_lo_off = 0; epilogue 3: SwiGLU over [gate16 | up16]-interleaved
  * weight rows (N % 32 == 0), C = bf16 split rows — silu(gate) * up as (hi, lo) pairs, hi at C[m][n], lo at C[m][c_lo_off + n], n < N / 2 (exact expf and
- * division, as padt_swiglu_split).  HF:641-757 at one token per row. */
+ * division, as padt_swiglu_split).  layout: bit 0 — A_split is the 16-row fragment-packed image of the split rows (padt_pack_rows over their 2K
+ * columns: lda = 2K, a_lo_off = 16 K); bit 1 — W is the fragment-packed image of padt_gemm_packed_bf16 ([N/16][ldw/32][64 lanes][8], ldw = K padded to
+ * 32, N % 16 == 0): every wave load of either operand is then 1 KiB contiguous.  HF:641-757 at one token per row. */
 int padt_gemm_split_rows(void* stream, const void* A_split, long lda, long a_lo_off, const void* W, long ldw, const void* bias, void* C,
-                         long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue);
+                         long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue, int layout);
 /* Row kernel: y0 = f(x), y1 = f(x) + pos[r % pos_rows], f(x) = act(RMSNorm_w(x[idx[r]] + add[r / add_div])), every stage
  * optional (null pointer); x bf16 or fp32 (x_f32); each output off (mode 0), fp32 rows (1) or bf16 split rows (2) laid out
  * [hi(chunk) lo(chunk)] x D/chunk.  padt_decoder.py:71-74 (RMSNorm), :30-31 (+ positional query), :220 (repeat4(low) + high),

@@ -755,36 +755,50 @@ extern "C" int padt_gemm_bf16_ex(void* stream, const void* A, long lda, const vo
 // W [N][ldw] bf16 with the first K columns used — pass the doubled image [W | W] of padt_gemm_bf16_ex with ldw = 2K and it is read ONCE.
 // M <= 64; epilogue 0 or 2 (fp32 residual, in place allowed) → fp32 C; epilogue 3 (SwiGLU over [gate16 | up16]-interleaved weight rows, N % 32 == 0)
 // → C = bf16 split rows: silu(gate) * up as (hi, lo) pairs, hi at C[m][n], lo at C[m][c_lo_off + n], n < N / 2.
+// layout (round 6): bit 0 — A is in the 16-row fragment-packed activation layout (padt_pack_rows of the split rows: lda = their row length 2K, a_lo_off =
+// 16 K: the lo fragment of K-step ks is the fragment of K-step ks + K / 32); bit 1 — W is the fragment-packed image of padt_gemm_packed_bf16
+// ([N/16][ldw/32][64 lanes][8], ldw = K padded to 32).  Row-major rows cost 16 x 64-byte pieces per wave load on both operands — the address unit, not
+// HBM, bounded these launches (gate/up 70 us at 64 rows against 24 us for the default path's packed launch).
+template <bool PACKED>
+static void split_rows_launch(const GemmArgs& a, long M, int epilogue, hipStream_t s) {
+    if (epilogue == EPI_SWIGLU) {
+        if (M <= 16) launch_skinny<1, EPI_SWIGLU, false, false, PACKED, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_SWIGLU, false, false, PACKED, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_SWIGLU, false, false, PACKED, 2>(a, 0.f, s);
+    } else if (epilogue == EPI_RESID) {
+        if (M <= 16) launch_skinny<1, EPI_RESID, true, false, PACKED, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_RESID, true, false, PACKED, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_RESID, true, false, PACKED, 2>(a, 0.f, s);
+    } else {
+        if (M <= 16) launch_skinny<1, EPI_NONE, true, false, PACKED, 2>(a, 0.f, s);
+        else if (M <= 32) launch_skinny<2, EPI_NONE, true, false, PACKED, 2>(a, 0.f, s);
+        else launch_skinny<4, EPI_NONE, true, false, PACKED, 2>(a, 0.f, s);
+    }
+}
+
 extern "C" int padt_gemm_split_rows(void* stream, const void* A_split, long lda, long a_lo_off, const void* W, long ldw, const void* bias, void* C,
-                                    long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue) {
+                                    long ldc, long c_lo_off, const void* R_f32, long ldr, long M, long N, long K, int epilogue, int layout) {
     if (M <= 0 || N <= 0) return 0;
     const bool glu = epilogue == EPI_SWIGLU;
+    const bool a_packed = layout & 1, w_packed = layout & 2;
     if (M > 64 || K <= 0 || (K & 7) || (lda & 7) || (ldw & 7) || (a_lo_off & 7) || a_lo_off < K || ((uintptr_t)A_split & 15) || ((uintptr_t)W & 15) ||
         (ldc & 3) || ((uintptr_t)C & 15) || ((uintptr_t)bias & 7) || (epilogue != EPI_NONE && epilogue != EPI_RESID && !glu) ||
         (epilogue == EPI_RESID && (R_f32 == nullptr || (ldr & 3) || ((uintptr_t)R_f32 & 15))) ||
-        (glu && ((N & 31) || (c_lo_off & 3) || c_lo_off < N / 2 || ldc < c_lo_off + N / 2)) || (!glu && c_lo_off != 0)) {
+        (glu && ((N & 31) || (c_lo_off & 3) || c_lo_off < N / 2 || ldc < c_lo_off + N / 2)) || (!glu && c_lo_off != 0) ||
+        (w_packed && ((ldw & 31) || ldw < K || (N & 15))) || (a_packed && ((K & 31) || a_lo_off != 16 * K)) || (layout & ~3)) {
         padt_set_error("padt_gemm_split_rows: M <= 64, K / lda / ldw / a_lo_off multiples of 8, a_lo_off >= K, 16-byte aligned A / W / C / R, epilogue 0, 2 "
-                       "(fp32 C, c_lo_off 0) or 3 (N % 32 == 0, bf16 pairs: c_lo_off % 4 == 0, c_lo_off >= N / 2, ldc >= c_lo_off + N / 2)");
+                       "(fp32 C, c_lo_off 0) or 3 (N % 32 == 0, bf16 pairs: c_lo_off % 4 == 0, c_lo_off >= N / 2, ldc >= c_lo_off + N / 2); packed W: ldw % 32 == 0, "
+                       "N % 16 == 0; packed A: K % 32 == 0 and a_lo_off == 16 K");
         return -1;
     }
     GemmArgs a{(const x16_t*)A_split, lda, (const x16_t*)W, ldw, (const x16_t*)bias, C, ldc, (const x16_t*)R_f32, ldr, (int)M, (int)N, (int)K};
     a.a_lo_off = a_lo_off;
     a.lo_off = c_lo_off;
     a.r_f32 = epilogue == EPI_RESID ? 1 : 0;
+    a.a_pack = a_packed ? 1 : 0;
     hipStream_t s = (hipStream_t)stream;
-    if (glu) {
-        if (M <= 16) launch_skinny<1, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
-        else if (M <= 32) launch_skinny<2, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
-        else launch_skinny<4, EPI_SWIGLU, false, false, false, 2>(a, 0.f, s);
-    } else if (epilogue == EPI_RESID) {
-        if (M <= 16) launch_skinny<1, EPI_RESID, true, false, false, 2>(a, 0.f, s);
-        else if (M <= 32) launch_skinny<2, EPI_RESID, true, false, false, 2>(a, 0.f, s);
-        else launch_skinny<4, EPI_RESID, true, false, false, 2>(a, 0.f, s);
-    } else {
-        if (M <= 16) launch_skinny<1, EPI_NONE, true, false, false, 2>(a, 0.f, s);
-        else if (M <= 32) launch_skinny<2, EPI_NONE, true, false, false, 2>(a, 0.f, s);
-        else launch_skinny<4, EPI_NONE, true, false, false, 2>(a, 0.f, s);
-    }
+    if (w_packed) split_rows_launch<true>(a, M, epilogue, s);
+    else split_rows_launch<false>(a, M, epilogue, s);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) { padt_set_error(hipGetErrorString(e)); return -2; }
     return 0;

@@ -782,10 +782,12 @@ F32 = torch.float32
 OUT_NONE, OUT_F32, OUT_SPLIT = 0, 1, 2
 
 
-def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_mode=OUT_F32, M=None):
+def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, out_mode=OUT_F32, M=None, w_packed=None):
     """Split-precision GEMM (include/padt_hip.h "hp decoder"): a_split (M, 2K) bf16 rows [hi | lo], w2 (N, 2K) = [W | W].
     out_mode OUT_F32 → fp32 (M, N) [+ fp32 residual, in place allowed]; OUT_SPLIT → bf16 (M, 2N) rows [hi | lo]; epilogue EPI_SWIGLU (OUT_SPLIT only,
-    weight rows [gate16 | up16]-interleaved) → bf16 (M, 2 * N/2) split rows of silu(gate) * up."""
+    weight rows [gate16 | up16]-interleaved) → bf16 (M, 2 * N/2) split rows of silu(gate) * up.
+    w_packed (few rows only): the pack_weight() image of W — the rows are then packed too (one padt_pack_rows launch) so that every wave load of
+    either operand is 1 KiB contiguous (padt_gemm_split_rows, layout 3)."""
     lib = _lib.load()
     _chk_bf16(a_split, w2, bias)
     M = a_split.shape[0] if M is None else M
@@ -809,8 +811,14 @@ def gemm_hp(a_split, w2, bias=None, out=None, epilogue=EPI_NONE, residual=None, 
     if M <= 64 and K2 % 16 == 0 and ((out_mode == OUT_F32 and epilogue in (EPI_NONE, EPI_RESID)) or epilogue == EPI_SWIGLU):
         # few rows (a decode step): bound by the weight stream — read W once and multiply it with the hi and the lo fragments (padt_gemm_split_rows)
         K = K2 // 2
+        if w_packed is not None and K % 32 == 0 and N % 16 == 0 and a_split.stride(0) == K2:
+            ap = torch.empty(((M + 15) // 16 * 16, K2), device=a_split.device, dtype=BF16)
+            pack_rows(a_split, ap, M, to_packed=True)
+            _lib.check(lib.padt_gemm_split_rows(_stream(), _p(ap), K2, 16 * K, _p(w_packed), w_packed.stride(0), _p(bias), _p(out), out.stride(0), lo_off,
+                                                _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue, 3), "padt_gemm_split_rows")
+            return out
         _lib.check(lib.padt_gemm_split_rows(_stream(), _p(a_split), a_split.stride(0), K, _p(w2), w2.stride(0), _p(bias), _p(out), out.stride(0), lo_off,
-                                            _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue), "padt_gemm_split_rows")
+                                            _p(residual), residual.stride(0) if residual is not None else 0, M, N, K, epilogue, 0), "padt_gemm_split_rows")
         return out
     if GEMM_LOG is not None:
         GEMM_LOG.append(("hp", a_split, w2, bias, out, epilogue, residual, out_mode, M))

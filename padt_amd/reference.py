@@ -79,6 +79,10 @@ def prepare_reference_weights(sd: Dict[str, torch.Tensor], cfg: PaDTConfig, devi
         R[d + "o.hp"] = _dbl(g(s + "self_attn.o_proj.weight"))
         R[d + "gu.hp"] = _dbl(interleave16(_pad_rows(g(s + "mlp.gate_proj.weight"), li_pad), _pad_rows(g(s + "mlp.up_proj.weight"), li_pad)))
         R[d + "down.hp"] = _dbl(_pad_cols(g(s + "mlp.down_proj.weight"), li_pad))
+        # decode steps (<= 64 rows): the fragment-packed image of each projection (the K' = 2K images above are the prompt pass's) — 1-KiB wave loads
+        for nm in ("qkv", "o", "gu", "down"):
+            w2 = R[d + nm + ".hp"]
+            R[d + nm + ".pk"] = ops.pack_weight(w2[:, : w2.shape[1] // 2].contiguous())
     R["llm.norm"] = g("model.norm.weight").contiguous()
     R["llm.embed32"] = sd["model.embed_tokens.weight"].to(device=dev, dtype=F32).contiguous()
     if cfg.use_visual_prototype_projection:
@@ -186,13 +190,15 @@ class ReferencePath:
     def _layer(self, i, x32, attention):
         cfg, R = self.cfg, self.R
         d = f"llm.{i}."
+        few = x32.shape[0] <= 64                                               # a decode step: packed operands (ops.gemm_hp, w_packed)
+        pk = (lambda nm: R[d + nm + ".pk"]) if few else (lambda nm: None)
         n, _ = ops.norm_split(x32, R[d + "in_norm"], eps=cfg.rms_norm_eps)
-        qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"])
+        qkv = ops.gemm_hp(n, R[d + "qkv.hp"], R[d + "qkv.b"], w_packed=pk("qkv"))
         a = attention(qkv)                                                     # fp32 rotary + fp32 attention → (hi, lo) rows
-        ops.gemm_hp(a, R[d + "o.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+        ops.gemm_hp(a, R[d + "o.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32, w_packed=pk("o"))
         n, _ = ops.norm_split(x32, R[d + "post_norm"], eps=cfg.rms_norm_eps)
-        h = ops.gemm_hp(n, R[d + "gu.hp"], epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)             # silu(gate) * up as (hi, lo) rows
-        ops.gemm_hp(h, R[d + "down.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32)
+        h = ops.gemm_hp(n, R[d + "gu.hp"], epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT, w_packed=pk("gu"))   # silu(gate) * up as (hi, lo) rows
+        ops.gemm_hp(h, R[d + "down.hp"], out=x32, epilogue=ops.EPI_RESID, residual=x32, w_packed=pk("down"))
 
     def prefill(self, plan, low32, sess, nf=None):
         """Packed prompt pass; fills the session's fp32 KV cache; → post-norm hidden rows of all prompt tokens, fp32 (T, D)."""

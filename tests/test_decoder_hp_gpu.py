@@ -82,14 +82,21 @@ def test_gemm_hp_against_fp64(ops, M, N, K, epi):
     ref = a.double() @ w.double().T + b.double()
     if epi == 1:
         ref = torch.nn.functional.gelu(ref)
+    wpk = ops.pack_weight(w) if (M <= 64 and N % 16 == 0 and K % 32 == 0) else None      # few rows: also through the packed operand layouts (layout 3)
     if epi == 2:
         r = rndf(M, N, seed=13)
         out = r.clone()
         ops.gemm_hp(a_s, w2, b, out=out, epilogue=ops.EPI_RESID, residual=out)      # in place, fp32 residual stream
         assert rel_err(out, ref + r.double()) < 5e-5
+        if wpk is not None:
+            o2 = r.clone()
+            ops.gemm_hp(a_s, w2, b, out=o2, epilogue=ops.EPI_RESID, residual=o2, w_packed=wpk)
+            assert torch.equal(o2, out), "packed operands change the few-row projection's bits"
         return
     out = ops.gemm_hp(a_s, w2, b, epilogue=epi)
     assert out.dtype == F32 and rel_err(out[:, :N], ref) < 5e-5
+    if wpk is not None and epi == 0:
+        assert torch.equal(ops.gemm_hp(a_s, w2, b, epilogue=epi, w_packed=wpk), out), "packed operands change the few-row projection's bits"
     if N % 4 == 0:
         sp = ops.gemm_hp(a_s, w2, b, epilogue=epi, out_mode=ops.OUT_SPLIT)
         assert sp.shape == (M, 2 * N) and rel_err(join(sp, N), ref) < 8e-5
@@ -121,6 +128,9 @@ def test_gemm_hp_split_swiglu_against_fp64(ops, M, I, K, bias):
     ref = torch.nn.functional.silu(g) * u
     h = ops.gemm_hp(a_s, w2, b, epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT)
     assert h.dtype == BF and h.shape == (M, 2 * I)
+    if M <= 64 and K % 32 == 0:
+        hp_ = ops.gemm_hp(a_s, w2, b, epilogue=ops.EPI_SWIGLU, out_mode=ops.OUT_SPLIT, w_packed=ops.pack_weight(interleave16(wg, wu)))
+        assert torch.equal(hp_, h), "packed operands change the few-row split SwiGLU's bits"
     assert rel_err(join(h, I), ref) < 2e-4          # max |d| / rms: gate and up each carry the GEMM's 5e-5-class input rounding, the product both (measured <= 8.5e-5)
     # the unfused form of round 5: fp32 [gate | up] rows, then the SwiGLU kernel
     w2s = torch.cat([torch.cat([wg, wu], 0)] * 2, dim=1).contiguous()
