@@ -28,7 +28,7 @@ extern "C" {
 #endif
 
 /* ---- plumbing --------------------------------------------------------------------------------------------------- */
-int         padt_abi_version(void);                                  /* 4: round 6 (collect summary, output scores, split-operand MFMA attention); 3: round 5; 2: round 4 (fp16 twins) */
+int         padt_abi_version(void);                                  /* 4: round 6 (collect summary, output scores, f32-MFMA attention, padt_gemm_split_rows, padt_argmax_rows_f32, split SwiGLU); 3: round 5; 2: round 4 (fp16 twins) */
 /* The fp16 instantiation stores mirror = fp16(PADT_F16_STREAM_SCALE * X32): a residual stream is un-normalised (checkpoints carry "massive
  * activations" of 1e3-1e4 in a few channels), fp16 ends at 65504, and every consumer of a mirror is scale-invariant — padt_row_rstd_f16 and the
  * fused RMSNorm statistics of padt_gemm_packed_f16 / padt_quant_rows_fp8_f16 return rstd / scale when called with eps * scale^2, which the
