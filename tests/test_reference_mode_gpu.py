@@ -80,6 +80,14 @@ def test_reference_precision_small_config_end_to_end():
     for (d0, c0, l0, v0), (d1, c1, l1, v1) in zip(ref, got):
         assert c0 == c1 and v0 == v1
         assert torch.equal(d0["pred_boxes"], d1["pred_boxes"]) and torch.equal(d0["pred_mask"], d1["pred_mask"])
+    # caller hooks on this mode (round 6): the hooked loop launches the same split-precision steps kernel by kernel — no-op hooks give the captured run's bits,
+    # a stopping criterion ends the sequences where HF's loop would
+    from transformers import LogitsProcessorList, MaxLengthCriteria, StoppingCriteriaList
+    kw = dict(input_ids=ids.cuda(), attention_mask=am.cuda(), pixel_values=pix.cuda(), image_grid_thw=grid, max_new_tokens=T, schedule=sched)
+    same = model.generate(logits_processor=LogitsProcessorList([lambda i, sc: sc]), **kw)
+    assert torch.equal(same.sequences, out.sequences) and torch.equal(same.hidden_states.last_layer_rows(), hid)
+    cut = model.generate(stopping_criteria=StoppingCriteriaList([MaxLengthCriteria(max_length=L + 4)]), **kw)
+    assert torch.equal(cut.sequences, out.sequences[:, : L + 4])
 
 
 def test_reference_precision_full_depth_3b_meets_the_north_star_on_every_float_output():
